@@ -1,0 +1,99 @@
+"""ctypes loaders for the checker libraries -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+* ``load_oracle()``  -> oracle/liboracle.so   (our plain-C restatement, oracle/mscomp_oracle.c)
+* ``load_ref()``     -> oracle/_ref/libMSCompression.so (the real reference compiled by oracle/Makefile
+                        from /root/reference/src; prebuilt file travels to the GPU box) or None.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NONE, LZNT1, XPRESS, XPRESS_HUFF = 0, 2, 3, 4
+FORMATS = {"lznt1": LZNT1, "xpress": XPRESS, "xpress_huff": XPRESS_HUFF}
+
+_oracle = None
+_ref = None
+
+
+def build(force=False):
+    """Compile liboracle.so (and oracle/_ref when /root/reference is present). Building the checker is not using it."""
+    so = os.path.join(HERE, "liboracle.so")
+    src = os.path.join(HERE, "mscomp_oracle.c")
+    need = force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)
+    need_ref = os.path.isdir("/root/reference/src") and not os.path.exists(os.path.join(HERE, "_ref", "libMSCompression.so"))
+    if need or need_ref:
+        subprocess.run(["make", "-C", HERE, "all"], check=True, stdout=subprocess.DEVNULL)
+
+
+def load_oracle():
+    global _oracle
+    if _oracle is None:
+        so = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        lib = C.CDLL(so)
+        lib.orc_compress.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+        lib.orc_compress.restype = C.c_int
+        lib.orc_decompress.argtypes = lib.orc_compress.argtypes
+        lib.orc_decompress.restype = C.c_int
+        lib.orc_max_compressed_size.argtypes = [C.c_int, C.c_size_t]
+        lib.orc_max_compressed_size.restype = C.c_size_t
+        lib.orc_huff_lengths.argtypes = [C.c_void_p, C.c_void_p]
+        lib.orc_huff_lengths_slow.argtypes = [C.c_void_p, C.c_void_p]
+        lib.orc_lznt1_match_table.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
+        lib.orc_xpress_match_table.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.orc_compress_units.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_int]
+        lib.orc_compress_units.restype = C.c_int
+        _oracle = lib
+    return _oracle
+
+
+def load_ref():
+    """The compiled reference, or None when oracle/_ref was not built (no /root/reference at build time)."""
+    global _ref
+    if _ref is None:
+        so = os.path.join(HERE, "_ref", "libMSCompression.so")
+        if not os.path.exists(so):
+            return None
+        lib = C.CDLL(so)
+        for f in (lib.ms_compress, lib.ms_decompress):
+            f.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+            f.restype = C.c_int
+        lib.ms_max_compressed_size.argtypes = [C.c_int, C.c_size_t]
+        lib.ms_max_compressed_size.restype = C.c_size_t
+        _ref = lib
+    return _ref
+
+
+def _one_shot(fn, fmt, data, cap):
+    data = bytes(data)
+    out = C.create_string_buffer(cap + 64)
+    n = C.c_size_t(cap)
+    st = fn(fmt, data, len(data), out, C.byref(n))
+    return st, (out.raw[: n.value] if st == 0 else b"")
+
+
+def oracle_compress(fmt, data, cap=None):
+    lib = load_oracle()
+    if cap is None:
+        cap = lib.orc_max_compressed_size(fmt, len(data))
+    return _one_shot(lib.orc_compress, fmt, data, cap)
+
+
+def oracle_decompress(fmt, data, out_len):
+    return _one_shot(load_oracle().orc_decompress, fmt, data, out_len)
+
+
+def ref_compress(fmt, data, cap=None):
+    lib = load_ref()
+    if cap is None:
+        cap = lib.ms_max_compressed_size(fmt, len(data))
+    return _one_shot(lib.ms_compress, fmt, data, cap)
+
+
+def ref_decompress(fmt, data, out_len):
+    return _one_shot(load_ref().ms_decompress, fmt, data, out_len)

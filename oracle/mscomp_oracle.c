@@ -1,0 +1,661 @@
+/* oracle/mscomp_oracle.c -- TEST INFRASTRUCTURE ONLY (see mscomp_oracle.h for the rules).
+ *
+ * Plain-C restatement of the reference's one-shot encoders, written from the validated pseudocode in
+ * SURVEY.md section 8a. Every function cites the reference file:line whose behaviour it restates.
+ * Data structures are our own (ascending per-key lists for LZNT1, int32 predecessor links for the
+ * Xpress hash chains, an explicit token array for Xpress-Huffman) -- only the observable bytes match.
+ *
+ * Parity status: PINNED against the compiled reference (oracle/_ref) and the SURVEY 8c KAT table;
+ * see tests/test_oracle_vs_ref.py and tests/test_oracle_golden.py.
+ */
+#include "mscomp_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+static inline void put16(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+static inline void put32(uint8_t* p, uint32_t v) { put16(p, v); put16(p + 2, v >> 16); }
+static inline uint32_t get16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+static inline uint32_t get32(const uint8_t* p) { return get16(p) | (get16(p + 2) << 16); }
+static inline unsigned ilog2(uint32_t v) { return 31u - (unsigned)__builtin_clz(v); }
+
+/* ===================================================================================================
+ * sizes  (lznt1_compress.cpp:27, xpress_compress.cpp:30, xpress_huff_compress.cpp:46, mscomp.cpp:33,96-100)
+ * =================================================================================================*/
+size_t orc_max_compressed_size(int format, size_t n)
+{
+	switch (format) {
+	case ORC_NONE:        return n;
+	case ORC_LZNT1:       return n + 3 + 2 * ((n + 4095) / 4096);
+	case ORC_XPRESS:      return n + 4 + 4 * (n / 32);
+	case ORC_XPRESS_HUFF: return n + 34 + 258 + 258 * (n / 65536);
+	default:              return (size_t)-1;
+	}
+}
+
+/* ===================================================================================================
+ * LZNT1
+ * =================================================================================================*/
+#define LZ_NONE 0xFFFFu
+typedef struct {
+	uint32_t stamp[65536];   /* generation in which first[] was last written (avoids the reference's */
+	uint16_t first[65536];   /*  128 KiB memset per chunk, LZNT1Dictionary.h:98)                       */
+	uint16_t next[4096];     /* next position (ascending) with the same 2-byte key                    */
+	uint32_t gen;
+} lznt1_dict;
+
+/* LZNT1Dictionary::Fill (LZNT1Dictionary.h:93-106): every p with p+2<n, keyed by (c[p],c[p+1]),
+ * lists in ascending position order. */
+static void lznt1_fill(lznt1_dict* d, const uint8_t* c, unsigned n)
+{
+	if (++d->gen == 0) { memset(d->stamp, 0, sizeof d->stamp); d->gen = 1; }
+	for (int p = (int)n - 3; p >= 0; --p) {
+		const unsigned k = ((unsigned)c[p] << 8) | c[p + 1];
+		d->next[p] = (d->stamp[k] == d->gen) ? d->first[k] : LZ_NONE;
+		d->first[k] = (uint16_t)p; d->stamp[k] = d->gen;
+	}
+}
+
+/* LZNT1Dictionary::Find (LZNT1Dictionary.h:114-143): ascending scan of the earlier positions with the
+ * same 2-byte key; third byte must match; strictly-longer wins (oldest on ties); stop at max_len. */
+static unsigned lznt1_find(const lznt1_dict* d, const uint8_t* c, unsigned p, unsigned max_len, unsigned* off)
+{
+	unsigned best = 0;
+	if (max_len < 3 || p == 0) { return 0; }
+	const unsigned k = ((unsigned)c[p] << 8) | c[p + 1];
+	for (unsigned q = d->first[k]; q < p; q = d->next[q]) {
+		if (c[q + 2] != c[p + 2]) { continue; }
+		unsigned l = 3;
+		while (l < max_len && c[q + l] == c[p + l]) { ++l; }
+		if (l > best) { best = l; *off = p - q; if (best == max_len) { break; } }
+	}
+	return best;
+}
+
+/* position-dependent split of the 16-bit match token (lznt1_compress.cpp:51,66): a pure function of pos */
+static inline void lznt1_split(unsigned pos, unsigned* shift, unsigned* mask3)
+{
+	unsigned pow2 = 0x10, m = 0x1002, s = 12;
+	while (pow2 < pos) { pow2 <<= 1; m = (m >> 1) + 1; --s; }
+	*shift = s; *mask3 = m;
+}
+
+/* lznt1_compress_chunk (lznt1_compress.cpp:49-94). Returns the payload size, or 0 when the chunk must be
+ * stored raw (running size reaches n, :85-86). out must have room for n bytes. */
+static unsigned lznt1_chunk(lznt1_dict* d, const uint8_t* c, unsigned n, uint8_t* out)
+{
+	unsigned pos = 0, o = 0;
+	lznt1_fill(d, c, n);
+	while (pos < n) {
+		uint8_t grp[16]; unsigned g = 0, flags = 0, i;
+		for (i = 0; i < 8 && pos < n; ++i) {
+			unsigned shift, mask3, off = 0;
+			lznt1_split(pos, &shift, &mask3);
+			const unsigned rem = n - pos, len = lznt1_find(d, c, pos, rem < mask3 ? rem : mask3, &off);
+			if (len >= 3) { put16(grp + g, ((off - 1) << shift) | (len - 3)); g += 2; flags |= 1u << i; pos += len; }
+			else { grp[g++] = c[pos++]; }
+		}
+		if (o + 1 + g >= n) { return 0; }
+		out[o++] = (uint8_t)flags; memcpy(out + o, grp, g); o += g;
+	}
+	return o;
+}
+
+/* lznt1_compress (lznt1_compress.cpp:233-273) */
+static int lznt1_compress_o(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)
+{
+	const size_t cap = *out_len;
+	size_t ip = 0, op = 0;
+	lznt1_dict* d = (lznt1_dict*)calloc(1, sizeof *d);
+	uint8_t tmp[4096 + 16];
+	if (!d) { return ORC_MEM_ERROR; }
+	while (ip < n) {
+		const unsigned sz = (unsigned)((n - ip < 4096) ? n - ip : 4096);
+		unsigned csz = lznt1_chunk(d, in + ip, sz, tmp);
+		const unsigned psz = csz ? csz : sz;
+		if (op + 2 + psz > cap) { free(d); return ORC_BUF_ERROR; }
+		put16(out + op, (csz ? 0xB000u : 0x3000u) | (psz - 1));
+		memcpy(out + op + 2, csz ? tmp : in + ip, psz);
+		op += 2 + psz; ip += sz;
+	}
+	if (cap - op >= 2) { out[op] = out[op + 1] = 0; }   /* End_of_buffer, not counted (:270-271) */
+	*out_len = op;
+	free(d);
+	return ORC_OK;
+}
+
+void orc_lznt1_match_table(const uint8_t* c, unsigned n, uint16_t* len, uint16_t* off)
+{
+	lznt1_dict* d = (lznt1_dict*)calloc(1, sizeof *d);
+	lznt1_fill(d, c, n);
+	for (unsigned p = 0; p < n; ++p) {
+		unsigned shift, mask3, o = 0;
+		lznt1_split(p, &shift, &mask3);
+		const unsigned rem = n - p, l = lznt1_find(d, c, p, rem < mask3 ? rem : mask3, &o);
+		len[p] = (uint16_t)l; off[p] = (uint16_t)(l ? o : 0);
+	}
+	free(d);
+}
+
+/* LZNT1 decoder (format only; used for round trips). */
+static int lznt1_decompress_o(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)
+{
+	const size_t cap = *out_len;
+	size_t ip = 0, op = 0;
+	while (ip + 2 <= n) {
+		const uint32_t hdr = get16(in + ip);
+		if (hdr == 0) { break; }
+		const size_t sz = (hdr & 0xFFF) + 1;
+		ip += 2;
+		if (ip + sz > n) { return ORC_DATA_ERROR; }
+		if (!(hdr & 0x8000)) {
+			if (op + sz > cap) { return ORC_BUF_ERROR; }
+			memcpy(out + op, in + ip, sz); op += sz; ip += sz; continue;
+		}
+		const size_t end = ip + sz, base = op;
+		while (ip < end) {
+			unsigned flags = in[ip++];
+			for (unsigned i = 0; i < 8 && ip < end; ++i, flags >>= 1) {
+				if (!(flags & 1)) { if (op >= cap) { return ORC_BUF_ERROR; } out[op++] = in[ip++]; continue; }
+				if (ip + 2 > end) { return ORC_DATA_ERROR; }
+				unsigned shift, mask3; lznt1_split((unsigned)(op - base), &shift, &mask3);
+				const uint32_t t = get16(in + ip); ip += 2;
+				const size_t off = (t >> shift) + 1; size_t len = (t & ((1u << shift) - 1)) + 3;
+				if (off > op - base) { return ORC_DATA_ERROR; }
+				if (op + len > cap) { return ORC_BUF_ERROR; }
+				while (len--) { out[op] = out[op - off]; ++op; }
+			}
+		}
+	}
+	*out_len = op;
+	return ORC_OK;
+}
+
+/* ===================================================================================================
+ * Xpress hash chains (shared by Xpress and Xpress-Huffman)
+ * =================================================================================================*/
+#define XP_HASH(d, p) (((((uint32_t)(d)[p] & 0x1F) << 10) ^ ((uint32_t)(d)[(p) + 1] << 5) ^ (d)[(p) + 2]) & 0x7FFF)
+typedef struct { int32_t head[32768]; int32_t* pred; size_t inserted; } xp_links;
+
+static int xp_links_init(xp_links* L, size_t n)
+{
+	memset(L->head, 0xFF, sizeof L->head);
+	L->pred = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t));
+	L->inserted = 0;
+	return L->pred ? 0 : -1;
+}
+/* XpressDictionary::Fill (XpressDictionary.h:104-118): insert positions [inserted, upto), upto <= n-2 */
+static void xp_links_insert(xp_links* L, const uint8_t* d, size_t upto)
+{
+	for (size_t p = L->inserted; p < upto; ++p) {
+		const uint32_t h = XP_HASH(d, p);
+		L->pred[p] = L->head[h]; L->head[h] = (int32_t)p;
+	}
+	if (upto > L->inserted) { L->inserted = upto; }
+}
+/* XpressDictionary::Find + GetMatchLength (XpressDictionary.h:145-183, :72-94), Level 3:
+ * MaxChain 11, NiceLength 48 (:30). Returns 2 when nothing of length >= 3 is found. */
+static uint32_t xp_find(const xp_links* L, const uint8_t* d, size_t n, size_t p, uint32_t max_off, uint32_t* off)
+{
+	uint32_t best = 2; int chain = 11;
+	const size_t lim = n - p - 1;                 /* the buffer's final byte is never counted (:88-93) */
+	for (int32_t x = L->pred[p]; chain > 0 && x >= 0 && (size_t)x + max_off >= p; x = L->pred[x], --chain) {
+		if (d[x] != d[p] || d[x + 1] != d[p + 1]) { continue; }
+		size_t l = 2;                             /* third byte is implied equal by the hash (:164) */
+		while (l < lim && d[x + l] == d[p + l]) { ++l; }
+		if (l > best) { best = (uint32_t)l; *off = (uint32_t)(p - x); if (best >= 48) { break; } }
+	}
+	return best;
+}
+
+void orc_xpress_match_table(const uint8_t* d, size_t n, uint32_t max_off, uint32_t* len, uint32_t* off)
+{
+	xp_links L;
+	if (xp_links_init(&L, n)) { return; }
+	if (n > 2) { xp_links_insert(&L, d, n - 2); }
+	for (size_t p = 0; p < n; ++p) {
+		uint32_t o = 0, l = (p + 2 < n) ? xp_find(&L, d, n, p, max_off, &o) : 2;
+		len[p] = l; off[p] = l >= 3 ? o : 0;
+	}
+	free(L.pred);
+}
+
+/* ===================================================================================================
+ * Xpress (plain LZ77)   xpress_compress (xpress_compress.cpp:240-347)
+ * =================================================================================================*/
+static int xpress_compress_o(const uint8_t* d, size_t n, uint8_t* out, size_t* out_len)
+{
+	const size_t cap = *out_len, bound = orc_max_compressed_size(ORC_XPRESS, n);
+	if (n == 0) { if (cap < 4) { return ORC_BUF_ERROR; } put32(out, 0xFFFFFFFFu); *out_len = 4; return ORC_OK; }
+	if (n >= 0x7FFFFFF0u) { return ORC_ARG_ERROR; }
+	uint8_t* o = (cap >= bound) ? out : (uint8_t*)malloc(bound);
+	xp_links L;
+	if (!o || xp_links_init(&L, n)) { if (o && o != out) { free(o); } return ORC_MEM_ERROR; }
+
+	const size_t end2 = n >= 2 ? n - 2 : 0;
+	size_t w = 4, slot = 0, p = 1, filled = 0, half = 0;
+	uint32_t flags = 0; unsigned cnt = 1; int have_half = 0;
+	o[w++] = d[0];
+	while (p < end2) {
+		if (filled <= p) {                       /* ONE lazy 8 KiB Fill per token (:269) */
+			filled = (filled + 0x2000 < end2) ? filled + 0x2000 : end2;
+			xp_links_insert(&L, d, filled);
+		}
+		flags <<= 1;
+		uint32_t off = 0, len = (p < filled) ? xp_find(&L, d, n, p, 0x2000, &off) : 2;  /* lagging fill => literal */
+		if (len < 3) { o[w++] = d[p++]; }
+		else {
+			uint32_t l = len - 3;
+			p += len;
+			put16(o + w, ((off - 1) << 3) | (l < 7 ? l : 7)); w += 2;
+			if (l >= 7) {
+				l -= 7;
+				if (have_half) { o[half] |= (uint8_t)((l < 15 ? l : 15) << 4); have_half = 0; }
+				else { half = w; have_half = 1; o[w++] = (uint8_t)(l < 15 ? l : 15); }
+				if (l >= 15) {
+					l -= 15;
+					o[w++] = (uint8_t)(l < 255 ? l : 255);
+					if (l >= 255) {
+						l += 22;                 /* back to len-3 (:297) */
+						if (l <= 0xFFFF) { put16(o + w, l); w += 2; }
+						else { put16(o + w, 0); put32(o + w + 2, l); w += 6; }
+					}
+				}
+			}
+			flags |= 1;
+		}
+		if (++cnt == 32) { put32(o + slot, flags); cnt = 0; slot = w; w += 4; }
+	}
+	while (p < n) {
+		o[w++] = d[p++]; flags <<= 1;
+		if (++cnt == 32) { put32(o + slot, flags); cnt = 0; slot = w; w += 4; }
+	}
+	flags = cnt ? (flags << (32 - cnt)) | ((1u << (32 - cnt)) - 1) : 0xFFFFFFFFu;
+	put32(o + slot, flags);
+	free(L.pred);
+	if (o != out) {
+		if (w > cap) { free(o); return ORC_BUF_ERROR; }
+		memcpy(out, o, w); free(o);
+	}
+	*out_len = w;
+	return ORC_OK;
+}
+
+/* Xpress decoder (format only; used for round trips). */
+static int xpress_decompress_o(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)
+{
+	const size_t cap = *out_len;
+	size_t ip = 0, op = 0, half = 0; int have_half = 0;
+	while (ip + 4 <= n) {
+		uint32_t flags = get32(in + ip); ip += 4;
+		for (unsigned i = 0; i < 32; ++i, flags <<= 1) {
+			if (ip >= n) { goto done; }
+			if (!(flags & 0x80000000u)) { if (op >= cap) { return ORC_BUF_ERROR; } out[op++] = in[ip++]; continue; }
+			if (ip + 2 > n) { return ORC_DATA_ERROR; }
+			const uint32_t s = get16(in + ip); ip += 2;
+			const size_t off = (s >> 3) + 1; size_t len = s & 7;
+			if (len == 7) {
+				uint32_t nib;
+				if (have_half) { nib = in[half] >> 4; have_half = 0; }
+				else { if (ip >= n) { return ORC_DATA_ERROR; } half = ip; have_half = 1; nib = in[ip++] & 0xF; }
+				len += nib;
+				if (nib == 15) {
+					if (ip >= n) { return ORC_DATA_ERROR; }
+					const uint32_t b = in[ip++]; len += b;
+					if (b == 255) {
+						if (ip + 2 > n) { return ORC_DATA_ERROR; }
+						len = get16(in + ip); ip += 2;
+						if (len == 0) { if (ip + 4 > n) { return ORC_DATA_ERROR; } len = get32(in + ip); ip += 4; }
+					}
+				}
+			}
+			len += 3;
+			if (off > op) { return ORC_DATA_ERROR; }
+			if (op + len > cap) { return ORC_BUF_ERROR; }
+			while (len--) { out[op] = out[op - off]; ++op; }
+		}
+	}
+done:
+	*out_len = op;
+	return ORC_OK;
+}
+
+/* ===================================================================================================
+ * Huffman code construction
+ * =================================================================================================*/
+/* HuffmanEncoder<15,512>::CreateCodes (HuffmanEncoder.h:58-127) with HEAP_PUSH/HEAP_POP (:31-55).
+ * Node ids 1..512 are the symbols, 513.. are internal; key = (count<<8)|depth. */
+typedef struct { uint32_t w[1024]; uint16_t heap[516]; unsigned len; } hheap;
+static inline void hh_push(hheap* h, unsigned x)
+{
+	unsigned j = ++h->len;
+	while (h->w[x] < h->w[h->heap[j >> 1]]) { h->heap[j] = h->heap[j >> 1]; j >>= 1; }
+	h->heap[j] = (uint16_t)x;
+}
+static inline unsigned hh_pop(hheap* h)
+{
+	const unsigned top = h->heap[1], t = h->heap[h->len--];
+	unsigned i = 1;
+	for (;;) {
+		unsigned j = i << 1;
+		if (j > h->len) { break; }
+		if (j < h->len && h->w[h->heap[j + 1]] < h->w[h->heap[j]]) { ++j; }
+		if (h->w[t] < h->w[h->heap[j]]) { break; }
+		h->heap[i] = h->heap[j]; i = j;
+	}
+	h->heap[i] = (uint16_t)t;
+	return top;
+}
+void orc_huff_lengths(const uint32_t counts[512], uint8_t lens[512])
+{
+	hheap h; uint16_t parent[1024];
+	h.w[0] = 0;
+	for (unsigned i = 0; i < 512; ++i) { h.w[i + 1] = (counts[i] ? counts[i] : 1u) << 8; }   /* :69 */
+	for (;;) {
+		h.len = 0; h.heap[0] = 0;
+		for (unsigned i = 1; i <= 512; ++i) { hh_push(&h, i); }
+		unsigned nn = 512;
+		memset(parent, 0, sizeof parent);
+		while (h.len > 1) {
+			const unsigned a = hh_pop(&h), b = hh_pop(&h);
+			const uint32_t da = h.w[a] & 0xFF, db = h.w[b] & 0xFF;
+			++nn; parent[a] = parent[b] = (uint16_t)nn;
+			h.w[nn] = ((h.w[a] & ~0xFFu) + (h.w[b] & ~0xFFu)) | (1 + (da > db ? da : db));
+			hh_push(&h, nn);
+		}
+		int too_long = 0;
+		for (unsigned i = 1; i <= 512; ++i) {
+			unsigned depth = 0;
+			for (unsigned k = i; parent[k]; k = parent[k]) { ++depth; }
+			lens[i - 1] = (uint8_t)depth;
+			if (depth > 15) { too_long = 1; }
+		}
+		if (!too_long) { return; }
+		for (unsigned i = 1; i <= 512; ++i) { h.w[i] = (1 + (h.w[i] >> 9)) << 8; }          /* :100-105 */
+	}
+}
+
+/* stable sort of symbol ids by key[] ascending (sorting.h:28-66 are both stable, so any stable sort agrees) */
+static void stable_sort_syms(uint16_t* s, unsigned n, const uint32_t* key)
+{
+	for (unsigned i = 1; i < n; ++i) {
+		const uint16_t x = s[i]; unsigned j = i;
+		while (j > 0 && key[s[j - 1]] > key[x]) { s[j] = s[j - 1]; --j; }
+		s[j] = x;
+	}
+}
+
+/* HuffmanEncoder<15,512>::CreateCodesSlow (HuffmanEncoder.h:129-226): package-merge over the symbols that
+ * are present; a package is (count, per-symbol multiplicity vector). */
+typedef struct { uint64_t count; uint8_t mult[512]; } pm_pkg;
+void orc_huff_lengths_slow(const uint32_t counts[512], uint8_t lens[512])
+{
+	uint16_t leaf[512]; unsigned nleaf = 0;
+	memset(lens, 0, 512);
+	for (unsigned i = 0; i < 512; ++i) { if (counts[i]) { leaf[nleaf++] = (uint16_t)i; lens[i] = 15; } }
+	stable_sort_syms(leaf, nleaf, counts);
+	if (nleaf == 0) { return; }
+	if (nleaf == 1) { lens[leaf[0]] = 1; return; }
+	pm_pkg* cur = (pm_pkg*)malloc(2 * 512 * sizeof(pm_pkg)), *nxt = cur + 512;
+	unsigned ncur = 0;
+	for (unsigned round = 0; round < 15; ++round) {
+		unsigned ci = 0, li = 0, nn = 0;
+		while ((ncur - ci) + (nleaf - li) > 1) {
+			pm_pkg* g = &nxt[nn++];
+			memset(g, 0, sizeof *g);
+			for (unsigned k = 0; k < 2; ++k) {
+				if (li >= nleaf || (ci < ncur && cur[ci].count < counts[leaf[li]])) {   /* strict: leaf wins ties */
+					g->count += cur[ci].count;
+					for (unsigned s = 0; s < 512; ++s) { g->mult[s] = (uint8_t)(g->mult[s] + cur[ci].mult[s]); }
+					++ci;
+				} else { g->count += counts[leaf[li]]; ++g->mult[leaf[li]]; ++li; }
+			}
+		}
+		if (ci < ncur) { for (unsigned s = 0; s < 512; ++s) { lens[s] = (uint8_t)(lens[s] - cur[ci].mult[s]); } }
+		else if (li < nleaf) { --lens[leaf[li]]; }
+		pm_pkg* t = cur; cur = nxt; nxt = t; ncur = nn;
+	}
+	free(cur < nxt ? cur : nxt);
+}
+
+/* canonical codes by (length, symbol); identical to both HuffmanEncoder.h:109-123 and :214-222 */
+static void canonical_codes(const uint8_t lens[512], uint16_t codes[512])
+{
+	uint32_t code = 0;
+	memset(codes, 0, 512 * sizeof(uint16_t));
+	for (unsigned l = 1; l <= 15; ++l) {
+		for (unsigned s = 0; s < 512; ++s) { if (lens[s] == l) { codes[s] = (uint16_t)code++; } }
+		code <<= 1;
+	}
+}
+
+/* ===================================================================================================
+ * Xpress-Huffman   xpress_huff_compress (xpress_huff_compress.cpp:247-331)
+ * =================================================================================================*/
+typedef struct { uint16_t sym; uint16_t offlow; uint32_t L; } xh_tok;   /* L = len-3 (matches only) */
+
+/* OutputBitstream (Bitstream.h:111-148): MSB-first bits into LE16 words, two word slots reserved ahead,
+ * raw bytes interleaved at the cursor. */
+typedef struct { uint8_t* base; size_t s0, s1, cur; uint32_t acc; unsigned nbits; } obits;
+static void ob_init(obits* b, uint8_t* base) { b->base = base; b->s0 = 0; b->s1 = 2; b->cur = 4; b->acc = 0; b->nbits = 0; }
+static void ob_bits(obits* b, uint32_t v, unsigned k)
+{
+	b->nbits += k;
+	b->acc |= (k ? v : 0) << (32 - b->nbits);
+	if (b->nbits > 16) {
+		put16(b->base + b->s0, b->acc >> 16);
+		b->acc <<= 16; b->nbits -= 16;
+		b->s0 = b->s1; b->s1 = b->cur; b->cur += 2;
+	}
+}
+static size_t ob_finish(obits* b) { put16(b->base + b->s0, b->acc >> 16); put16(b->base + b->s1, 0); return b->cur; }
+
+static size_t xh_emit(const xh_tok* t, size_t nt, const uint8_t* lens, const uint16_t* codes, uint8_t* out)
+{
+	obits b; ob_init(&b, out);
+	for (size_t i = 0; i < nt; ++i) {                                   /* xh_compress_encode (:195-245) */
+		const unsigned s = t[i].sym;
+		ob_bits(&b, codes[s], lens[s]);
+		if (s >= 0x100) {
+			const uint32_t L = t[i].L;
+			if ((s & 0xF) == 0xF) {
+				if (L > 0xFFFF) { out[b.cur] = 0xFF; put16(out + b.cur + 1, 0); put32(out + b.cur + 3, L); b.cur += 7; }
+				else if (L >= 270) { out[b.cur] = 0xFF; put16(out + b.cur + 1, L); b.cur += 3; }
+				else { out[b.cur++] = (uint8_t)(L - 15); }
+			}
+			ob_bits(&b, t[i].offlow, (s >> 4) & 0xF);
+		}
+	}
+	return ob_finish(&b);
+}
+
+static int xpress_huff_compress_o(const uint8_t* d, size_t n, uint8_t* out, size_t* out_len)
+{
+	const size_t cap = *out_len;
+	if (n == 0) { *out_len = 0; return ORC_OK; }                         /* :249 */
+	if (n >= 0x7FFFFFF0u) { return ORC_ARG_ERROR; }
+	xp_links L;
+	xh_tok* tok = (xh_tok*)malloc(65537 * sizeof(xh_tok));
+	uint8_t* tmp = (uint8_t*)malloc(65536 + 600);
+	if (!tok || !tmp || xp_links_init(&L, n)) { free(tok); free(tmp); return ORC_MEM_ERROR; }
+	if (n > 2) { xp_links_insert(&L, d, n - 2); }                       /* links are causal: fill everything up front */
+	size_t op = 0;
+	for (size_t cs = 0; cs < n; cs += 65536) {
+		const size_t ce = (n - cs > 65536) ? cs + 65536 : n;
+		const int last = (ce == n);
+		uint32_t counts[512]; uint8_t lens[512]; uint16_t codes[512];
+		size_t nt = 0, extra = 0;
+		memset(counts, 0, sizeof counts);
+		for (size_t p = cs; p < ce; ) {                                   /* xh_compress_lz77 (:52-153) */
+			const size_t rem = ce - p;
+			uint32_t off = 0, len = (rem >= 3) ? xp_find(&L, d, n, p, 0xFFFF, &off) : 2;
+			if (len >= 3) {
+				if (len > rem) { len = (uint32_t)rem; }
+				const unsigned ob = ilog2(off);
+				const uint32_t l3 = len - 3;
+				tok[nt].sym = (uint16_t)(0x100 | (ob << 4) | (l3 < 15 ? l3 : 15));
+				tok[nt].offlow = (uint16_t)(off ^ (1u << ob)); tok[nt].L = l3;
+				extra += (l3 > 0xFFFF) ? 7 : (l3 >= 270) ? 3 : (l3 >= 15) ? 1 : 0;
+				p += len;
+			} else { tok[nt].sym = d[p++]; tok[nt].offlow = 0; tok[nt].L = 0; }
+			++counts[tok[nt++].sym];
+		}
+		if (last) { tok[nt].sym = 0x100; tok[nt].offlow = 0; tok[nt].L = 0; ++counts[0x100]; ++nt; }   /* EOS (:127-144) */
+		orc_huff_lengths(counts, lens);
+		size_t bits = 16;                                                 /* xh_calc_compressed_len (:181-188) */
+		for (unsigned s = 0; s < 512; ++s) { bits += (size_t)(lens[s] + (s >= 0x100 ? ((s >> 4) & 0xF) : 0)) * counts[s]; }
+		size_t comp = (bits + 15) / 16 * 2 + extra;
+		if (comp > (last ? (ce - cs) + 36 : 65538)) {                     /* fallback (:274-280 / :310-316) */
+			memset(counts, 0, sizeof counts);
+			nt = 0;
+			for (size_t p = cs; p < ce; ++p) { tok[nt].sym = d[p]; tok[nt].offlow = 0; tok[nt].L = 0; ++counts[d[p]]; ++nt; }
+			if (last) { tok[nt].sym = 0x100; tok[nt].offlow = 0; tok[nt].L = 0; ++counts[0x100]; ++nt; }
+			orc_huff_lengths_slow(counts, lens);
+			bits = 16;
+			for (unsigned s = 0; s <= 0x100; ++s) { bits += (size_t)lens[s] * counts[s]; }
+			comp = (bits + 15) / 16 * 2;
+		}
+		if (cap - op < 256 + comp) { free(tok); free(tmp); free(L.pred); return ORC_BUF_ERROR; }
+		canonical_codes(lens, codes);
+		for (unsigned i = 0; i < 256; ++i) { out[op + i] = (uint8_t)(lens[2 * i] | (lens[2 * i + 1] << 4)); }
+		const size_t wrote = xh_emit(tok, nt, lens, codes, tmp);
+		if (wrote != comp) { free(tok); free(tmp); free(L.pred); return ORC_DATA_ERROR; }   /* self-check */
+		memcpy(out + op + 256, tmp, comp);
+		op += 256 + comp;
+	}
+	free(tok); free(tmp); free(L.pred);
+	*out_len = op;
+	return ORC_OK;
+}
+
+/* Xpress-Huffman decoder (format only; used for round trips). */
+static int xpress_huff_decompress_o(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)
+{
+	const size_t cap = *out_len;
+	size_t ip = 0, op = 0;
+	uint16_t* tab = (uint16_t*)malloc(32768 * sizeof(uint16_t));   /* 15-bit prefix -> (sym<<4)|len */
+	if (!tab) { return ORC_MEM_ERROR; }
+	while (ip < n) {
+		uint8_t lens[512]; uint16_t codes[512];
+		if (n - ip < 260) { free(tab); return ORC_DATA_ERROR; }
+		for (unsigned i = 0; i < 256; ++i) { lens[2 * i] = in[ip + i] & 0xF; lens[2 * i + 1] = in[ip + i] >> 4; }
+		ip += 256;
+		canonical_codes(lens, codes);
+		memset(tab, 0, 32768 * sizeof(uint16_t));
+		for (unsigned s = 0; s < 512; ++s) {
+			if (!lens[s]) { continue; }
+			const unsigned lo = (unsigned)codes[s] << (15 - lens[s]), cnt = 1u << (15 - lens[s]);
+			if (lo + cnt > 32768) { free(tab); return ORC_DATA_ERROR; }
+			for (unsigned k = 0; k < cnt; ++k) { tab[lo + k] = (uint16_t)((s << 4) | lens[s]); }
+		}
+		uint32_t bits = (get16(in + ip) << 16) | get16(in + ip + 2);
+		int extra = 16;
+		const size_t chunk_end = op + 65536;
+		ip += 4;
+#define XH_CONSUME(k) do { bits <<= (k); extra -= (int)(k); if (extra < 0) { if (ip + 2 > n) { free(tab); return ORC_DATA_ERROR; } \
+	bits |= get16(in + ip) << (-extra); ip += 2; extra += 16; } } while (0)
+		for (;;) {
+			if (op >= chunk_end) { break; }
+			const unsigned e = tab[bits >> 17];
+			if (!e) { free(tab); return ORC_DATA_ERROR; }
+			const unsigned s = e >> 4;
+			XH_CONSUME(e & 0xF);
+			if (s < 0x100) { if (op >= cap) { free(tab); return ORC_BUF_ERROR; } out[op++] = (uint8_t)s; continue; }
+			/* EOS: all input consumed. (Ambiguous with a real off=1,len=3 match when the EOS code is all
+			 * zero bits -- the reference decoder has the same ambiguity -- so callers of this test helper
+			 * pass cap == original length and we keep decoding while output is still owed.) */
+			if (s == 0x100 && ip >= n && bits == 0 && op >= cap) { goto done; }
+			size_t len = s & 0xF; const unsigned ob = (s >> 4) & 0xF;
+			if (len == 15) {
+				if (ip >= n) { free(tab); return ORC_DATA_ERROR; }
+				len = in[ip++];
+				if (len == 255) {
+					if (ip + 2 > n) { free(tab); return ORC_DATA_ERROR; }
+					len = get16(in + ip); ip += 2;
+					if (len == 0) { if (ip + 4 > n) { free(tab); return ORC_DATA_ERROR; } len = get32(in + ip); ip += 4; }
+					if (len < 15) { free(tab); return ORC_DATA_ERROR; }
+					len -= 15;
+				}
+				len += 15;
+			}
+			len += 3;
+			const size_t off = (ob ? (bits >> (32 - ob)) : 0) + ((size_t)1 << ob);
+			XH_CONSUME(ob);
+			if (off > op) { free(tab); return ORC_DATA_ERROR; }
+			if (op + len > cap) { free(tab); return ORC_BUF_ERROR; }
+			while (len--) { out[op] = out[op - off]; ++op; }
+		}
+#undef XH_CONSUME
+		/* a full 64 KiB chunk was produced. A following chunk needs >= 256+4 bytes; anything shorter is the
+		 * EOS tail of a final chunk that held exactly 64 KiB (its EOS code is still in `bits`). */
+		if (n - ip < 260) { break; }
+	}
+done:
+	free(tab);
+	*out_len = op;
+	return ORC_OK;
+}
+
+/* ===================================================================================================
+ * dispatch   (mscomp.cpp:104-117, :119-134)
+ * =================================================================================================*/
+int orc_compress(int format, const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)
+{
+	switch (format) {
+	case ORC_NONE: if (n > *out_len) { return ORC_BUF_ERROR; } memcpy(out, in, n); *out_len = n; return ORC_OK;
+	case ORC_LZNT1: return lznt1_compress_o(in, n, out, out_len);
+	case ORC_XPRESS: return xpress_compress_o(in, n, out, out_len);
+	case ORC_XPRESS_HUFF: return xpress_huff_compress_o(in, n, out, out_len);
+	default: return ORC_ARG_ERROR;
+	}
+}
+int orc_decompress(int format, const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)
+{
+	switch (format) {
+	case ORC_NONE: if (n > *out_len) { return ORC_BUF_ERROR; } memcpy(out, in, n); *out_len = n; return ORC_OK;
+	case ORC_LZNT1: return lznt1_decompress_o(in, n, out, out_len);
+	case ORC_XPRESS: return xpress_decompress_o(in, n, out, out_len);
+	case ORC_XPRESS_HUFF: return xpress_huff_decompress_o(in, n, out, out_len);
+	default: return ORC_ARG_ERROR;
+	}
+}
+
+/* ===================================================================================================
+ * multi-threaded independent-unit driver (cpu_baseline leg of bench.py, batch parity tests)
+ * =================================================================================================*/
+typedef struct {
+	int format; const uint8_t* in; const uint64_t* in_off; size_t n_units;
+	uint8_t* out; const uint64_t* out_off; uint64_t* out_len; int32_t* status;
+	size_t next; pthread_mutex_t mu;
+} units_job;
+static void* units_worker(void* arg)
+{
+	units_job* j = (units_job*)arg;
+	for (;;) {
+		pthread_mutex_lock(&j->mu);
+		const size_t i0 = j->next, i1 = (i0 + 16 < j->n_units) ? i0 + 16 : j->n_units;
+		j->next = i1;
+		pthread_mutex_unlock(&j->mu);
+		if (i0 >= j->n_units) { return NULL; }
+		for (size_t i = i0; i < i1; ++i) {
+			size_t ol = (size_t)(j->out_off[i + 1] - j->out_off[i]);
+			const int st = orc_compress(j->format, j->in + j->in_off[i], (size_t)(j->in_off[i + 1] - j->in_off[i]),
+			                            j->out + j->out_off[i], &ol);
+			j->status[i] = st; j->out_len[i] = st == ORC_OK ? ol : 0;
+		}
+	}
+}
+int orc_compress_units(int format, const uint8_t* in, const uint64_t* in_off, size_t n_units,
+                       uint8_t* out, const uint64_t* out_off, uint64_t* out_len, int32_t* status, int threads)
+{
+	units_job j = { format, in, in_off, n_units, out, out_off, out_len, status, 0, PTHREAD_MUTEX_INITIALIZER };
+	if (threads < 1) { threads = 1; }
+	if (threads > 256) { threads = 256; }
+	pthread_t th[256]; pthread_attr_t at;
+	pthread_attr_init(&at); pthread_attr_setstacksize(&at, 8u << 20);
+	for (int t = 1; t < threads; ++t) { if (pthread_create(&th[t], &at, units_worker, &j)) { threads = t; break; } }
+	units_worker(&j);
+	for (int t = 1; t < threads; ++t) { pthread_join(th[t], NULL); }
+	pthread_attr_destroy(&at);
+	return 0;
+}
