@@ -1,0 +1,101 @@
+/* include/mscomp_amd.h -- C-ABI of libmscomp_amd.so, the MI355X-native drop-in for the one-shot
+ * compressors of coderforlife/ms-compress.
+ *
+ * Part 1 re-exports, with identical names / argument meaning / error behaviour, exactly the symbols that
+ * the reference's three compressor translation units and its facade export for this path:
+ *
+ *   reference symbol (file:line)                                              -> replaced by
+ *   ms_compress               include/mscomp.h:59,  src/mscomp.cpp:113-117     -> ms_compress
+ *   ms_max_compressed_size    include/mscomp.h:99,  src/mscomp.cpp:96-100      -> ms_max_compressed_size
+ *   lznt1_compress            include/lznt1.h:49,   src/lznt1_compress.cpp:233 -> lznt1_compress
+ *   lznt1_max_compressed_size include/lznt1.h:50,   src/lznt1_compress.cpp:27  -> lznt1_max_compressed_size
+ *   xpress_compress           include/xpress.h:47,  src/xpress_compress.cpp:240-> xpress_compress
+ *   xpress_max_compressed_size include/xpress.h:48, src/xpress_compress.cpp:30 -> xpress_max_compressed_size
+ *   xpress_huff_compress      include/xpress_huff.h:46, src/xpress_huff_compress.cpp:247 -> xpress_huff_compress
+ *   xpress_huff_max_compressed_size include/xpress_huff.h:47, src/xpress_huff_compress.cpp:46 -> (same name)
+ *
+ * These take HOST pointers (the reference contract). Every byte of output is produced by HIP kernels on
+ * the current device; there is no CPU encoder in this library -- if no usable GPU/HIP runtime is present
+ * the calls return MSCOMP_ERRNO and never fall back.
+ *
+ * Part 2 is the additive batch interface the GPU needs (SURVEY.md 8b "batch extension"): many independent
+ * units (buffers) already resident in HBM, compressed in one pass, output written to HBM.
+ *
+ * Plain C types only (no torch / HIP types in any signature; a hipStream_t is passed as void*).
+ */
+#ifndef MSCOMP_AMD_H
+#define MSCOMP_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums: values identical to include/mscomp/general.h:65-93 of the reference ---- */
+typedef enum _MSCompFormat {
+	MSCOMP_NONE = 0, MSCOMP_RESERVED = 1, MSCOMP_LZNT1 = 2, MSCOMP_XPRESS = 3, MSCOMP_XPRESS_HUFF = 4
+} MSCompFormat;
+typedef enum _MSCompStatus {
+	MSCOMP_OK = 0, MSCOMP_STREAM_END = 1, MSCOMP_POSSIBLE_STREAM_END = 2,
+	MSCOMP_ERRNO = -1, MSCOMP_ARG_ERROR = -2, MSCOMP_DATA_ERROR = -3, MSCOMP_MEM_ERROR = -4, MSCOMP_BUF_ERROR = -5
+} MSCompStatus;
+
+/* ================= Part 1: drop-in one-shot interface (host pointers) ================= */
+MSCompStatus ms_compress(MSCompFormat format, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
+size_t       ms_max_compressed_size(MSCompFormat format, size_t in_len);
+
+MSCompStatus lznt1_compress(const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
+size_t       lznt1_max_compressed_size(size_t in_len);
+MSCompStatus xpress_compress(const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
+size_t       xpress_max_compressed_size(size_t in_len);
+MSCompStatus xpress_huff_compress(const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
+size_t       xpress_huff_max_compressed_size(size_t in_len);
+
+/* ================= Part 2: batch interface (device pointers) ================= */
+typedef struct mscomp_amd_ctx  mscomp_amd_ctx;    /* one per (device, stream); owns scratch in HBM  */
+typedef struct mscomp_amd_plan mscomp_amd_plan;   /* unit layout of one batch, uploaded once        */
+
+/* device = HIP ordinal; hip_stream = hipStream_t to launch on (NULL = the null stream). */
+MSCompStatus mscomp_amd_ctx_create(int device, void* hip_stream, mscomp_amd_ctx** ctx);
+void         mscomp_amd_ctx_destroy(mscomp_amd_ctx* ctx);
+
+/* A batch is n_units independent buffers resident in HBM. Unit i is (all four arrays: n_units entries, host memory)
+ *   input    d_in  + in_off[i]  , in_len[i]  bytes
+ *   output   d_out + out_off[i] , out_cap[i] bytes of capacity
+ * and is compressed exactly as one ms_compress(format, ...) call would compress it:
+ *   LZNT1        4 KiB chunks inside the unit, End_of_buffer 00 00 appended when capacity allows
+ *   XPRESS       one Xpress stream per unit
+ *   XPRESS_HUFF  64 KiB chunks inside the unit, matches reach into the previous chunk, EOS in the last
+ * Units must not overlap on the output side. For best load/store width keep in_off[i] and out_off[i] multiples
+ * of 16 (any alignment is accepted). */
+MSCompStatus mscomp_amd_plan_create(mscomp_amd_ctx* ctx, MSCompFormat format, size_t n_units,
+                                    const uint64_t* in_off, const uint64_t* in_len,
+                                    const uint64_t* out_off, const uint64_t* out_cap, mscomp_amd_plan** plan);
+void         mscomp_amd_plan_destroy(mscomp_amd_plan* plan);
+
+/* Asynchronous on the ctx stream. d_out_len[i] (device, uint64) receives the compressed size of unit i,
+ * d_status[i] (device, int32) MSCOMP_OK or MSCOMP_BUF_ERROR (unit did not fit its capacity; its output
+ * bytes are then unspecified). Returns MSCOMP_OK when everything was enqueued, MSCOMP_ERRNO on a HIP error. */
+MSCompStatus mscomp_amd_plan_execute(mscomp_amd_plan* plan, const uint8_t* d_in, uint8_t* d_out,
+                                     uint64_t* d_out_len, int32_t* d_status);
+
+/* Convenience: create plan + execute + stream-synchronize + destroy. */
+MSCompStatus mscomp_amd_compress_batch(mscomp_amd_ctx* ctx, MSCompFormat format, size_t n_units,
+                                       const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len,
+                                       uint8_t* d_out, const uint64_t* out_off, const uint64_t* out_cap,
+                                       uint64_t* d_out_len, int32_t* d_status);
+
+/* ---- measurement hooks (bench.py / profiles) ---- */
+/* When enabled, every kernel launch of plan_execute is bracketed by hipEvents on the ctx stream. */
+void         mscomp_amd_profile_enable(mscomp_amd_ctx* ctx, int on);
+/* Synchronizes the stream, then returns the number of distinct kernels seen since the last reset and fills
+ * up to cap entries: name (static string), accumulated milliseconds, launch count. Resets the counters. */
+int          mscomp_amd_profile_read(mscomp_amd_ctx* ctx, const char** names, double* ms, uint64_t* launches, int cap);
+/* Version / build string of the library (includes the gfx target it was compiled for). */
+const char*  mscomp_amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,289 @@
+// api.hip -- C-ABI of libmscomp_amd.so (include/mscomp_amd.h): context, plan, batch execution and the
+// drop-in one-shot entry points. Host orchestration only; every output byte comes from the HIP kernels.
+//
+// Reference boundary mirrored here: ms_compress / ms_max_compressed_size (/root/reference/src/mscomp.cpp:96-117),
+// lznt1_compress (/root/reference/src/lznt1_compress.cpp:233), xpress_compress (/root/reference/src/xpress_compress.cpp:240),
+// xpress_huff_compress (/root/reference/src/xpress_huff_compress.cpp:247).
+#include "../../include/mscomp_amd.h"
+#include "kernels.h"
+#include <hip/hip_runtime.h>
+#include <new>
+#include <string>
+#include <vector>
+#include <cstring>
+
+using namespace msc;
+
+namespace {
+
+struct DevBuf {
+	void* p = nullptr; size_t cap = 0;
+	bool reserve(size_t n)
+	{
+		if (n <= cap) { return true; }
+		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+		const size_t want = n + n / 8 + 256;
+		if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
+		cap = want; return true;
+	}
+	void release() { if (p) { (void)hipFree(p); } p = nullptr; cap = 0; }
+};
+
+struct ProfRec { const char* name; hipEvent_t a, b; };
+
+} // namespace
+
+struct mscomp_amd_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	DevBuf slots, slot_size, prefix, tile_sums;        // chunk scratch (grow-only, shared by all plans of the ctx)
+	DevBuf one_in, one_out, one_meta;                  // staging of the host-pointer one-shot path
+	bool profiling = false;
+	std::vector<ProfRec> recs;
+	std::vector<hipEvent_t> free_events;
+};
+
+struct mscomp_amd_plan {
+	mscomp_amd_ctx* ctx = nullptr;
+	MSCompFormat format = MSCOMP_NONE;
+	uint32_t n_units = 0, n_chunks = 0;
+	uint64_t total_in = 0;
+	DevBuf tables;                                     // in_off | out_off | chunk_prefix
+	BatchTables bt{};
+};
+
+namespace {
+
+struct DeviceGuard {
+	int prev = -1; bool ok = true;
+	explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; } if (prev != dev) { ok = hipSetDevice(dev) == hipSuccess; } }
+	~DeviceGuard() { int cur = -1; if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) { (void)hipSetDevice(prev); } }
+};
+
+hipEvent_t get_event(mscomp_amd_ctx* c)
+{
+	if (!c->free_events.empty()) { hipEvent_t e = c->free_events.back(); c->free_events.pop_back(); return e; }
+	hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+}
+struct KernelTimer {
+	mscomp_amd_ctx* c; ProfRec r;
+	KernelTimer(mscomp_amd_ctx* ctx, const char* name) : c(ctx), r{name, nullptr, nullptr}
+	{ if (c->profiling) { r.a = get_event(c); r.b = get_event(c); (void)hipEventRecord(r.a, c->stream); } }
+	~KernelTimer() { if (c->profiling) { (void)hipEventRecord(r.b, c->stream); c->recs.push_back(r); } }
+};
+
+uint32_t chunks_of(MSCompFormat f, uint64_t n)
+{
+	switch (f) {
+	case MSCOMP_LZNT1:       return (uint32_t)((n + 4095u) / 4096u);
+	case MSCOMP_XPRESS_HUFF: return (uint32_t)((n + 65535u) / 65536u);   // n==0 -> 0 chunks, 0 bytes of output
+	default:                 return 1;                                   // one Xpress stream per unit
+	}
+}
+
+} // namespace
+
+extern "C" {
+
+const char* mscomp_amd_version(void) { return "mscomp_amd 0.1 (gfx950, HIP; LZNT1/Xpress/Xpress+Huffman one-shot compressors)"; }
+
+size_t lznt1_max_compressed_size(size_t n)       { return n + 3 + 2 * ((n + 4095) / 4096); }
+size_t xpress_max_compressed_size(size_t n)      { return n + 4 + 4 * (n / 32); }
+size_t xpress_huff_max_compressed_size(size_t n) { return n + 34 + 258 + 258 * (n / 65536); }
+size_t ms_max_compressed_size(MSCompFormat f, size_t n)
+{
+	switch ((int)f) {
+	case MSCOMP_NONE:        return n;
+	case MSCOMP_LZNT1:       return lznt1_max_compressed_size(n);
+	case MSCOMP_XPRESS:      return xpress_max_compressed_size(n);
+	case MSCOMP_XPRESS_HUFF: return xpress_huff_max_compressed_size(n);
+	default:                 return (size_t)-1;                          // mscomp.cpp:98
+	}
+}
+
+MSCompStatus mscomp_amd_ctx_create(int device, void* hip_stream, mscomp_amd_ctx** out)
+{
+	if (!out) { return MSCOMP_ARG_ERROR; }
+	*out = nullptr;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { return MSCOMP_ERRNO; }
+	mscomp_amd_ctx* c = new (std::nothrow) mscomp_amd_ctx();
+	if (!c) { return MSCOMP_MEM_ERROR; }
+	c->device = device; c->stream = (hipStream_t)hip_stream;
+	*out = c;
+	return MSCOMP_OK;
+}
+
+void mscomp_amd_ctx_destroy(mscomp_amd_ctx* c)
+{
+	if (!c) { return; }
+	DeviceGuard g(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+	for (auto e : c->free_events) { (void)hipEventDestroy(e); }
+	c->slots.release(); c->slot_size.release(); c->prefix.release(); c->tile_sums.release();
+	c->one_in.release(); c->one_out.release(); c->one_meta.release();
+	delete c;
+}
+
+void mscomp_amd_profile_enable(mscomp_amd_ctx* c, int on) { if (c) { c->profiling = on != 0; } }
+
+int mscomp_amd_profile_read(mscomp_amd_ctx* c, const char** names, double* ms, uint64_t* launches, int cap)
+{
+	if (!c) { return 0; }
+	DeviceGuard g(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	int n = 0;
+	for (auto& r : c->recs) {
+		float t = 0.f; (void)hipEventElapsedTime(&t, r.a, r.b);
+		int k = 0;
+		for (; k < n; ++k) { if (names[k] == r.name) { break; } }
+		if (k == n) { if (n >= cap) { continue; } names[n] = r.name; ms[n] = 0; launches[n] = 0; ++n; }
+		ms[k] += t; launches[k] += 1;
+		c->free_events.push_back(r.a); c->free_events.push_back(r.b);
+	}
+	c->recs.clear();
+	return n;
+}
+
+MSCompStatus mscomp_amd_plan_create(mscomp_amd_ctx* c, MSCompFormat format, size_t n_units,
+                                    const uint64_t* in_off, const uint64_t* in_len,
+                                    const uint64_t* out_off, const uint64_t* out_cap, mscomp_amd_plan** out)
+{
+	if (!out) { return MSCOMP_ARG_ERROR; }
+	*out = nullptr;
+	if (!c || (n_units && (!in_off || !in_len || !out_off || !out_cap)) || n_units > 0x7FFFFFF0u) { return MSCOMP_ARG_ERROR; }
+	if (format != MSCOMP_LZNT1 && format != MSCOMP_XPRESS && format != MSCOMP_XPRESS_HUFF) { return MSCOMP_ARG_ERROR; }
+	DeviceGuard g(c->device);
+	if (!g.ok) { return MSCOMP_ERRNO; }
+	mscomp_amd_plan* p = new (std::nothrow) mscomp_amd_plan();
+	if (!p) { return MSCOMP_MEM_ERROR; }
+	p->ctx = c; p->format = format; p->n_units = (uint32_t)n_units;
+
+	std::vector<uint64_t> host(n_units * 4 + (n_units + 2) / 2 + 1);
+	uint64_t* h = host.data();
+	uint32_t* h_cp = reinterpret_cast<uint32_t*>(h + 4 * n_units);
+	uint64_t chunks = 0, total = 0;
+	for (size_t i = 0; i < n_units; ++i) {
+		h[i] = in_off[i]; h[n_units + i] = in_len[i]; h[2 * n_units + i] = out_off[i]; h[3 * n_units + i] = out_cap[i];
+		h_cp[i] = (uint32_t)chunks;
+		chunks += chunks_of(format, in_len[i]);
+		total += in_len[i];
+		if (chunks > 0x7FFFFFF0u) { delete p; return MSCOMP_ARG_ERROR; }
+	}
+	h_cp[n_units] = (uint32_t)chunks;
+	p->n_chunks = (uint32_t)chunks;
+	p->total_in = total;
+	const size_t bytes = host.size() * sizeof(uint64_t);
+	if (!p->tables.reserve(bytes)) { delete p; return MSCOMP_MEM_ERROR; }
+	if (hipMemcpyAsync(p->tables.p, host.data(), bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+	    hipStreamSynchronize(c->stream) != hipSuccess) { p->tables.release(); delete p; return MSCOMP_ERRNO; }
+	uint64_t* d = static_cast<uint64_t*>(p->tables.p);
+	p->bt.in_off = d; p->bt.in_len = d + n_units; p->bt.out_off = d + 2 * n_units; p->bt.out_cap = d + 3 * n_units;
+	p->bt.chunk_prefix = reinterpret_cast<const uint32_t*>(d + 4 * n_units);
+	p->bt.n_units = p->n_units; p->bt.n_chunks = p->n_chunks;
+
+	// size the ctx scratch now so that execute() never allocates
+	bool ok = c->slot_size.reserve(((size_t)p->n_chunks + 1) * sizeof(uint32_t)) &&
+	          c->prefix.reserve(((size_t)p->n_chunks + 2) * sizeof(uint64_t)) &&
+	          c->tile_sums.reserve(((size_t)p->n_chunks / 1024 + 4) * sizeof(uint64_t));
+	if (ok && format == MSCOMP_LZNT1) { ok = c->slots.reserve((size_t)p->n_chunks * LZNT1_SLOT + 64); }
+	if (!ok) { p->tables.release(); delete p; return MSCOMP_MEM_ERROR; }
+	*out = p;
+	return MSCOMP_OK;
+}
+
+void mscomp_amd_plan_destroy(mscomp_amd_plan* p)
+{
+	if (!p) { return; }
+	DeviceGuard g(p->ctx->device);
+	(void)hipStreamSynchronize(p->ctx->stream);
+	p->tables.release();
+	delete p;
+}
+
+MSCompStatus mscomp_amd_plan_execute(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t* d_out, uint64_t* d_out_len, int32_t* d_status)
+{
+	if (!p || (p->n_units && (!d_out_len || !d_status)) || (p->total_in && !d_in)) { return MSCOMP_ARG_ERROR; }
+	mscomp_amd_ctx* c = p->ctx;
+	DeviceGuard g(c->device);
+	if (!g.ok) { return MSCOMP_ERRNO; }
+	hipStream_t st = c->stream;
+	uint32_t* slot_size = static_cast<uint32_t*>(c->slot_size.p);
+	u64* prefix = static_cast<u64*>(c->prefix.p);
+	u64* tile_sums = static_cast<u64*>(c->tile_sums.p);
+	switch (p->format) {
+	case MSCOMP_LZNT1: {
+		uint8_t* slots = static_cast<uint8_t*>(c->slots.p);
+		{ KernelTimer t(c, "lznt1_chunk_kernel"); launch_lznt1_chunks(st, d_in, p->bt, slots, slot_size); }
+		{ KernelTimer t(c, "scan_sizes"); launch_scan_sizes(st, slot_size, prefix, p->n_chunks, tile_sums); }
+		{ KernelTimer t(c, "concat_slots_kernel"); launch_concat_slots(st, slots, LZNT1_SLOT, slot_size, prefix, p->bt, d_out); }
+		{ KernelTimer t(c, "finalize_units_kernel"); launch_finalize_units(st, prefix, p->bt, d_out, d_out_len, d_status, 1); }
+		break;
+	}
+	default:
+		return MSCOMP_ARG_ERROR;
+	}
+	return hipGetLastError() == hipSuccess ? MSCOMP_OK : MSCOMP_ERRNO;
+}
+
+MSCompStatus mscomp_amd_compress_batch(mscomp_amd_ctx* c, MSCompFormat format, size_t n_units,
+                                       const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len,
+                                       uint8_t* d_out, const uint64_t* out_off, const uint64_t* out_cap,
+                                       uint64_t* d_out_len, int32_t* d_status)
+{
+	mscomp_amd_plan* p = nullptr;
+	MSCompStatus s = mscomp_amd_plan_create(c, format, n_units, in_off, in_len, out_off, out_cap, &p);
+	if (s != MSCOMP_OK) { return s; }
+	s = mscomp_amd_plan_execute(p, d_in, d_out, d_out_len, d_status);
+	DeviceGuard g(c->device);
+	if (hipStreamSynchronize(c->stream) != hipSuccess && s == MSCOMP_OK) { s = MSCOMP_ERRNO; }
+	mscomp_amd_plan_destroy(p);
+	return s;
+}
+
+// ---- drop-in one-shot path (host pointers): H2D, one-unit batch on the GPU, D2H. No CPU encoder exists here. ----
+static MSCompStatus one_shot(MSCompFormat format, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len)
+{
+	if (!out_len || (in_len && !in) || (*out_len && !out)) { return MSCOMP_ARG_ERROR; }
+	thread_local mscomp_amd_ctx* tl_ctx = nullptr;            // reentrant: one context per calling host thread
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) { return MSCOMP_ERRNO; }   // no GPU / no HIP runtime: fail loudly, never fall back
+	if (tl_ctx && tl_ctx->device != dev) { mscomp_amd_ctx_destroy(tl_ctx); tl_ctx = nullptr; }
+	if (!tl_ctx) { MSCompStatus s = mscomp_amd_ctx_create(dev, nullptr, &tl_ctx); if (s != MSCOMP_OK) { return s; } }
+	mscomp_amd_ctx* c = tl_ctx;
+	const size_t cap = *out_len;
+	if (!c->one_in.reserve(in_len + 64) || !c->one_out.reserve(cap + 64) || !c->one_meta.reserve(64)) { return MSCOMP_MEM_ERROR; }
+	const uint64_t in_off[1] = { 0 }, in_ln[1] = { in_len }, out_off[1] = { 0 }, out_cp[1] = { cap };
+	uint8_t* d_in = static_cast<uint8_t*>(c->one_in.p); uint8_t* d_out = static_cast<uint8_t*>(c->one_out.p);
+	uint64_t* d_len = static_cast<uint64_t*>(c->one_meta.p); int32_t* d_st = reinterpret_cast<int32_t*>(d_len + 1);
+	if (in_len && hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, c->stream) != hipSuccess) { return MSCOMP_ERRNO; }
+	MSCompStatus s = mscomp_amd_compress_batch(c, format, 1, d_in, in_off, in_ln, d_out, out_off, out_cp, d_len, d_st);
+	if (s != MSCOMP_OK) { return s; }
+	struct { uint64_t len; int32_t st; int32_t pad; } meta;
+	if (hipMemcpy(&meta, d_len, sizeof meta, hipMemcpyDeviceToHost) != hipSuccess) { return MSCOMP_ERRNO; }
+	if (meta.st != MSCOMP_OK) { return (MSCompStatus)meta.st; }
+	size_t copy = (size_t)meta.len;
+	if (format == MSCOMP_LZNT1 && cap - copy >= 2) { copy += 2; }    // the uncounted End_of_buffer bytes (lznt1_compress.cpp:270)
+	if (copy && hipMemcpy(out, d_out, copy, hipMemcpyDeviceToHost) != hipSuccess) { return MSCOMP_ERRNO; }
+	*out_len = (size_t)meta.len;
+	return MSCOMP_OK;
+}
+
+MSCompStatus lznt1_compress(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)       { return one_shot(MSCOMP_LZNT1, in, n, out, out_len); }
+MSCompStatus xpress_compress(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)      { return one_shot(MSCOMP_XPRESS, in, n, out, out_len); }
+MSCompStatus xpress_huff_compress(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len) { return one_shot(MSCOMP_XPRESS_HUFF, in, n, out, out_len); }
+
+MSCompStatus ms_compress(MSCompFormat format, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len)
+{
+	switch ((int)format) {
+	case MSCOMP_LZNT1: case MSCOMP_XPRESS: case MSCOMP_XPRESS_HUFF: return one_shot(format, in, in_len, out, out_len);
+	case MSCOMP_NONE:                                               // the reference's "copy" codec (mscomp.cpp:26-32): host memcpy
+		if (!out_len || in_len > *out_len) { return out_len ? MSCOMP_BUF_ERROR : MSCOMP_ARG_ERROR; }
+		if (in_len) { memcpy(out, in, in_len); }
+		*out_len = in_len; return MSCOMP_OK;
+	default: return MSCOMP_ARG_ERROR;                                // mscomp.cpp:115
+	}
+}
+
+} // extern "C"

@@ -1,0 +1,21 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (internal to libmscomp_amd.so).
+#pragma once
+#include "common.h"
+
+namespace msc {
+
+// ---- LZNT1 (lznt1.hip) ----
+#define LZNT1_SLOT 4352u     // scratch bytes per 4 KiB chunk image (2 B header + <=4096 B payload + emit slack)
+void launch_lznt1_chunks(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* slots, uint32_t* slot_size);
+
+// ---- utilities (util.hip) ----
+// prefix[0..n] = exclusive scan of sizes[0..n) as u64 (prefix[n] = total). block_sums: scratch of ceil(n/1024)+1 u64.
+void launch_scan_sizes(hipStream_t st, const uint32_t* sizes, u64* prefix, uint32_t n, u64* block_sums);
+// Concatenate the chunk images of every unit into the caller's output (skips units that do not fit).
+void launch_concat_slots(hipStream_t st, const uint8_t* slots, uint32_t slot_stride, const uint32_t* slot_size,
+                         const u64* prefix, const BatchTables& bt, uint8_t* d_out);
+// Per unit: out_len, status (OK / BUF_ERROR); LZNT1 also appends the uncounted 00 00 End_of_buffer when room.
+void launch_finalize_units(hipStream_t st, const u64* prefix, const BatchTables& bt, uint8_t* d_out,
+                           u64* d_out_len, int32_t* d_status, int lznt1_eob);
+
+} // namespace msc
