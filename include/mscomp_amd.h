@@ -92,6 +92,10 @@ void         mscomp_amd_profile_enable(mscomp_amd_ctx* ctx, int on);
 /* Synchronizes the stream, then returns the number of distinct kernels seen since the last reset and fills
  * up to cap entries: name (static string), accumulated milliseconds, launch count. Resets the counters. */
 int          mscomp_amd_profile_read(mscomp_amd_ctx* ctx, const char** names, double* ms, uint64_t* launches, int cap);
+/* Stage-level test hook: per-position matches (len-3 capped at 45, offset; 0 = no match) of ONE device-resident buffer as
+ * found by the HIP hash-chain match finder. max_off = 0x2000 (Xpress) / 0xFFFF with clip=1 (Xpress+Huffman). */
+MSCompStatus mscomp_amd_debug_xpress_matches(mscomp_amd_ctx* ctx, const uint8_t* d_in, size_t in_len, uint32_t max_off, int clip,
+                                             uint16_t* h_len3, uint16_t* h_off);
 /* Version / build string of the library (includes the gfx target it was compiled for). */
 const char*  mscomp_amd_version(void);
 

@@ -37,6 +37,7 @@ struct mscomp_amd_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	DevBuf slots, slot_size, prefix, tile_sums;        // chunk scratch (grow-only, shared by all plans of the ctx)
+	DevBuf links, lasthead, mlen3, moff;               // Xpress-family match finder scratch (per 64 KiB link chunk)
 	DevBuf one_in, one_out, one_meta;                  // staging of the host-pointer one-shot path
 	bool profiling = false;
 	std::vector<ProfRec> recs;
@@ -77,7 +78,7 @@ uint32_t chunks_of(MSCompFormat f, uint64_t n)
 	switch (f) {
 	case MSCOMP_LZNT1:       return (uint32_t)((n + 4095u) / 4096u);
 	case MSCOMP_XPRESS_HUFF: return (uint32_t)((n + 65535u) / 65536u);   // n==0 -> 0 chunks, 0 bytes of output
-	default:                 return 1;                                   // one Xpress stream per unit
+	default:                 return (uint32_t)((n + 65535u) / 65536u);   // Xpress: 64 KiB link chunks (one stream per unit)
 	}
 }
 
@@ -123,6 +124,7 @@ void mscomp_amd_ctx_destroy(mscomp_amd_ctx* c)
 	for (auto e : c->free_events) { (void)hipEventDestroy(e); }
 	c->slots.release(); c->slot_size.release(); c->prefix.release(); c->tile_sums.release();
 	c->one_in.release(); c->one_out.release(); c->one_meta.release();
+	c->links.release(); c->lasthead.release(); c->mlen3.release(); c->moff.release();
 	delete c;
 }
 
@@ -188,6 +190,10 @@ MSCompStatus mscomp_amd_plan_create(mscomp_amd_ctx* c, MSCompFormat format, size
 	          c->prefix.reserve(((size_t)p->n_chunks + 2) * sizeof(uint64_t)) &&
 	          c->tile_sums.reserve(((size_t)p->n_chunks / 1024 + 4) * sizeof(uint64_t));
 	if (ok && format == MSCOMP_LZNT1) { ok = c->slots.reserve((size_t)p->n_chunks * LZNT1_SLOT + 64); }
+	if (ok && format != MSCOMP_LZNT1) {
+		const size_t per = (size_t)p->n_chunks * 65536u * sizeof(uint16_t) + 64;
+		ok = c->links.reserve(per) && c->mlen3.reserve(per) && c->moff.reserve(per) && c->lasthead.reserve(per / 2 + 64);
+	}
 	if (!ok) { p->tables.release(); delete p; return MSCOMP_MEM_ERROR; }
 	*out = p;
 	return MSCOMP_OK;
@@ -221,6 +227,14 @@ MSCompStatus mscomp_amd_plan_execute(mscomp_amd_plan* p, const uint8_t* d_in, ui
 		{ KernelTimer t(c, "finalize_units_kernel"); launch_finalize_units(st, prefix, p->bt, d_out, d_out_len, d_status, 1); }
 		break;
 	}
+	case MSCOMP_XPRESS: {
+		uint16_t* links = static_cast<uint16_t*>(c->links.p); uint16_t* lasthead = static_cast<uint16_t*>(c->lasthead.p);
+		uint16_t* mlen3 = static_cast<uint16_t*>(c->mlen3.p); uint16_t* moff = static_cast<uint16_t*>(c->moff.p);
+		{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
+		{ KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0x2000u, 0); }
+		{ KernelTimer t(c, "xpress_emit_kernel"); launch_xpress_emit(st, d_in, p->bt, mlen3, moff, d_out, d_out_len, d_status); }
+		break;
+	}
 	default:
 		return MSCOMP_ARG_ERROR;
 	}
@@ -240,6 +254,28 @@ MSCompStatus mscomp_amd_compress_batch(mscomp_amd_ctx* c, MSCompFormat format, s
 	if (hipStreamSynchronize(c->stream) != hipSuccess && s == MSCOMP_OK) { s = MSCOMP_ERRNO; }
 	mscomp_amd_plan_destroy(p);
 	return s;
+}
+
+// Stage-level test hook: per-position (len-3 capped at 45, offset) of ONE unit as found by the HIP match finder.
+// h_len3/h_off: host arrays of in_len u16. max_off 0x2000 (Xpress) or 0xFFFF (Xpress+Huffman, clip to 64 KiB chunks).
+MSCompStatus mscomp_amd_debug_xpress_matches(mscomp_amd_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t max_off, int clip,
+                                             uint16_t* h_len3, uint16_t* h_off)
+{
+	if (!c) { return MSCOMP_ARG_ERROR; }
+	const uint64_t z = 0, len = in_len, cap = 0;
+	mscomp_amd_plan* p = nullptr;
+	MSCompStatus s = mscomp_amd_plan_create(c, MSCOMP_XPRESS, 1, &z, &len, &z, &cap, &p);
+	if (s != MSCOMP_OK) { return s; }
+	DeviceGuard g(c->device);
+	uint16_t* links = static_cast<uint16_t*>(c->links.p); uint16_t* lasthead = static_cast<uint16_t*>(c->lasthead.p);
+	uint16_t* mlen3 = static_cast<uint16_t*>(c->mlen3.p); uint16_t* moff = static_cast<uint16_t*>(c->moff.p);
+	launch_xp_links(c->stream, d_in, p->bt, links, lasthead);
+	launch_xp_find(c->stream, d_in, p->bt, links, lasthead, mlen3, moff, max_off, clip);
+	bool ok = hipStreamSynchronize(c->stream) == hipSuccess;
+	ok = ok && hipMemcpy(h_len3, mlen3, in_len * 2, hipMemcpyDeviceToHost) == hipSuccess;
+	ok = ok && hipMemcpy(h_off, moff, in_len * 2, hipMemcpyDeviceToHost) == hipSuccess;
+	mscomp_amd_plan_destroy(p);
+	return ok ? MSCOMP_OK : MSCOMP_ERRNO;
 }
 
 // ---- drop-in one-shot path (host pointers): H2D, one-unit batch on the GPU, D2H. No CPU encoder exists here. ----

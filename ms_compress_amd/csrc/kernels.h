@@ -8,6 +8,17 @@ namespace msc {
 #define LZNT1_SLOT 4352u     // scratch bytes per 4 KiB chunk image (2 B header + <=4096 B payload + emit slack)
 void launch_lznt1_chunks(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* slots, uint32_t* slot_size);
 
+// ---- Xpress / Xpress+Huffman match finder (xpress_match.hip) ----
+// links: u16 per position (64 KiB "link chunks", chunk-major), lasthead: 32768 u16 per link chunk,
+// mlen3/moff: per position len-3 (capped at 48-3) and offset (0 = no match).
+void launch_xp_links(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead);
+void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead,
+                    uint16_t* mlen3, uint16_t* moff, uint32_t max_off, int clip);
+
+// ---- Xpress stream emission (xpress_emit.hip): one wavefront per unit ----
+void launch_xpress_emit(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* mlen3, const uint16_t* moff,
+                        uint8_t* d_out, u64* d_out_len, int32_t* d_status);
+
 // ---- utilities (util.hip) ----
 // prefix[0..n] = exclusive scan of sizes[0..n) as u64 (prefix[n] = total). block_sums: scratch of ceil(n/1024)+1 u64.
 void launch_scan_sizes(hipStream_t st, const uint32_t* sizes, u64* prefix, uint32_t n, u64* block_sums);

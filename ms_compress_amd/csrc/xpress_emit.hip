@@ -1,0 +1,213 @@
+// xpress_emit.hip -- Xpress (plain LZ77) greedy parse + stream emission for gfx950, bit-exact with the reference.
+//
+// Replaces the token loop of xpress_compress (/root/reference/src/xpress_compress.cpp:262-345): greedy selection,
+// the ONE-lazy-Fill-per-token rule (:269, "lagging fill": a position at or beyond `filled` is a forced literal),
+// the 16-bit match symbol + nibble / byte / u16 / u32 length extensions (:274-315) and the 32-token flag words
+// (:317-324, :343-344).
+//
+// One wavefront per unit (an Xpress stream is sequential: flag words and the shared length nibble couple all tokens).
+// Per 64-position window the lanes hold the per-position matches found by xp_find_kernel; the greedy walk runs on
+// the scalar unit over the ballot mask of candidates (one step per MATCH; literal runs are skipped with s_ff1); a
+// chosen match whose length hit the finder's cap (48) is extended by the whole wave, 256 bytes per step. Every
+// output byte position is a prefix sum (SURVEY.md 8a "scan layouts"):
+//   pos(t) = 4*(t div 32 + 1) + sum size(u<t),  size = 1 | 2 + [L>=7 and long-rank even] + [L>=22] + [L>=277]*(2|6)
+// evaluated with mbcnt popcounts and a DPP add-scan; flag bits are OR-ed into an LDS ring of 4 flag words.
+#include "common.h"
+#include "kernels.h"
+
+namespace msc {
+
+__device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v)
+{
+#define MSC_DPP_ADD(ctrl, rmask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, true);
+	MSC_DPP_ADD(0x111, 0xf) MSC_DPP_ADD(0x112, 0xf) MSC_DPP_ADD(0x114, 0xf) MSC_DPP_ADD(0x118, 0xf)
+	MSC_DPP_ADD(0x142, 0xa) MSC_DPP_ADD(0x143, 0xc)
+#undef MSC_DPP_ADD
+	return v;
+}
+
+__device__ __forceinline__ uint32_t ldg32_lim(const uint8_t* __restrict__ d, u64 pos, u64 n)
+{
+	if (pos + 4u <= n) { return ld32(d + pos); }
+	uint32_t v = 0;
+	for (uint32_t k = 0; k < 4u && pos + k < n; ++k) { v |= (uint32_t)d[pos + k] << (8u * k); }
+	return v;
+}
+
+// Number of equal bytes of d[a..] and d[b..] (a < b), at most maxadd; the whole wave compares 256 bytes per step.
+__device__ __forceinline__ u64 wave_extend(const uint8_t* __restrict__ d, u64 a, u64 b, u64 maxadd, u64 n, uint32_t lane)
+{
+	u64 done = 0;
+	while (done < maxadd) {
+		const u64 off = done + 4u * lane;
+		uint32_t x = 0xFFFFFFFFu;                               // lanes beyond the limit report a mismatch
+		if (off < maxadd) { x = ldg32_lim(d, a + off, n) ^ ldg32_lim(d, b + off, n); }
+		const u64 mis = __ballot(x != 0);
+		if (mis) {
+			const uint32_t l = ctz64(mis);
+			const uint32_t xl = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)l);
+			const u64 r = done + 4u * l + ((uint32_t)__builtin_ctz(xl) >> 3);
+			return r < maxadd ? r : maxadd;
+		}
+		done += 256u;
+	}
+	return maxadd;
+}
+
+__device__ __forceinline__ void put8(uint8_t* __restrict__ out, u64 cap, u64 pos, uint32_t v) { if (pos < cap) { out[pos] = (uint8_t)v; } }
+
+__global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
+                                                        const uint16_t* __restrict__ mlen3, const uint16_t* __restrict__ moff,
+                                                        uint8_t* __restrict__ d_out, u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
+{
+	__shared__ uint32_t s_facc[4];
+	__shared__ uint32_t s_fpos[4];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t u = blockIdx.x;
+	const u64 n = bt.in_len[u];
+	const u64 cap = bt.out_cap[u];
+	const uint8_t* __restrict__ d = d_in + bt.in_off[u];
+	uint8_t* __restrict__ out = d_out + bt.out_off[u];
+	const u64 mbase = (u64)bt.chunk_prefix[u] * 65536u;           // this unit's slice of the per-position match arrays
+	const u64 end2 = n >= 2u ? n - 2u : 0u;
+
+	if (lane < 4) { s_facc[lane] = 0; s_fpos[lane] = 0; }
+	__syncthreads();
+
+	u64 cur = 0, F = 0, S = 0, N = 0, R = 0;                      // next token start, filled, sum sizes, tokens, long matches
+	bool pend = false; u64 pend_pos = 0; uint32_t pend_low = 0;   // length nibble byte waiting for its high half
+
+	for (u64 wbase = 0; wbase < n; wbase += 64u) {
+		const u64 wend = (wbase + 64u < n) ? wbase + 64u : n;
+		if (cur >= wend) { continue; }                            // window wholly covered by a match
+		const u64 p = wbase + lane;
+		const bool inr = p < n;
+		uint32_t off = 0, L = 0, byte = 0;
+		if (inr) { off = moff[mbase + p]; L = mlen3[mbase + p]; byte = d[p]; }
+		const u64 mm = __ballot(inr && off != 0 && p >= cur);
+		u64 tokmask = 0, matchmask = 0;
+		while (cur < wend) {
+			if (cur < end2) {
+				if (F <= cur) { F = (F + 0x2000u < end2) ? F + 0x2000u : end2; }          // this token's lazy Fill (:269)
+				if (cur >= F) { tokmask |= ((u64)1) << (cur - wbase); ++cur; continue; }   // lagging fill => literal
+			}
+			const uint32_t rel = (uint32_t)(cur - wbase);
+			const u64 rest = (mm >> rel);
+			if (rest == 0) {
+				tokmask |= (~(u64)0) << rel;
+				const u64 lastp = (wend - 1u < end2) ? wend - 1u : end2;              // fills done by the literal tokens up to wend
+				if (end2 && F <= lastp && lastp < end2) { F = (F + 0x2000u < end2) ? F + 0x2000u : end2; }
+				cur = wend;
+				break;
+			}
+			const uint32_t j = ctz64(rest);
+			const uint32_t mp = rel + j;
+			const u64 pm = wbase + mp;
+			tokmask |= ((((u64)2) << j) - (u64)1) << rel;        // j literals + the match start
+			if (F <= pm) { F = (F + 0x2000u < end2) ? F + 0x2000u : end2; }            // fill by a token in (cur, pm]
+			matchmask |= ((u64)1) << mp;
+			u64 Lm = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)mp);
+			if (Lm == 45u) {                                      // the finder capped this match at 48: extend it
+				const u64 x = pm - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
+				const u64 lim = n - pm - 1u;                        // never count the buffer's final byte
+				Lm = 45u + wave_extend(d, x + 48u, pm + 48u, lim - 48u, n, lane);
+				if (lane == mp) { L = (uint32_t)Lm; }
+			}
+			cur = pm + Lm + 3u;
+		}
+		if (wend - wbase < 64u) { tokmask &= (((u64)1) << (wend - wbase)) - (u64)1; }
+
+		// ---- emit ----------------------------------------------------------------------------------------------
+		const bool is_tok = (tokmask >> lane) & (u64)1;
+		const bool is_m = (matchmask >> lane) & (u64)1;
+		const bool lng = is_m && L >= 7u;
+		const u64 longmask = __ballot(lng);
+		const u64 r = R + popc_below(longmask);
+		const bool even = !(r & 1u);
+		uint32_t sz = 0;
+		if (is_tok) { sz = !is_m ? 1u : 2u + (uint32_t)(lng && even) + (uint32_t)(L >= 22u) + (L >= 277u ? (L <= 0xFFFFu ? 2u : 6u) : 0u); }
+		const uint32_t incl = wave_incl_scan_add(sz);
+		const uint32_t tb = popc_below(tokmask);
+		const u64 t = N + tb;
+		const u64 pos = 4u * (t / 32u + 1u) + S + (incl - sz);
+		// the nibble of the NEXT long match in this window (it shares my byte when my rank is even)
+		const u64 above = (longmask >> lane) >> 1;
+		const uint32_t nib = L >= 7u ? (L - 7u < 15u ? L - 7u : 15u) : 0u;
+		const uint32_t partner = above ? lane + 1u + ctz64(above) : lane;
+		const uint32_t pnib = (uint32_t)__shfl((int)nib, (int)partner, 64);
+		if (is_tok) {
+			if (!is_m) { put8(out, cap, pos, byte); }
+			else {
+				const uint32_t sym = ((off - 1u) << 3) | (L < 7u ? L : 7u);
+				put8(out, cap, pos, sym); put8(out, cap, pos + 1u, sym >> 8);
+				u64 q = pos + 2u;
+				if (lng) {
+					if (even) { put8(out, cap, q, nib | (above ? pnib << 4 : 0u)); ++q; }
+					else if (pend && (longmask & ((((u64)1) << lane) - 1u)) == 0) { put8(out, cap, pend_pos, pend_low | (nib << 4)); }
+					if (L >= 22u) {
+						put8(out, cap, q, L - 22u < 255u ? L - 22u : 255u); ++q;
+						if (L >= 277u) {
+							if (L <= 0xFFFFu) { put8(out, cap, q, L); put8(out, cap, q + 1u, L >> 8); }
+							else {
+								put8(out, cap, q, 0); put8(out, cap, q + 1u, 0);
+								put8(out, cap, q + 2u, L); put8(out, cap, q + 3u, L >> 8); put8(out, cap, q + 4u, L >> 16); put8(out, cap, q + 5u, L >> 24);
+							}
+						}
+					}
+				}
+			}
+			if ((t & 31u) == 0) { __hip_atomic_store(&s_fpos[(t >> 5) & 3u], (uint32_t)(pos - 4u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		if (is_m) { atomicOr(&s_facc[(t >> 5) & 3u], 1u << (31u - (uint32_t)(t & 31u))); }
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		const u64 N2 = N + (uint32_t)__popcll(tokmask);
+		for (u64 g = N / 32u; g < N2 / 32u; ++g) {                // flag words completed in this window
+			if (lane == 0) {
+				const uint32_t wv = __hip_atomic_load(&s_facc[g & 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				const u64 fp = __hip_atomic_load(&s_fpos[g & 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				put8(out, cap, fp, wv); put8(out, cap, fp + 1u, wv >> 8); put8(out, cap, fp + 2u, wv >> 16); put8(out, cap, fp + 3u, wv >> 24);
+				__hip_atomic_store(&s_facc[g & 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		// carry
+		if (longmask) {
+			const uint32_t ll = 63u - (uint32_t)__builtin_clzll(longmask);        // last long match of the window
+			const u64 rl = R + (uint32_t)__popcll(longmask) - 1u;
+			pend = !(rl & 1u);
+			if (pend) {
+				const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pos, (int)ll);
+				const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pos >> 32), (int)ll);
+				pend_pos = (((u64)hi << 32) | lo) + 2u;
+				pend_low = (uint32_t)__builtin_amdgcn_readlane((int)nib, (int)ll);
+			}
+			R += (uint32_t)__popcll(longmask);
+		}
+		N = N2;
+		S += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+	}
+
+	// ---- final flag word (:343-344), size, status ----------------------------------------------------------------
+	const u64 gf = N / 32u;
+	const uint32_t cnt = (uint32_t)(N & 31u);
+	const u64 total = 4u * (gf + 1u) + S;
+	if (lane == 0) {
+		uint32_t wv; u64 fp;
+		if (cnt) { wv = s_facc[gf & 3u] | ((1u << (32u - cnt)) - 1u); fp = s_fpos[gf & 3u]; }
+		else { wv = 0xFFFFFFFFu; fp = total - 4u; }
+		put8(out, cap, fp, wv); put8(out, cap, fp + 1u, wv >> 8); put8(out, cap, fp + 2u, wv >> 16); put8(out, cap, fp + 3u, wv >> 24);
+		const bool ok = total <= cap;
+		d_out_len[u] = ok ? total : 0;
+		d_status[u] = ok ? 0 : -5;
+	}
+}
+
+void launch_xpress_emit(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* mlen3, const uint16_t* moff,
+                        uint8_t* d_out, u64* d_out_len, int32_t* d_status)
+{
+	if (bt.n_units == 0) { return; }
+	hipLaunchKernelGGL(xpress_emit_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, mlen3, moff, d_out, d_out_len, d_status);
+}
+
+} // namespace msc

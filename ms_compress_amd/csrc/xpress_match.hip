@@ -1,0 +1,200 @@
+// xpress_match.hip -- the Xpress / Xpress+Huffman match finder for gfx950: hash-chain links + per-position Find.
+//
+// Replaces XpressDictionary<MaxOffset,ChunkSize,15,.,3>::Fill / Find / GetMatchLength
+// (/root/reference/include/mscomp/XpressDictionary.h:104-118, :145-183, :72-94), used by xpress_compress
+// (/root/reference/src/xpress_compress.cpp:269-271) and xh_compress_lz77 (/root/reference/src/xpress_huff_compress.cpp:60,90).
+//
+// The reference keeps one head table (32768 pointers) + a predecessor ring for the whole buffer and inserts
+// positions serially. Here every 64 KiB slice ("link chunk") of a unit is independent:
+//   xp_links_kernel : one wavefront per link chunk, head table (32768 x u16 = 64 KiB) in LDS. Positions are inserted
+//                     64 at a time: one LDS gather of the heads, ballot-resolved intra-batch hash conflicts, one LDS
+//                     scatter; the predecessor links leave as coalesced u16 stores. pred(p) restricted to the chunk;
+//                     the chunk's final head table is exported so the NEXT chunk can continue a chain into it
+//                     (a chain never needs to reach further back than one chunk: 65535 / 8192 byte windows).
+//   xp_find_kernel  : one thread per position: walks <= 11 links (MaxChain, Level 3) while inside the window,
+//                     candidates must share the first 2 bytes, length by 4-byte XOR compares, strictly-longer wins
+//                     (nearest on ties), stop at >= 48 (NiceLength). Lengths are CAPPED at 48 here: the candidate
+//                     choice never depends on more (48 ends the walk); the parse kernels extend the chosen match.
+//                     The reference's "never count the buffer's final byte" rule (XpressDictionary.h:88-93) is the
+//                     limit n-p-1.
+#include "common.h"
+#include "kernels.h"
+
+namespace msc {
+
+__device__ __forceinline__ uint32_t xp_hash3(uint32_t w)      // w = b0 | b1<<8 | b2<<16  (XpressDictionary.h:57-60 closed form)
+{
+	return (((w & 0x1Fu) << 10) ^ (((w >> 8) & 0xFFu) << 5) ^ ((w >> 16) & 0xFFu)) & 0x7FFFu;
+}
+
+// 4 bytes at unit offset pos (any alignment); bytes at or beyond n read as 0
+__device__ __forceinline__ uint32_t ldg32_safe(const uint8_t* __restrict__ d, u64 pos, u64 n)
+{
+	if (pos + 4u <= n) { return ld32(d + pos); }
+	uint32_t v = 0;
+	for (uint32_t k = 0; k < 4u && pos + k < n; ++k) { v |= (uint32_t)d[pos + k] << (8u * k); }
+	return v;
+}
+
+__global__ __launch_bounds__(64) void xp_links_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
+                                                     uint16_t* __restrict__ links, uint16_t* __restrict__ lasthead)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];          // 64 KiB heads + stage + conflict detector
+	uint16_t* const s_head = reinterpret_cast<uint16_t*>(smem);
+	uint8_t* const s_stage = smem + 65536u;
+	uint8_t* const s_tmp = smem + 65536u + 4096u + 16u;
+
+	const uint32_t lane = threadIdx.x;
+	const uint32_t lc = blockIdx.x;
+	const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, lc);
+	const uint32_t k = lc - bt.chunk_prefix[u];
+	const u64 n = bt.in_len[u];
+	const u64 cbase = (u64)k * 65536u;
+	const uint32_t cn = (n - cbase < 65536u) ? (uint32_t)(n - cbase) : 65536u;            // positions in this chunk
+	const uint32_t ins = (n >= cbase + 3u) ? ((n - 2u - cbase < cn) ? (uint32_t)(n - 2u - cbase) : cn) : 0u;   // p < n-2
+	const uint8_t* __restrict__ src = d_in + bt.in_off[u] + cbase;
+	const u64 avail = n - cbase;                                                          // readable bytes from src
+	uint16_t* __restrict__ lk = links + (u64)lc * 65536u;
+
+	for (uint32_t i = lane * 8u; i < 32768u; i += 512u) { *reinterpret_cast<uint4*>(s_head + i) = make_uint4(~0u, ~0u, ~0u, ~0u); }
+
+	for (uint32_t tbase = 0; tbase < ins; tbase += 4096u) {
+		__syncthreads();
+		// stage 4096+4 bytes (zero beyond the unit end)
+		const bool vec = (((uintptr_t)(src + tbase) & 15u) == 0);
+		for (uint32_t i = lane * 16u; i < 4096u + 16u; i += 1024u) {
+			uint4 v = make_uint4(0, 0, 0, 0);
+			if (vec && (u64)tbase + i + 16u <= avail) { v = *reinterpret_cast<const uint4*>(src + tbase + i); }
+			else {
+				uint32_t w[4] = { 0, 0, 0, 0 };
+				for (uint32_t b = 0; b < 16u; ++b) { if ((u64)tbase + i + b < avail) { w[b >> 2] |= (uint32_t)src[tbase + i + b] << (8u * (b & 3u)); } }
+				v = make_uint4(w[0], w[1], w[2], w[3]);
+			}
+			*reinterpret_cast<uint4*>(s_stage + i) = v;
+		}
+		__syncthreads();
+		const uint32_t tn = (ins - tbase < 4096u) ? ins - tbase : 4096u;
+		for (uint32_t b = 0; b * 64u < tn; ++b) {
+			const uint32_t r = b * 64u + lane;                    // position inside the tile
+			const uint32_t o = tbase + r;                          // position inside the chunk
+			const bool valid = r < tn;
+			const uint32_t h = xp_hash3(ld32(s_stage + r));
+			uint32_t pred = 0xFFFFu;
+			if (valid) {
+				pred = __hip_atomic_load(&s_head[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				__hip_atomic_store(&s_tmp[h & 4095u], (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			const bool loser = valid && __hip_atomic_load(&s_tmp[h & 4095u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) != lane;
+			bool writer = valid;
+			u64 lm = __ballot(loser);
+			while (lm) {                                          // one iteration per hash shared by >1 lane of the batch
+				const uint32_t hh = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)ctz64(lm));
+				const bool grp = valid && h == hh;
+				const u64 g = __ballot(grp);
+				if (grp) {
+					const u64 below = g & ((((u64)1) << lane) - 1u);
+					if (below) { pred = tbase + b * 64u + (63u - (uint32_t)__builtin_clzll(below)); }   // nearest earlier lane
+					writer = (lane == 63u - (uint32_t)__builtin_clzll(g));                             // head = latest position
+				}
+				lm &= ~g;
+			}
+			if (valid) {
+				lk[o] = (uint16_t)pred;
+				if (writer) { __hip_atomic_store(&s_head[h], (uint16_t)o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		}
+	}
+	__syncthreads();
+	if (lc + 1u < bt.chunk_prefix[u + 1]) {                     // a later chunk of this unit continues chains into this one
+		uint16_t* __restrict__ lh = lasthead + (u64)lc * 32768u;
+		for (uint32_t i = lane * 8u; i < 32768u; i += 512u) { *reinterpret_cast<uint4*>(lh + i) = *reinterpret_cast<const uint4*>(s_head + i); }
+	}
+}
+
+// One thread per position. max_off = 0x2000 (Xpress) / 0xFFFF (Xpress+Huffman); clip != 0: positions with fewer than
+// 3 bytes left in their 64 KiB chunk get no match (xpress_huff_compress.cpp:90).
+__global__ __launch_bounds__(256) void xp_find_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
+                                                     const uint16_t* __restrict__ links, const uint16_t* __restrict__ lasthead,
+                                                     uint16_t* __restrict__ mlen3, uint16_t* __restrict__ moff,
+                                                     uint32_t max_off, int clip)
+{
+	const uint32_t lc = blockIdx.x >> 8;
+	const uint32_t o = ((blockIdx.x & 255u) << 8) + threadIdx.x;
+	const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, lc);
+	const uint32_t k = lc - bt.chunk_prefix[u];
+	const u64 n = bt.in_len[u];
+	const u64 cbase = (u64)k * 65536u;
+	const uint32_t cn = (n - cbase < 65536u) ? (uint32_t)(n - cbase) : 65536u;
+	if (o >= cn) { return; }
+	const u64 P = cbase + o;
+	const u64 gi = (u64)lc * 65536u + o;
+	uint32_t best = 2, boff = 0;
+	const bool can = (P + 2u < n) && (!clip || cn - o >= 3u);
+	if (can) {
+		const uint8_t* __restrict__ d = d_in + bt.in_off[u];
+		const uint16_t* __restrict__ lk = links + (u64)lc * 65536u;
+		const uint32_t w = ldg32_safe(d, P, n);
+		const uint32_t h = xp_hash3(w);
+		const u64 lim = n - P - 1u;
+		const uint32_t cap = lim < 48u ? (uint32_t)lim : 48u;
+		uint32_t chain = 11;
+		// The exported head table of the previous chunk cannot distinguish "none" from position 65535 (both 0xFFFF):
+		// 65535 is the head exactly when that chunk's last position has this hash.
+		const bool prev_last = (k > 0) && (xp_hash3(ldg32_safe(d, cbase - 1u, n)) == h);
+		bool inprev = false;
+		uint32_t x = lk[o];
+		bool alive = true;
+		if (x == 0xFFFFu) {
+			if (k == 0) { alive = false; }
+			else { x = lasthead[(u64)(lc - 1u) * 32768u + h]; inprev = true; alive = (x != 0xFFFFu) || prev_last; }
+		}
+		while (alive) {
+			const u64 X = inprev ? cbase - 65536u + x : cbase + x;
+			if (P - X > max_off) { break; }
+			if (ld16(d + X) == (w & 0xFFFFu)) {
+				uint32_t l = 0;
+				while (l < cap) {
+					const uint32_t a = ldg32_safe(d, X + l, n) ^ ldg32_safe(d, P + l, n);
+					if (a) { l += (uint32_t)__builtin_ctz(a) >> 3; break; }
+					l += 4;
+				}
+				if (l > cap) { l = cap; }
+				if (l > best) { best = l; boff = (uint32_t)(P - X); if (best >= 48u) { break; } }
+			}
+			if (--chain == 0) { break; }
+			if (!inprev) {
+				x = lk[x];
+				if (x == 0xFFFFu) {
+					if (k == 0) { break; }
+					x = lasthead[(u64)(lc - 1u) * 32768u + h]; inprev = true;
+					if (x == 0xFFFFu && !prev_last) { break; }
+				}
+			} else {
+				x = links[(u64)(lc - 1u) * 65536u + x];     // a link is always < its position, so 0xFFFF is unambiguous here
+				if (x == 0xFFFFu) { break; }
+			}
+		}
+	}
+	const bool m = best >= 3u;
+	mlen3[gi] = (uint16_t)(m ? best - 3u : 0u);
+	moff[gi] = (uint16_t)(m ? boff : 0u);
+}
+
+void launch_xp_links(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead)
+{
+	if (bt.n_chunks == 0) { return; }
+	const uint32_t lds = 65536u + 4096u + 16u + 4096u;
+	static bool attr_set = false;
+	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_links_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+	hipLaunchKernelGGL(xp_links_kernel, dim3(bt.n_chunks), dim3(64), lds, st, d_in, bt, links, lasthead);
+}
+void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead,
+                    uint16_t* mlen3, uint16_t* moff, uint32_t max_off, int clip)
+{
+	if (bt.n_chunks == 0) { return; }
+	hipLaunchKernelGGL(xp_find_kernel, dim3(bt.n_chunks * 256u), dim3(256), 0, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip);
+}
+
+} // namespace msc
