@@ -235,4 +235,4 @@ def format_supported(fmt):
     return int(fmt) in SUPPORTED
 
 
-SUPPORTED = {MSCOMP_LZNT1, MSCOMP_XPRESS}
+SUPPORTED = {MSCOMP_LZNT1, MSCOMP_XPRESS, MSCOMP_XPRESS_HUFF}

@@ -30,6 +30,7 @@ struct DevBuf {
 };
 
 struct ProfRec { const char* name; hipEvent_t a, b; };
+const uint32_t XH_FB_BLOCKS = 256;                     // resident blocks (and HBM scratch slots) of the fallback kernel
 
 } // namespace
 
@@ -38,6 +39,7 @@ struct mscomp_amd_ctx {
 	hipStream_t stream = nullptr;
 	DevBuf slots, slot_size, prefix, tile_sums;        // chunk scratch (grow-only, shared by all plans of the ctx)
 	DevBuf links, lasthead, mlen3, moff;               // Xpress-family match finder scratch (per 64 KiB link chunk)
+	DevBuf tokbits, counts, extra, lens, codes, fb_list, fbflag, fb_pool;   // Xpress+Huffman per-chunk scratch
 	DevBuf one_in, one_out, one_meta;                  // staging of the host-pointer one-shot path
 	bool profiling = false;
 	std::vector<ProfRec> recs;
@@ -125,6 +127,8 @@ void mscomp_amd_ctx_destroy(mscomp_amd_ctx* c)
 	c->slots.release(); c->slot_size.release(); c->prefix.release(); c->tile_sums.release();
 	c->one_in.release(); c->one_out.release(); c->one_meta.release();
 	c->links.release(); c->lasthead.release(); c->mlen3.release(); c->moff.release();
+	c->tokbits.release(); c->counts.release(); c->extra.release(); c->lens.release(); c->codes.release();
+	c->fb_list.release(); c->fbflag.release(); c->fb_pool.release();
 	delete c;
 }
 
@@ -194,6 +198,12 @@ MSCompStatus mscomp_amd_plan_create(mscomp_amd_ctx* c, MSCompFormat format, size
 		const size_t per = (size_t)p->n_chunks * 65536u * sizeof(uint16_t) + 64;
 		ok = c->links.reserve(per) && c->mlen3.reserve(per) && c->moff.reserve(per) && c->lasthead.reserve(per / 2 + 64);
 	}
+	if (ok && format == MSCOMP_XPRESS_HUFF) {
+		const size_t nc = (size_t)p->n_chunks + 1;
+		ok = c->tokbits.reserve(nc * 1024 * 8) && c->counts.reserve(nc * 512 * 4) && c->extra.reserve(nc * 4) &&
+		     c->lens.reserve(nc * 512) && c->codes.reserve(nc * 1024) && c->fb_list.reserve(nc * 4 + 64) && c->fbflag.reserve(nc * 4) &&
+		     c->fb_pool.reserve((size_t)XH_FB_BLOCKS * xh_fallback_pool_bytes_per_block());
+	}
 	if (!ok) { p->tables.release(); delete p; return MSCOMP_MEM_ERROR; }
 	*out = p;
 	return MSCOMP_OK;
@@ -233,6 +243,23 @@ MSCompStatus mscomp_amd_plan_execute(mscomp_amd_plan* p, const uint8_t* d_in, ui
 		{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
 		{ KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0x2000u, 0); }
 		{ KernelTimer t(c, "xpress_emit_kernel"); launch_xpress_emit(st, d_in, p->bt, mlen3, moff, d_out, d_out_len, d_status); }
+		break;
+	}
+	case MSCOMP_XPRESS_HUFF: {
+		uint16_t* links = static_cast<uint16_t*>(c->links.p); uint16_t* lasthead = static_cast<uint16_t*>(c->lasthead.p);
+		uint16_t* mlen3 = static_cast<uint16_t*>(c->mlen3.p); uint16_t* moff = static_cast<uint16_t*>(c->moff.p);
+		u64* tokbits = static_cast<u64*>(c->tokbits.p); uint32_t* counts = static_cast<uint32_t*>(c->counts.p);
+		uint32_t* extra = static_cast<uint32_t*>(c->extra.p); uint8_t* lens = static_cast<uint8_t*>(c->lens.p);
+		uint16_t* codes = static_cast<uint16_t*>(c->codes.p); uint32_t* fbflag = static_cast<uint32_t*>(c->fbflag.p);
+		uint32_t* fb_count = static_cast<uint32_t*>(c->fb_list.p); uint32_t* fb_list = fb_count + 16;
+		{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
+		{ KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0xFFFFu, 1); }
+		{ KernelTimer t(c, "xh_parse_kernel"); launch_xh_parse(st, d_in, p->bt, mlen3, moff, tokbits, counts, extra); }
+		{ KernelTimer t(c, "xh_huff_kernel"); launch_xh_huff(st, p->bt, counts, extra, lens, codes, slot_size, fb_list, fb_count, fbflag); }
+		{ KernelTimer t(c, "xh_fallback_kernel"); launch_xh_fallback(st, d_in, p->bt, fb_list, fb_count, static_cast<uint8_t*>(c->fb_pool.p), XH_FB_BLOCKS, tokbits, lens, codes, slot_size); }
+		{ KernelTimer t(c, "scan_sizes"); launch_scan_sizes(st, slot_size, prefix, p->n_chunks, tile_sums); }
+		{ KernelTimer t(c, "xh_encode_kernel"); launch_xh_encode(st, d_in, p->bt, mlen3, moff, tokbits, lens, codes, fbflag, prefix, d_out); }
+		{ KernelTimer t(c, "finalize_units_kernel"); launch_finalize_units(st, prefix, p->bt, d_out, d_out_len, d_status, 0); }
 		break;
 	}
 	default:

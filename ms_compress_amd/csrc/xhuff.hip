@@ -1,0 +1,508 @@
+// xhuff.hip -- Xpress+Huffman chunk pipeline for gfx950, bit-exact with the reference CPU encoder.
+//
+// Replaces, per 64 KiB chunk of a unit (/root/reference/src/xpress_huff_compress.cpp:247-331):
+//   xh_parse_kernel    xh_compress_lz77 (:52-153): greedy tokens over the matches of xp_find_kernel (0xFFFF window
+//                      reaching into the previous chunk), length clipped to the chunk (:93), 512-symbol histogram
+//                      (+ EOS 0x100 in the unit's last chunk, :127-144). One wavefront per chunk; scalar walk over
+//                      ballot masks; histogram by LDS atomics. The reference's private intermediate byte buffer is not
+//                      reproduced: tokens stay as (token-start bit mask, per-position len-3 / offset).
+//   xh_huff_kernel     HuffmanEncoder<15,512>::CreateCodes (/root/reference/include/mscomp/HuffmanEncoder.h:58-127):
+//                      the bzip2-style heap is simulated operation for operation (tie-breaking defines the lengths) by
+//                      one lane in LDS, depths / size test (xh_calc_compressed_len :181-188) / canonical codes (:109-123)
+//                      by the whole wave; flags chunks that need the fallback (:274, :310).
+//   xh_fallback_kernel xh_compress_no_matching + CreateCodesSlow (:155-180, HuffmanEncoder.h:129-226): literals only,
+//                      package-merge lengths (packages = per-symbol multiplicity vectors in an HBM scratch pool).
+//   xh_encode_kernel   xh_compress_encode + OutputBitstream (:195-245, Bitstream.h:111-148): every bit/byte position is
+//                      a prefix sum: a WriteBits call that raises flushes(T)=ceil(T/16)-1 to f allocates
+//                      the slot of word f+1 at 4+2(f-1)+R; raw length bytes sit at 4+2*flushes+R. Bits are OR-ed into a
+//                      256-word LDS ring, completed words leave to their slots every window.
+#include "common.h"
+#include "kernels.h"
+
+namespace msc {
+
+__device__ __forceinline__ uint32_t xh_incl_scan_add(uint32_t v)
+{
+#define MSC_DPP_ADD(ctrl, rmask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, true);
+	MSC_DPP_ADD(0x111, 0xf) MSC_DPP_ADD(0x112, 0xf) MSC_DPP_ADD(0x114, 0xf) MSC_DPP_ADD(0x118, 0xf)
+	MSC_DPP_ADD(0x142, 0xa) MSC_DPP_ADD(0x143, 0xc)
+#undef MSC_DPP_ADD
+	return v;
+}
+__device__ __forceinline__ uint32_t xh_wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)xh_incl_scan_add(v), 63); }
+
+__device__ __forceinline__ uint32_t xh_ldg32(const uint8_t* __restrict__ d, u64 pos, u64 n)
+{
+	if (pos + 4u <= n) { return ld32(d + pos); }
+	uint32_t v = 0;
+	for (uint32_t k = 0; k < 4u && pos + k < n; ++k) { v |= (uint32_t)d[pos + k] << (8u * k); }
+	return v;
+}
+// equal bytes of d[a..] and d[b..] (a < b), at most maxadd; 256 bytes per wave step
+__device__ __forceinline__ uint32_t xh_extend(const uint8_t* __restrict__ d, u64 a, u64 b, uint32_t maxadd, u64 n, uint32_t lane)
+{
+	uint32_t done = 0;
+	while (done < maxadd) {
+		const uint32_t off = done + 4u * lane;
+		uint32_t x = 0xFFFFFFFFu;
+		if (off < maxadd) { x = xh_ldg32(d, a + off, n) ^ xh_ldg32(d, b + off, n); }
+		const u64 mis = __ballot(x != 0);
+		if (mis) {
+			const uint32_t l = ctz64(mis);
+			const uint32_t xl = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)l);
+			const uint32_t r = done + 4u * l + ((uint32_t)__builtin_ctz(xl) >> 3);
+			return r < maxadd ? r : maxadd;
+		}
+		done += 256u;
+	}
+	return maxadd;
+}
+
+struct ChunkGeom { uint32_t u, k, cn; u64 n, cbase; bool last; };
+__device__ __forceinline__ ChunkGeom chunk_geom(const BatchTables& bt, uint32_t lc)
+{
+	ChunkGeom g;
+	g.u = unit_of_chunk(bt.chunk_prefix, bt.n_units, lc);
+	g.k = lc - bt.chunk_prefix[g.u];
+	g.n = bt.in_len[g.u];
+	g.cbase = (u64)g.k * 65536u;
+	g.cn = (g.n - g.cbase < 65536u) ? (uint32_t)(g.n - g.cbase) : 65536u;
+	g.last = (lc + 1u == bt.chunk_prefix[g.u + 1]);
+	return g;
+}
+
+// ===================================================================================================================
+// parse: tokens + histogram
+// ===================================================================================================================
+__global__ __launch_bounds__(64) void xh_parse_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
+                                                     uint16_t* __restrict__ mlen3, const uint16_t* __restrict__ moff,
+                                                     u64* __restrict__ tokbits, uint32_t* __restrict__ counts, uint32_t* __restrict__ extra)
+{
+	__shared__ uint32_t s_cnt[512];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t lc = blockIdx.x;
+	const ChunkGeom g = chunk_geom(bt, lc);
+	const uint8_t* __restrict__ d = d_in + bt.in_off[g.u];
+	const u64 gbase = (u64)lc * 65536u;
+	for (uint32_t i = lane; i < 512u; i += 64u) { s_cnt[i] = 0; }
+	__syncthreads();
+
+	uint32_t cur = 0, xtra = 0;                                  // next token start (offset in chunk), sum of raw length bytes
+	for (uint32_t wbase = 0; wbase < g.cn; wbase += 64u) {
+		const uint32_t wend = (wbase + 64u < g.cn) ? wbase + 64u : g.cn;
+		if (cur >= wend) { if (lane == 0) { tokbits[(u64)lc * 1024u + (wbase >> 6)] = 0; } continue; }
+		const uint32_t o = wbase + lane;
+		const bool inr = o < g.cn;
+		uint32_t off = 0, L = 0, byte = 0;
+		if (inr) { off = moff[gbase + o]; L = mlen3[gbase + o]; byte = d[g.cbase + o]; }
+		const u64 mm = __ballot(inr && off != 0 && o >= cur);
+		u64 tokmask = 0, matchmask = 0;
+		while (cur < wend) {
+			const uint32_t rel = cur - wbase;
+			const u64 rest = mm >> rel;
+			if (rest == 0) { tokmask |= (~(u64)0) << rel; cur = wend; break; }
+			const uint32_t j = ctz64(rest);
+			const uint32_t mp = rel + j;
+			const uint32_t om = wbase + mp;
+			tokmask |= ((((u64)2) << j) - (u64)1) << rel;
+			matchmask |= ((u64)1) << mp;
+			uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)mp) + 3u;
+			const uint32_t rem = g.cn - om;                        // bytes left in the chunk (>= 3 for a candidate)
+			if (len == 48u && rem > 48u) {                         // capped by the finder: extend, at most to the chunk end
+				const u64 P = g.cbase + om;
+				const u64 X = P - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
+				const u64 lim = g.n - P - 1u;                      // never count the buffer's final byte
+				const uint32_t maxadd = (uint32_t)((lim < rem ? lim : rem) - 48u);
+				len = 48u + xh_extend(d, X + 48u, P + 48u, maxadd, g.n, lane);
+			}
+			if (len > rem) { len = rem; }                          // :93
+			if (lane == mp) { L = len - 3u; }
+			cur = om + len;
+		}
+		if (wend - wbase < 64u) { tokmask &= (((u64)1) << (wend - wbase)) - (u64)1; }
+		const bool is_tok = (tokmask >> lane) & (u64)1;
+		const bool is_m = (matchmask >> lane) & (u64)1;
+		if (is_m) { mlen3[gbase + o] = (uint16_t)L; }
+		if (lane == 0) { tokbits[(u64)lc * 1024u + (wbase >> 6)] = tokmask; }
+		uint32_t raw = 0;
+		if (is_tok) {
+			uint32_t sym = byte;
+			if (is_m) {
+				const uint32_t ob = 31u - (uint32_t)__builtin_clz(off);
+				sym = 0x100u | (ob << 4) | (L < 15u ? L : 15u);
+				raw = L >= 270u ? 3u : (L >= 15u ? 1u : 0u);
+			}
+			atomicAdd(&s_cnt[sym], 1u);
+		}
+		xtra += xh_wave_sum(raw);
+	}
+	__syncthreads();
+	if (g.last && lane == 0) { s_cnt[0x100] += 1u; }               // EOS (:127-144)
+	__syncthreads();
+	for (uint32_t i = lane; i < 512u; i += 64u) { counts[(u64)lc * 512u + i] = s_cnt[i]; }
+	if (lane == 0) { extra[lc] = xtra; }
+}
+
+// ===================================================================================================================
+// Huffman lengths (heap), size, canonical codes
+// ===================================================================================================================
+struct HuffLds {
+	uint32_t w[1024];      // node weights: (count<<8)|depth ; w[0] = 0 sentinel
+	uint16_t heap[516];
+	uint16_t parent[1024];
+	uint32_t cnt[512];
+	uint8_t  lens[512];
+	uint16_t codes[512];
+	uint32_t flag;
+};
+
+// HEAP_PUSH / HEAP_POP (HuffmanEncoder.h:31-55), executed by ONE lane
+__device__ __forceinline__ void hh_push(HuffLds& h, uint32_t& hl, uint32_t x)
+{
+	uint32_t j = ++hl;
+	const uint32_t wx = h.w[x];
+	while (wx < h.w[h.heap[j >> 1]]) { h.heap[j] = h.heap[j >> 1]; j >>= 1; }
+	h.heap[j] = (uint16_t)x;
+}
+__device__ __forceinline__ uint32_t hh_pop(HuffLds& h, uint32_t& hl)
+{
+	const uint32_t top = h.heap[1], t = h.heap[hl--];
+	const uint32_t wt = h.w[t];
+	uint32_t i = 1;
+	for (;;) {
+		uint32_t j = i << 1;
+		if (j > hl) { break; }
+		uint32_t cj = h.heap[j], wj = h.w[cj];
+		if (j < hl) { const uint32_t c2 = h.heap[j + 1], w2 = h.w[c2]; if (w2 < wj) { ++j; cj = c2; wj = w2; } }
+		if (wt < wj) { break; }
+		h.heap[i] = (uint16_t)cj; i = j;
+	}
+	h.heap[i] = (uint16_t)t;
+	return top;
+}
+
+// CreateCodes lengths from h.cnt -> h.lens (whole wave enters; lane 0 runs the heap)
+__device__ void huff_lengths_fast(HuffLds& h, uint32_t lane)
+{
+	for (uint32_t i = lane; i < 512u; i += 64u) { const uint32_t c = h.cnt[i]; h.w[i + 1u] = (c ? c : 1u) << 8; }   // :69
+	if (lane == 0) { h.w[0] = 0; }
+	__syncthreads();
+	for (;;) {
+		for (uint32_t i = lane; i < 1024u; i += 64u) { h.parent[i] = 0; }
+		__syncthreads();
+		if (lane == 0) {
+			uint32_t hl = 0; h.heap[0] = 0;
+			for (uint32_t i = 1; i <= 512u; ++i) { hh_push(h, hl, i); }
+			uint32_t nn = 512;
+			while (hl > 1) {
+				const uint32_t a = hh_pop(h, hl), b = hh_pop(h, hl);
+				const uint32_t wa = h.w[a], wb = h.w[b];
+				const uint32_t da = wa & 0xFFu, db = wb & 0xFFu;
+				++nn; h.parent[a] = (uint16_t)nn; h.parent[b] = (uint16_t)nn;
+				h.w[nn] = ((wa & ~0xFFu) + (wb & ~0xFFu)) | (1u + (da > db ? da : db));
+				hh_push(h, hl, nn);
+			}
+		}
+		__syncthreads();
+		bool too_long = false;
+		for (uint32_t i = lane + 1u; i <= 512u; i += 64u) {
+			uint32_t depth = 0;
+			for (uint32_t k = i; h.parent[k]; k = h.parent[k]) { ++depth; }
+			h.lens[i - 1u] = (uint8_t)depth;
+			too_long |= depth > 15u;
+		}
+		if (!__ballot(too_long)) { break; }
+		__syncthreads();
+		for (uint32_t i = lane + 1u; i <= 512u; i += 64u) { h.w[i] = (1u + (h.w[i] >> 9)) << 8; }    // :100-105
+		__syncthreads();
+	}
+	__syncthreads();
+}
+
+// canonical codes by (length, symbol) for the symbols with lens != 0 (HuffmanEncoder.h:109-123 / :214-222 agree)
+__device__ void huff_canonical(HuffLds& h, uint32_t lane)
+{
+	uint32_t mylen[8];
+	#pragma unroll
+	for (int k = 0; k < 8; ++k) { mylen[k] = h.lens[lane * 8u + k]; }
+	uint32_t code = 0;
+	for (uint32_t l = 1; l <= 15u; ++l) {
+		uint32_t mine = 0;
+		#pragma unroll
+		for (int k = 0; k < 8; ++k) { mine += (mylen[k] == l); }
+		const uint32_t incl = xh_incl_scan_add(mine);
+		uint32_t c = code + incl - mine;
+		#pragma unroll
+		for (int k = 0; k < 8; ++k) { if (mylen[k] == l) { h.codes[lane * 8u + k] = (uint16_t)c++; } }
+		code = (code + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63)) << 1;
+	}
+	#pragma unroll
+	for (int k = 0; k < 8; ++k) { if (mylen[k] == 0) { h.codes[lane * 8u + k] = 0; } }
+}
+
+__device__ __forceinline__ void huff_store(const HuffLds& h, uint32_t lane, uint8_t* __restrict__ lens_out, uint16_t* __restrict__ codes_out)
+{
+	reinterpret_cast<uint2*>(lens_out)[lane] = reinterpret_cast<const uint2*>(h.lens)[lane];
+	reinterpret_cast<uint4*>(codes_out)[lane] = reinterpret_cast<const uint4*>(h.codes)[lane];
+}
+
+__global__ __launch_bounds__(64) void xh_huff_kernel(BatchTables bt, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ extra,
+                                                    uint8_t* __restrict__ lens_out, uint16_t* __restrict__ codes_out,
+                                                    uint32_t* __restrict__ chunk_size, uint32_t* __restrict__ fb_list, uint32_t* __restrict__ fb_count,
+                                                    uint32_t* __restrict__ fbflag)
+{
+	__shared__ HuffLds h;
+	const uint32_t lane = threadIdx.x;
+	const uint32_t lc = blockIdx.x;
+	const ChunkGeom g = chunk_geom(bt, lc);
+	for (uint32_t i = lane; i < 512u; i += 64u) { h.cnt[i] = counts[(u64)lc * 512u + i]; }
+	__syncthreads();
+	huff_lengths_fast(h, lane);
+	// xh_calc_compressed_len (:181-188): 16 + sum (len + offset bits) * count, rounded to 16-bit words, + raw length bytes
+	uint32_t bits = 0;
+	for (uint32_t s = lane; s < 512u; s += 64u) { bits += ((uint32_t)h.lens[s] + (s >= 0x100u ? ((s >> 4) & 0xFu) : 0u)) * h.cnt[s]; }
+	bits = 16u + xh_wave_sum(bits);
+	const uint32_t comp = (bits + 15u) / 16u * 2u + extra[lc];
+	const uint32_t limit = g.last ? g.cn + 36u : 65538u;         // :310 / :274
+	if (comp > limit) {
+		if (lane == 0) { fb_list[atomicAdd(fb_count, 1u)] = lc; chunk_size[lc] = 0; fbflag[lc] = 1; }
+		return;
+	}
+	huff_canonical(h, lane);
+	__syncthreads();
+	huff_store(h, lane, lens_out + (u64)lc * 512u, codes_out + (u64)lc * 512u);
+	if (lane == 0) { chunk_size[lc] = 256u + comp; fbflag[lc] = 0; }
+}
+
+// ===================================================================================================================
+// fallback: literals only + package-merge (CreateCodesSlow)
+// ===================================================================================================================
+// scratch per resident block: two generations of <=512 packages, each a 512-byte multiplicity vector -> 512 KiB
+#define XH_FB_POOL_BYTES (2u * 512u * 512u)
+
+__global__ __launch_bounds__(512) void xh_fallback_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
+                                                         const uint32_t* __restrict__ fb_list, const uint32_t* __restrict__ fb_count,
+                                                         uint8_t* __restrict__ pool, u64* __restrict__ tokbits,
+                                                         uint8_t* __restrict__ lens_out, uint16_t* __restrict__ codes_out, uint32_t* __restrict__ chunk_size)
+{
+	__shared__ HuffLds h;
+	__shared__ uint16_t s_leaf[512];
+	__shared__ u64 s_pc[2][512];                                   // package counts, two generations
+	__shared__ uint32_t s_n[4];
+	const uint32_t tid = threadIdx.x;
+	uint8_t* gen[2] = { pool + (u64)blockIdx.x * XH_FB_POOL_BYTES, pool + (u64)blockIdx.x * XH_FB_POOL_BYTES + 512u * 512u };
+	const uint32_t nfb = *fb_count;
+	for (uint32_t it = blockIdx.x; it < nfb; it += gridDim.x) {
+		const uint32_t lc = fb_list[it];
+		const ChunkGeom g = chunk_geom(bt, lc);
+		const uint8_t* __restrict__ d = d_in + bt.in_off[g.u] + g.cbase;
+		__syncthreads();
+		h.cnt[tid] = 0;
+		__syncthreads();
+		for (uint32_t i = tid; i < g.cn; i += 512u) { atomicAdd(&h.cnt[d[i]], 1u); }     // xh_compress_no_matching (:155-180)
+		for (uint32_t w = tid; w < 1024u; w += 512u) {                                   // every position is a literal token
+			const uint32_t lo = w * 64u;
+			tokbits[(u64)lc * 1024u + w] = lo >= g.cn ? 0 : (g.cn - lo >= 64u ? ~(u64)0 : ((((u64)1) << (g.cn - lo)) - 1u));
+		}
+		__syncthreads();
+		if (tid == 0 && g.last) { h.cnt[0x100] += 1u; }
+		__syncthreads();
+		// present symbols, stable-sorted by count (ties: symbol order)  -- rank = #{(count, sym) smaller}
+		const uint32_t myc = h.cnt[tid];
+		h.lens[tid] = myc ? 15 : 0;
+		uint32_t rank = 0;
+		if (myc) { for (uint32_t s = 0; s < 512u; ++s) { const uint32_t c = h.cnt[s]; rank += (c != 0) && (c < myc || (c == myc && s < tid)); } }
+		if (tid == 0) { s_n[0] = 0; }
+		__syncthreads();
+		if (myc) { s_leaf[rank] = (uint16_t)tid; atomicAdd(&s_n[0], 1u); }
+		__syncthreads();
+		const uint32_t nleaf = s_n[0];
+		if (nleaf == 1) { if (myc) { h.lens[tid] = 1; } }
+		else {
+			uint32_t ncur = 0;
+			int mylen = myc ? 15 : 0;
+			for (uint32_t round = 0; round < 15u; ++round) {
+				uint8_t* cur = gen[round & 1u]; uint8_t* nxt = gen[(round & 1u) ^ 1u];
+				const u64* pc = s_pc[round & 1u]; u64* pn = s_pc[(round & 1u) ^ 1u];
+				uint32_t ci = 0, li = 0, nn = 0;
+				while ((ncur - ci) + (nleaf - li) > 1u) {             // every thread runs the same (uniform) merge decisions
+					u64 cnt = 0; uint32_t m = 0;
+					for (int e = 0; e < 2; ++e) {
+						if (li >= nleaf || (ci < ncur && pc[ci] < (u64)h.cnt[s_leaf[li]])) {     // strict: the leaf wins ties
+							cnt += pc[ci]; m += cur[(u64)ci * 512u + tid]; ++ci;
+						} else { const uint32_t lf = s_leaf[li]; cnt += h.cnt[lf]; m += (lf == tid); ++li; }
+					}
+					nxt[(u64)nn * 512u + tid] = (uint8_t)m;
+					if (tid == 0) { pn[nn] = cnt; }
+					++nn;
+				}
+				if (ci < ncur) { mylen -= cur[(u64)ci * 512u + tid]; }                    // the leftover item is dropped
+				else if (li < nleaf) { mylen -= (s_leaf[li] == tid); }
+				ncur = nn;
+				__syncthreads();
+			}
+			h.lens[tid] = (uint8_t)mylen;
+		}
+		__syncthreads();
+		// size: xh_calc_compressed_len_no_matching (:189-194)
+		if (tid < 64u) {
+			uint32_t bits = 0;
+			for (uint32_t s = tid; s <= 0x100u; s += 64u) { bits += (uint32_t)h.lens[s] * h.cnt[s]; }
+			bits = 16u + xh_wave_sum(bits);
+			if (tid == 0) { chunk_size[lc] = 256u + (bits + 15u) / 16u * 2u; }
+		}
+		__syncthreads();
+		if (tid < 64u) { huff_canonical(h, tid); }
+		__syncthreads();
+		if (tid < 64u) { huff_store(h, tid, lens_out + (u64)lc * 512u, codes_out + (u64)lc * 512u); }
+	}
+}
+
+// ===================================================================================================================
+// encode
+// ===================================================================================================================
+__global__ __launch_bounds__(64) void xh_encode_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
+                                                      const uint16_t* __restrict__ mlen3, const uint16_t* __restrict__ moff,
+                                                      const u64* __restrict__ tokbits, const uint8_t* __restrict__ lens_in, const uint16_t* __restrict__ codes_in,
+                                                      const uint32_t* __restrict__ fbflag,
+                                                      const u64* __restrict__ prefix, uint8_t* __restrict__ d_out)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t  s_lens[512];
+	__shared__ __attribute__((aligned(16))) uint16_t s_codes[512];
+	__shared__ uint32_t s_bits[128];                               // ring of 256 16-bit words (word w = half (w&1) of dword (w&255)>>1)
+	__shared__ uint32_t s_slot[256];                               // byte position of word w (mod 256)
+	const uint32_t lane = threadIdx.x;
+	const uint32_t lc = blockIdx.x;
+	const ChunkGeom g = chunk_geom(bt, lc);
+	const u64 ustart = prefix[bt.chunk_prefix[g.u]];
+	const u64 utotal = prefix[bt.chunk_prefix[g.u + 1]] - ustart;
+	if (utotal > bt.out_cap[g.u]) { return; }                     // BUF_ERROR unit
+	uint8_t* __restrict__ out = d_out + bt.out_off[g.u] + (prefix[lc] - ustart);
+	const uint8_t* __restrict__ d = d_in + bt.in_off[g.u] + g.cbase;
+	const u64 gbase = (u64)lc * 65536u;
+	const bool fallback = fbflag[lc] != 0;                        // literals only: ignore the match arrays
+
+	reinterpret_cast<uint2*>(s_lens)[lane] = reinterpret_cast<const uint2*>(lens_in + (u64)lc * 512u)[lane];
+	reinterpret_cast<uint4*>(s_codes)[lane] = reinterpret_cast<const uint4*>(codes_in + (u64)lc * 512u)[lane];
+	s_bits[lane] = 0; s_bits[lane + 64u] = 0;
+	if (lane == 0) { s_slot[0] = 0; s_slot[1] = 2; }
+	__syncthreads();
+	// 256-byte table: lens[2i] | lens[2i+1] << 4   (:284 / :320)
+	{
+		const uint32_t a = reinterpret_cast<const uint32_t*>(s_lens)[lane * 2u], b = reinterpret_cast<const uint32_t*>(s_lens)[lane * 2u + 1u];
+		const uint32_t pa = (a & 0xFu) | ((a >> 4) & 0xF0u) | ((a >> 8) & 0xF00u) | ((a >> 12) & 0xF000u);
+		const uint32_t pb = (b & 0xFu) | ((b >> 4) & 0xF0u) | ((b >> 8) & 0xF00u) | ((b >> 12) & 0xF000u);
+		const uint32_t v = pa | (pb << 16);
+		out[lane * 4u] = (uint8_t)v; out[lane * 4u + 1u] = (uint8_t)(v >> 8); out[lane * 4u + 2u] = (uint8_t)(v >> 16); out[lane * 4u + 3u] = (uint8_t)(v >> 24);
+	}
+	uint8_t* __restrict__ bs = out + 256u;                         // the chunk's bitstream
+
+	uint32_t T = 0, R = 0, Wdone = 0;                            // bits so far, raw bytes so far, words already stored
+#define XH_F(t) ((t) ? (((t) - 1u) >> 4) : 0u)                    /* flushes after t bits */
+#define XH_ORBITS(val, len, at) { const uint32_t w0_ = (at) >> 4, b_ = (at) & 15u; \
+		if (b_ + (len) <= 16u) { atomicOr(&s_bits[(w0_ & 255u) >> 1], (((val) << (16u - b_ - (len))) & 0xFFFFu) << ((w0_ & 1u) * 16u)); } \
+		else { atomicOr(&s_bits[(w0_ & 255u) >> 1], (((val) >> (b_ + (len) - 16u)) & 0xFFFFu) << ((w0_ & 1u) * 16u)); \
+		       atomicOr(&s_bits[((w0_ + 1u) & 255u) >> 1], (((val) << (32u - b_ - (len))) & 0xFFFFu) << (((w0_ + 1u) & 1u) * 16u)); } }
+	const uint32_t nwin = (g.cn + 63u) >> 6;
+	for (uint32_t w = 0; w <= nwin; ++w) {
+		// window w < nwin: the tokens starting in it; w == nwin: the EOS token of the unit's last chunk (lane 0)
+		uint32_t clen = 0, code = 0, ob = 0, offlow = 0, rawn = 0, L = 0;
+		bool is_tok = false;
+		if (w < nwin) {
+			const u64 tm = tokbits[(u64)lc * 1024u + w];
+			if (tm == 0) { continue; }
+			is_tok = (tm >> lane) & (u64)1;
+			if (is_tok) {
+				const uint32_t o = w * 64u + lane;
+				const uint32_t off = moff[gbase + o];
+				uint32_t sym = d[o];
+				if (off != 0 && !fallback) {
+					L = mlen3[gbase + o];
+					ob = 31u - (uint32_t)__builtin_clz(off);
+					sym = 0x100u | (ob << 4) | (L < 15u ? L : 15u);
+					offlow = off ^ (1u << ob);
+					rawn = L >= 270u ? 3u : (L >= 15u ? 1u : 0u);
+				}
+				clen = s_lens[sym]; code = s_codes[sym];
+			}
+		} else {
+			if (!g.last) { break; }
+			is_tok = (lane == 0);
+			if (is_tok) { clen = s_lens[0x100]; code = s_codes[0x100]; }
+		}
+		const uint32_t tb = clen + ob;
+		const uint32_t ib = xh_incl_scan_add(tb), ir = xh_incl_scan_add(rawn);
+		const uint32_t T0 = T + ib - tb, T1 = T0 + clen, T2 = T1 + ob;
+		const uint32_t R0 = R + ir - rawn;
+		if (is_tok) {
+			if (clen) { XH_ORBITS(code, clen, T0) }
+			if (ob) { XH_ORBITS(offlow, ob, T1) }
+			const uint32_t f0 = XH_F(T0), f1 = XH_F(T1), f2 = XH_F(T2);
+			if (f1 > f0) { s_slot[(f1 + 1u) & 255u] = 4u + 2u * (f1 - 1u) + R0; }
+			if (f2 > f1) { s_slot[(f2 + 1u) & 255u] = 4u + 2u * (f2 - 1u) + R0 + rawn; }
+			if (rawn) {
+				uint8_t* q = bs + 4u + 2u * f1 + R0;
+				if (rawn == 1u) { q[0] = (uint8_t)(L - 15u); }
+				else { q[0] = 0xFF; q[1] = (uint8_t)L; q[2] = (uint8_t)(L >> 8); }
+			}
+		}
+		T += (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
+		R += (uint32_t)__builtin_amdgcn_readlane((int)ir, 63);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		// store the words that are complete now
+		const uint32_t wcomplete = T >> 4;
+		for (uint32_t base = Wdone; base < wcomplete; base += 64u) {
+			const uint32_t ww = base + lane;
+			if (ww < wcomplete) {
+				const uint32_t v = (__hip_atomic_load(&s_bits[(ww & 255u) >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> ((ww & 1u) * 16u)) & 0xFFFFu;
+				const uint32_t sp = __hip_atomic_load(&s_slot[ww & 255u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				bs[sp] = (uint8_t)v; bs[sp + 1u] = (uint8_t)(v >> 8);
+				atomicAnd(&s_bits[(ww & 255u) >> 1], ~(0xFFFFu << ((ww & 1u) * 16u)));
+			}
+		}
+		if (wcomplete > Wdone) { Wdone = wcomplete; }
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	}
+	// Finish (Bitstream.h:142-147): the current word (zero padded) and one zero word
+	const uint32_t fe = XH_F(T);
+	for (uint32_t ww = Wdone + lane; ww <= fe + 1u; ww += 64u) {
+		const uint32_t v = (s_bits[(ww & 255u) >> 1] >> ((ww & 1u) * 16u)) & 0xFFFFu;
+		const uint32_t sp = s_slot[ww & 255u];
+		bs[sp] = (uint8_t)v; bs[sp + 1u] = (uint8_t)(v >> 8);
+	}
+#undef XH_F
+#undef XH_ORBITS
+}
+
+// ===================================================================================================================
+// launchers
+// ===================================================================================================================
+void launch_xh_parse(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* mlen3, const uint16_t* moff,
+                     u64* tokbits, uint32_t* counts, uint32_t* extra)
+{
+	if (bt.n_chunks == 0) { return; }
+	hipLaunchKernelGGL(xh_parse_kernel, dim3(bt.n_chunks), dim3(64), 0, st, d_in, bt, mlen3, moff, tokbits, counts, extra);
+}
+void launch_xh_huff(hipStream_t st, const BatchTables& bt, const uint32_t* counts, const uint32_t* extra, uint8_t* lens, uint16_t* codes,
+                    uint32_t* chunk_size, uint32_t* fb_list, uint32_t* fb_count, uint32_t* fbflag)
+{
+	if (bt.n_chunks == 0) { return; }
+	(void)hipMemsetAsync(fb_count, 0, sizeof(uint32_t), st);
+	hipLaunchKernelGGL(xh_huff_kernel, dim3(bt.n_chunks), dim3(64), 0, st, bt, counts, extra, lens, codes, chunk_size, fb_list, fb_count, fbflag);
+}
+void launch_xh_fallback(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint32_t* fb_list, const uint32_t* fb_count,
+                        uint8_t* pool, uint32_t pool_blocks, u64* tokbits, uint8_t* lens, uint16_t* codes, uint32_t* chunk_size)
+{
+	if (bt.n_chunks == 0) { return; }
+	const uint32_t grid = bt.n_chunks < pool_blocks ? bt.n_chunks : pool_blocks;
+	hipLaunchKernelGGL(xh_fallback_kernel, dim3(grid), dim3(512), 0, st, d_in, bt, fb_list, fb_count, pool, tokbits, lens, codes, chunk_size);
+}
+void launch_xh_encode(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* mlen3, const uint16_t* moff,
+                      const u64* tokbits, const uint8_t* lens, const uint16_t* codes, const uint32_t* fbflag, const u64* prefix, uint8_t* d_out)
+{
+	if (bt.n_chunks == 0) { return; }
+	hipLaunchKernelGGL(xh_encode_kernel, dim3(bt.n_chunks), dim3(64), 0, st, d_in, bt, mlen3, moff, tokbits, lens, codes, fbflag, prefix, d_out);
+}
+uint32_t xh_fallback_pool_bytes_per_block() { return XH_FB_POOL_BYTES; }
+
+} // namespace msc
