@@ -1,0 +1,84 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mscomp_amd.h declares; host-only behaviour
+(sizes, argument errors, the MSCOMP_NONE copy codec) matches the reference facade. No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mscomp_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:ms|lznt1|xpress|xpress_huff|mscomp_amd)_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_exports_every_declared_symbol():
+    import ms_compress_amd as m
+    lib = m.load_library()
+    syms = _declared_symbols()
+    assert len(syms) >= 17
+    for s in syms:
+        assert hasattr(lib, s), "libmscomp_amd.so does not export " + s
+    assert sorted(m.api.EXPORTS) == syms, "api.EXPORTS and include/mscomp_amd.h disagree"
+
+
+def test_max_compressed_size_matches_reference_table():
+    import ms_compress_amd as m
+    n = [0, 1, 4096, 65536, 1 << 20]
+    assert [m.max_compressed_size(2, x) for x in n] == [3, 6, 4101, 65571, 1049091]
+    assert [m.max_compressed_size(3, x) for x in n] == [4, 5, 4612, 73732, 1179652]
+    assert [m.max_compressed_size(4, x) for x in n] == [292, 293, 4388, 66086, 1052996]
+    assert [m.max_compressed_size(0, x) for x in n] == n
+    assert m.max_compressed_size(1, 10) == 2 ** 64 - 1 and m.max_compressed_size(5, 10) == 2 ** 64 - 1   # mscomp.cpp:98
+    lib = m.load_library()
+    assert lib.lznt1_max_compressed_size(4096) == 4101 and lib.xpress_max_compressed_size(65536) == 73732
+    assert lib.xpress_huff_max_compressed_size(65536) == 66086
+
+
+def test_argument_errors_without_gpu():
+    import ms_compress_amd as m
+    lib = m.load_library()
+    out = C.create_string_buffer(64)
+    n = C.c_size_t(64)
+    assert lib.ms_compress(1, b"abc", 3, out, C.byref(n)) == m.MSCOMP_ARG_ERROR      # MSCOMP_RESERVED (mscomp.cpp:115)
+    assert lib.ms_compress(7, b"abc", 3, out, C.byref(n)) == m.MSCOMP_ARG_ERROR
+    n = C.c_size_t(64)
+    assert lib.ms_compress(0, b"abc", 3, out, C.byref(n)) == 0 and n.value == 3 and out.raw[:3] == b"abc"   # copy codec
+    n = C.c_size_t(2)
+    assert lib.ms_compress(0, b"abc", 3, out, C.byref(n)) == m.MSCOMP_BUF_ERROR
+    ctx = C.c_void_p()
+    assert lib.mscomp_amd_ctx_create(9999, None, C.byref(ctx)) == m.MSCOMP_ERRNO     # no such device: fails loudly
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a machine without a GPU the compress path must FAIL (never silently run on the CPU)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import ms_compress_amd as m
+    with pytest.raises(m.MSCompError) as e:
+        m.compress(2, b"hello hello hello hello")
+    assert e.value.status == m.MSCOMP_ERRNO
+    with pytest.raises(RuntimeError):
+        m.Context()
+
+
+def test_product_does_not_touch_oracle():
+    """Nothing under ms_compress_amd/ may import, link or mention the checker (oracle/)."""
+    pkg = os.path.join(ROOT, "ms_compress_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".c", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in txt and "orc_compress" not in txt and "from oracle" not in txt, os.path.join(dirpath, f)
+
+
+def test_pack_offsets():
+    import ms_compress_amd as m
+    off, total = m.pack_offsets([5, 0, 17, 16])
+    assert off.tolist() == [0, 16, 16, 48] and total == 64
+    off, total = m.pack_offsets([5, 0, 17], align=1)
+    assert off.tolist() == [0, 5, 5] and total == 22

@@ -1,0 +1,132 @@
+"""-m gpu: the HIP path, called through the C-ABI, against the oracle (bit-exact) and the committed golden fixtures."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+FMTS = {"lznt1": 2, "xpress": 3, "xpress_huff": 4}
+sha = lambda b: hashlib.sha256(b).hexdigest()
+
+
+def _check_units(m, oracle, fmt, units, ctx):
+    got, st = m.compress_units(fmt, units, ctx=ctx)
+    for i, (u, g, s) in enumerate(zip(units, got, st)):
+        es, exp = oracle.oracle_compress(fmt, u)
+        assert es == 0 and s == 0, (i, len(u), s)
+        assert g == exp, "fmt %d unit %d (len %d): GPU bytes differ from the oracle (%d vs %d B)" % (fmt, i, len(u), len(g), len(exp))
+
+
+@pytest.mark.parametrize("fmt", list(FMTS))
+def test_edge_families(oracle, gpu_ctx, fmt):
+    """empty / tiny / ragged / chunk-boundary sizes x {random, 2-symbol, run, words, synthetic LZ} (SURVEY.md 8c fuzz classes)."""
+    import ms_compress_amd as m
+    units = cases.edge_cases()
+    _check_units(m, oracle, FMTS[fmt], units, gpu_ctx)
+    # and against the committed digest generated from the real reference
+    g = json.load(open(os.path.join(G, "edge_families.json")))[fmt]
+    got, _ = m.compress_units(FMTS[fmt], units, ctx=gpu_ctx)
+    h = hashlib.sha256()
+    for o in got:
+        h.update(len(o).to_bytes(8, "little")); h.update(o)
+    assert h.hexdigest() == g["sha256"]
+
+
+@pytest.mark.parametrize("fmt", list(FMTS))
+def test_corpus_golden(gpu_ctx, fmt):
+    """1 MB of every corpus member + the mixed buffer (100 000 zeros: Xpress lagging fill, >64 KiB match; 70 000 random
+    bytes: XH fallback) against SHA-256 of the REFERENCE's output (tests/golden, tools/make_golden.py)."""
+    import ms_compress_amd as m
+    from ms_compress_amd import corpus
+    g = json.load(open(os.path.join(G, "corpus_1mb.json")))
+    names = corpus.NAMES + ["mixed_buffer"]
+    units = [corpus.file_bytes(i, g[n]["input_len"]).tobytes() for i, n in enumerate(corpus.NAMES)] + [cases.mixed_buffer()]
+    got, st = m.compress_units(FMTS[fmt], units, ctx=gpu_ctx)
+    for n, o, s in zip(names, got, st):
+        assert s == 0 and len(o) == g[n][fmt]["len"] and sha(o) == g[n][fmt]["sha256"], (n, fmt)
+
+
+def test_xpress_units_64k_golden(gpu_ctx):
+    """BASELINE config 3: every 64 KiB slice an independent Xpress stream."""
+    import ms_compress_amd as m
+    from ms_compress_amd import corpus
+    g = json.load(open(os.path.join(G, "corpus_1mb.json")))
+    for i, n in enumerate(corpus.NAMES[:4]):
+        data = corpus.file_bytes(i, g[n]["input_len"]).tobytes()
+        got, st = m.compress_units(3, [data[o:o + 65536] for o in range(0, len(data), 65536)], ctx=gpu_ctx)
+        cat = b"".join(got)
+        assert all(s == 0 for s in st) and len(cat) == g[n]["xpress_units64k"]["len"] and sha(cat) == g[n]["xpress_units64k"]["sha256"]
+
+
+@pytest.mark.parametrize("mode", [(0x2000, 0), (0xFFFF, 1)])
+def test_match_finder_stage(oracle, gpu_ctx, mode):
+    """Stage-level parity: per-position (length capped at 48, offset) of the HIP hash-chain finder == XpressDictionary::Find."""
+    import torch
+    import ms_compress_amd as m
+    from ms_compress_amd import corpus
+    lib, orc = m.load_library(), oracle.load_oracle()
+    max_off, clip = mode
+    for data in [corpus.file_bytes(1, 300_000).tobytes(), cases.mixed_buffer(), cases.family("lz", 131073, __import__("random").Random(9))]:
+        n = len(data)
+        d = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+        gl = np.zeros(n, dtype=np.uint16); go = np.zeros(n, dtype=np.uint16)
+        assert lib.mscomp_amd_debug_xpress_matches(gpu_ctx._h, C.c_void_p(d.data_ptr()), n, max_off, clip, gl.ctypes.data, go.ctypes.data) == 0
+        ol = np.zeros(n, dtype=np.uint32); oo = np.zeros(n, dtype=np.uint32)
+        orc.orc_xpress_match_table(data, n, max_off, ol.ctypes.data, oo.ctypes.data)
+        exp_l = np.where(ol >= 3, np.minimum(ol, 48) - 3, 0).astype(np.uint16)
+        exp_o = np.where(ol >= 3, oo, 0).astype(np.uint16)
+        if clip:
+            pos = np.arange(n); rem = np.minimum((pos // 65536 + 1) * 65536, n) - pos
+            exp_l[rem < 3] = 0; exp_o[rem < 3] = 0
+        assert np.array_equal(gl, exp_l) and np.array_equal(go, exp_o)
+
+
+@pytest.mark.parametrize("fmt", list(FMTS))
+def test_one_shot_abi_and_capacity(oracle, fmt):
+    """ms_compress with host pointers (the drop-in path): exact-fit capacity, BUF_ERROR one byte short (reference semantics:
+    lznt1_compress.cpp:251,267; xpress_compress.cpp:255-342; xpress_huff_compress.cpp:283,319), empty input."""
+    import ms_compress_amd as m
+    f = FMTS[fmt]
+    data = cases.mixed_buffer()[:150_000]
+    exp = oracle.oracle_compress(f, data)[1]
+    assert m.compress(f, data) == exp
+    assert m.compress(f, data, out_capacity=len(exp)) == exp
+    with pytest.raises(m.MSCompError) as e:
+        m.compress(f, data, out_capacity=len(exp) - 1)
+    assert e.value.status == m.MSCOMP_BUF_ERROR
+    assert m.compress(f, b"") == oracle.oracle_compress(f, b"")[1]
+    # per-codec entry points are the same code path
+    lib = m.load_library()
+    out = C.create_string_buffer(len(exp) + 8); n = C.c_size_t(len(exp) + 8)
+    assert getattr(lib, fmt + "_compress")(data, len(data), out, C.byref(n)) == 0 and out.raw[: n.value] == exp
+
+
+def test_lznt1_end_of_buffer_terminal(gpu_ctx):
+    """00 00 is written past *out_len when >= 2 bytes of capacity remain, and not counted (lznt1_compress.cpp:270-271)."""
+    import ms_compress_amd as m
+    lib = m.load_library()
+    data = b"hello hello hello hello hello hello"
+    out = C.create_string_buffer(b"\xAA" * 128, 128); n = C.c_size_t(128)
+    assert lib.ms_compress(2, data, len(data), out, C.byref(n)) == 0
+    assert out.raw[n.value: n.value + 2] == b"\x00\x00" and out.raw[n.value + 2] == 0xAA
+
+
+def test_batch_exact_capacities(oracle, gpu_ctx):
+    """batch interface: per-unit BUF_ERROR does not disturb neighbours; unaligned output offsets are accepted."""
+    import ms_compress_amd as m
+    units = cases.edge_cases(sizes=[0, 1, 100, 4097, 70000], kinds=["words", "lz", "random"])
+    for f in (2, 3, 4):
+        exp = [oracle.oracle_compress(f, u)[1] for u in units]
+        caps = [len(e) - (1 if (i % 3 == 1 and len(e) > 0) else 0) for i, e in enumerate(exp)]
+        got, st = m.compress_units(f, units, ctx=gpu_ctx, capacities=caps)
+        for i, (g, s, e) in enumerate(zip(got, st, exp)):
+            if caps[i] < len(e):
+                assert s == m.MSCOMP_BUF_ERROR and g is None
+            else:
+                assert s == 0 and g == e, (f, i)

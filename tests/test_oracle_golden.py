@@ -1,0 +1,107 @@
+"""CPU: the oracle (our C restatement) against the committed golden vectors generated from the real reference
+(tools/make_golden.py) and the SURVEY.md 8c known-answer table; decoders round-trip."""
+import hashlib
+import json
+import os
+
+import pytest
+
+import cases
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+FMTS = {"lznt1": 2, "xpress": 3, "xpress_huff": 4}
+sha = lambda b: hashlib.sha256(b).hexdigest()
+
+KAT_INPUTS = {"empty": b"", "a": b"a", "abc": b"abc", "a-z": bytes(range(97, 123)), "abc*100": b"abc" * 100,
+              "zeros4096": bytes(4096), "zeros4097": bytes(4097), "zeros70000": bytes(70000)}
+# SURVEY.md 8c, hex = full output of the reference
+SURVEY_KAT = {("empty", "xpress"): "ffffffff", ("a", "lznt1"): "003061", ("a", "xpress"): "ffffff7f61",
+              ("abc", "lznt1"): "0230616263", ("abc", "xpress"): "ffffff1f616263",
+              ("abc*100", "lznt1"): "05b0086162632621", ("abc*100", "xpress"): "ffffff1761626317000fff250163",
+              ("zeros4096", "lznt1"): "03b00200fc0f", ("zeros4096", "xpress"): "ffffff5f0007000ffffb0f00",
+              ("zeros4097", "lznt1"): "03b00200fc0f003000", ("zeros4097", "xpress"): "ffffff5f0007000ffffc0f00",
+              ("zeros70000", "xpress"): "ffffff5f0007000fff00006b11010000"}
+
+
+@pytest.mark.parametrize("fmt", list(FMTS))
+def test_kat(oracle, fmt):
+    kat = json.load(open(os.path.join(G, "kat.json")))["kat"]
+    for name, data in KAT_INPUTS.items():
+        st, out = oracle.oracle_compress(FMTS[fmt], data)
+        e = kat[name][fmt]
+        assert st == 0 and len(out) == e["len"] and sha(out) == e["sha256"], (name, fmt)
+        if e["hex"] is not None:
+            assert out.hex() == e["hex"]
+        if (name, fmt) in SURVEY_KAT:
+            assert out.hex() == SURVEY_KAT[(name, fmt)]
+
+
+def test_max_compressed_size(oracle):
+    g = json.load(open(os.path.join(G, "kat.json")))["max_compressed_size"]
+    lib = oracle.load_oracle()
+    for fmt, f in FMTS.items():
+        assert [lib.orc_max_compressed_size(f, n) for n in g["n"]] == g[fmt]
+    assert g["lznt1"] == [3, 6, 4101, 65571, 1049091] and g["xpress"] == [4, 5, 4612, 73732, 1179652]
+    assert g["xpress_huff"] == [292, 293, 4388, 66086, 1052996]
+    assert lib.orc_max_compressed_size(1, 10) == 2 ** 64 - 1 and lib.orc_max_compressed_size(5, 10) == 2 ** 64 - 1
+
+
+@pytest.mark.parametrize("fmt", list(FMTS))
+def test_corpus_golden(oracle, fmt):
+    from ms_compress_amd import corpus
+    g = json.load(open(os.path.join(G, "corpus_1mb.json")))
+    for i, name in enumerate(corpus.NAMES):
+        data = corpus.file_bytes(i, g[name]["input_len"]).tobytes()
+        assert sha(data) == g[name]["input_sha256"], "corpus generator drifted: " + name
+        st, out = oracle.oracle_compress(FMTS[fmt], data)
+        assert st == 0 and len(out) == g[name][fmt]["len"] and sha(out) == g[name][fmt]["sha256"], (name, fmt)
+        st, back = oracle.oracle_decompress(FMTS[fmt], out, len(data))
+        assert st == 0 and back == data
+    data = cases.mixed_buffer()
+    st, out = oracle.oracle_compress(FMTS[fmt], data)
+    assert st == 0 and sha(out) == g["mixed_buffer"][fmt]["sha256"]
+
+
+@pytest.mark.parametrize("fmt", list(FMTS))
+def test_edge_families_golden(oracle, fmt):
+    g = json.load(open(os.path.join(G, "edge_families.json")))[fmt]
+    h = hashlib.sha256()
+    units = cases.edge_cases()
+    assert len(units) == g["units"]
+    tot = 0
+    for u in units:
+        st, out = oracle.oracle_compress(FMTS[fmt], u)
+        assert st == 0
+        h.update(len(out).to_bytes(8, "little")); h.update(out); tot += len(out)
+        st, back = oracle.oracle_decompress(FMTS[fmt], out, len(u))
+        assert st == 0 and back == u, (fmt, len(u))
+    assert tot == g["total_len"] and h.hexdigest() == g["sha256"]
+
+
+def test_buf_error_and_capacity(oracle):
+    data = cases.mixed_buffer()[:30000]
+    for f in FMTS.values():
+        st, out = oracle.oracle_compress(f, data)
+        assert st == 0
+        assert oracle.oracle_compress(f, data, cap=len(out))[1] == out
+        assert oracle.oracle_compress(f, data, cap=len(out) - 1)[0] == -5      # MSCOMP_BUF_ERROR
+
+
+def test_units_driver_threads(oracle):
+    import ctypes as C
+    import numpy as np
+    lib = oracle.load_oracle()
+    units = cases.edge_cases(sizes=[0, 1, 100, 5000, 70000], kinds=["words", "lz"])
+    blob = b"".join(units)
+    in_off = np.cumsum([0] + [len(u) for u in units]).astype(np.uint64)
+    caps = [lib.orc_max_compressed_size(4, len(u)) for u in units]
+    out_off = np.cumsum([0] + caps).astype(np.uint64)
+    out = np.zeros(int(out_off[-1]) + 8, dtype=np.uint8)
+    out_len = np.zeros(len(units), dtype=np.uint64)
+    status = np.zeros(len(units), dtype=np.int32)
+    for fmt in (2, 3, 4):
+        lib.orc_compress_units(fmt, blob, in_off.ctypes.data, len(units), out.ctypes.data, out_off.ctypes.data,
+                               out_len.ctypes.data, status.ctypes.data, 4)
+        for i, u in enumerate(units):
+            exp = oracle.oracle_compress(fmt, u)[1]
+            assert status[i] == 0 and bytes(out[int(out_off[i]): int(out_off[i]) + int(out_len[i])]) == exp
