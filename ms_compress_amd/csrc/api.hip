@@ -93,6 +93,7 @@ const char* mscomp_amd_version(void) { return "mscomp_amd 0.1 (gfx950, HIP; LZNT
 size_t lznt1_max_compressed_size(size_t n)       { return n + 3 + 2 * ((n + 4095) / 4096); }
 size_t xpress_max_compressed_size(size_t n)      { return n + 4 + 4 * (n / 32); }
 size_t xpress_huff_max_compressed_size(size_t n) { return n + 34 + 258 + 258 * (n / 65536); }
+#ifndef MSCOMP_AMD_NO_FACADE   /* define when src/mscomp.cpp of the reference is linked too */
 size_t ms_max_compressed_size(MSCompFormat f, size_t n)
 {
 	switch ((int)f) {
@@ -337,6 +338,7 @@ MSCompStatus lznt1_compress(const uint8_t* in, size_t n, uint8_t* out, size_t* o
 MSCompStatus xpress_compress(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)      { return one_shot(MSCOMP_XPRESS, in, n, out, out_len); }
 MSCompStatus xpress_huff_compress(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len) { return one_shot(MSCOMP_XPRESS_HUFF, in, n, out, out_len); }
 
+#ifndef MSCOMP_AMD_NO_FACADE
 MSCompStatus ms_compress(MSCompFormat format, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len)
 {
 	switch ((int)format) {
@@ -348,5 +350,6 @@ MSCompStatus ms_compress(MSCompFormat format, const uint8_t* in, size_t in_len, 
 	default: return MSCOMP_ARG_ERROR;                                // mscomp.cpp:115
 	}
 }
+#endif
 
 } // extern "C"
