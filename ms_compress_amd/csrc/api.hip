@@ -104,6 +104,7 @@ size_t ms_max_compressed_size(MSCompFormat f, size_t n)
 	default:                 return (size_t)-1;                          // mscomp.cpp:98
 	}
 }
+#endif
 
 MSCompStatus mscomp_amd_ctx_create(int device, void* hip_stream, mscomp_amd_ctx** out)
 {
