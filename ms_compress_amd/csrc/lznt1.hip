@@ -3,22 +3,23 @@
 // Replaces: lznt1_compress / lznt1_compress_chunk (/root/reference/src/lznt1_compress.cpp:233-273, :49-94) and
 // LZNT1Dictionary::Fill/Find (/root/reference/include/mscomp/LZNT1Dictionary.h:93-106, :114-143).
 //
-// One 256-thread block (4 wavefronts) = one 4 KiB chunk, everything staged in LDS (33 KiB -> 4 blocks / CU):
-//   A. coalesced 16 B/thread load of the chunk into LDS;
-//   B. dictionary = the reference's per-key position arrays, as ONE position-sorted bucket array in LDS built by a
-//      stable counting sort on a 12-bit hash of the 3-byte key: rank[p] = #earlier positions with the same hash is
-//      computed in 64 ascending batches (wave w owns hash class h&3==w, so the four waves never touch the same bin;
-//      intra-batch conflicts are resolved with ballots), an exclusive scan turns counts into bucket starts, and a
-//      scatter fills bucket[start+rank] = p;
-//   C. Find for every position (a pure function of (chunk, position)): each lane scans the OLDEST 8 candidates of
-//      its position itself (4 loads in flight, early exit at max_len exactly like the reference), positions with
-//      more candidates are then finished cooperatively: 64 lanes take 64 candidates at a time, wave-max of
-//      (len, -position) = "longest, oldest on ties";
-//   D. wave 0 runs the greedy parse on the scalar unit over per-window ballot masks (one step per MATCH; literal
-//      runs are skipped with s_ff1) and places tokens/flag bytes with the closed form
-//      pos(t) = (t div 8 + 1) + sum size(u<t)  (mbcnt prefix popcounts); flag bits are OR-ed into LDS;
-//   E. the chunk image (2-byte header + payload, or the raw chunk) goes to a 16 B aligned scratch slot with
-//      16 B/thread stores; util.hip concatenates slots into the caller's buffer.
+// One wavefront (64-thread block) = one 4 KiB chunk, everything staged in LDS (~29 KiB -> 5 chunks in flight per CU):
+//   A. coalesced 16 B/lane load of the chunk into LDS;
+//   B. dictionary = the reference's per-key position arrays as ONE position-sorted bucket array in LDS, built by a stable
+//      counting sort on a 12-bit hash of the 3-byte key: rank[p] = #earlier positions with the same hash in 64 ascending
+//      batches (one LDS gather + scatter per batch, intra-batch conflicts resolved with ballots), exclusive scan of the
+//      counts (DPP), scatter bucket[start+rank] = p;
+//   C. window by window (64 positions, lane = position), LAZILY like the reference (Find runs only where the greedy parse
+//      can start a token):
+//        1. every lane at or after the parse position scans the 8 OLDEST candidates of its position itself (4 loads in
+//           flight, own bytes in registers, strictly-longer wins, early exit at max_len);
+//        2. the greedy walk runs on the scalar unit over ballot masks (s_ff1 over literal runs). When it lands on a
+//           position that still has unexamined candidates, the whole wave finishes that ONE position: 64 candidates per
+//           step, DPP max of (len, -position) = longest, oldest on ties, stop when max_len is reached. Positions covered
+//           by a match are never finished;
+//        3. tokens go straight to the chunk's scratch slot, placed by the closed form
+//           pos(t) = (t div 8 + 1) + sum size(u<t)   (mbcnt prefix popcounts); flag bits collect in a 16-entry LDS ring;
+//   D. header (0xB000|size-1), or the raw chunk (0x3000|n-1) when the running size reaches n; util.hip concatenates slots.
 #include "common.h"
 #include "kernels.h"
 
@@ -26,11 +27,13 @@ namespace msc {
 
 #ifdef LZ_PROFILE   // dev-only phase timers (s_memtime cycles summed over blocks); not in the production build
 __device__ unsigned long long g_lz_prof[16];
-#define LZ_T(i) if (tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_lz_prof[i], t_ - t_prev); t_prev = t_; }
+#define LZ_T(i) if (lane == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_lz_prof[i], t_ - t_prev); t_prev = t_; }
 #define LZ_T0   unsigned long long t_prev = __builtin_readcyclecounter();
+#define LZ_CNT(i, v) if (lane == 0) { atomicAdd(&g_lz_prof[i], (unsigned long long)(v)); }
 #else
 #define LZ_T(i)
 #define LZ_T0
+#define LZ_CNT(i, v)
 #endif
 
 #define LZ_TBL_BITS 12
@@ -49,9 +52,11 @@ __device__ __forceinline__ uint32_t lz_shift(uint32_t pos)
 // DS operations of a wave execute in program order) so the compiler neither forwards nor reorders them.
 __device__ __forceinline__ void     wst16(uint16_t* p, uint32_t v) { __hip_atomic_store(p, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 __device__ __forceinline__ uint32_t wld16(uint16_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+__device__ __forceinline__ void     wst32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+__device__ __forceinline__ uint32_t wld32(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 __device__ __forceinline__ void     wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
-// max over the 64 lanes (DPP: row_shr 1,2,4,8 then row_bcast 15/31), result broadcast from lane 63
+// DPP scans over the 64 lanes: row_shr 1,2,4,8 then row_bcast 15/31
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
 #define MSC_DPP_MAX(ctrl, rmask) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false); v = o > v ? o : v; }
@@ -60,61 +65,85 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 #undef MSC_DPP_MAX
 	return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-
-// length of the common prefix of d[q..] and d[p..], limited to maxlen; x3 = (byte 3 of q) ^ (byte 3 of p)
-__device__ __forceinline__ uint32_t lz_lcp(const uint8_t* d, uint32_t q, uint32_t p, uint32_t maxlen, uint32_t x3)
+__device__ __forceinline__ uint32_t wave_incl_scan_add_u32(uint32_t v)
 {
-	if (x3) { return 3u; }
-	uint32_t l = 4;
-	while (l < maxlen) {
-		const uint32_t x = ld32(d + q + l) ^ ld32(d + p + l);
-		if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
-		l += 4;
+#define MSC_DPP_ADD(ctrl, rmask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, true);
+	MSC_DPP_ADD(0x111, 0xf) MSC_DPP_ADD(0x112, 0xf) MSC_DPP_ADD(0x114, 0xf) MSC_DPP_ADD(0x118, 0xf)
+	MSC_DPP_ADD(0x142, 0xa) MSC_DPP_ADD(0x143, 0xc)
+#undef MSC_DPP_ADD
+	return v;
+}
+
+// Common prefix of d[q..] and the string whose first 16 bytes are o0..o3 (at d[p..]), limited to maxlen (>= 3).
+// The caller has verified the first 3 bytes; x0 = ld32(d+q) ^ o0.
+__device__ __forceinline__ uint32_t lz_lcp(const uint8_t* d, uint32_t q, uint32_t p, uint32_t maxlen,
+                                           uint32_t x0, uint32_t o1, uint32_t o2, uint32_t o3)
+{
+	uint32_t l;
+	if (x0) { l = 3u; }
+	else {
+		uint32_t x = ld32(d + q + 4u) ^ o1;
+		if (x || maxlen <= 8u) { l = x ? 4u + ((uint32_t)__builtin_ctz(x) >> 3) : 8u; }
+		else {
+			x = ld32(d + q + 8u) ^ o2;
+			if (x || maxlen <= 12u) { l = x ? 8u + ((uint32_t)__builtin_ctz(x) >> 3) : 12u; }
+			else {
+				x = ld32(d + q + 12u) ^ o3;
+				if (x) { l = 12u + ((uint32_t)__builtin_ctz(x) >> 3); }
+				else {
+					l = 16u;
+					while (l < maxlen) {
+						x = ld32(d + q + l) ^ ld32(d + p + l);
+						if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
+						l += 4u;
+					}
+				}
+			}
+		}
 	}
 	return l < maxlen ? l : maxlen;
 }
 
-__global__ __launch_bounds__(256) void lznt1_chunk_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
-                                                         uint8_t* __restrict__ slots, uint32_t* __restrict__ slot_size)
+__global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
+                                                        uint8_t* __restrict__ slots, uint32_t* __restrict__ slot_size)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t  s_data[4096 + 32];
 	__shared__ __attribute__((aligned(16))) uint16_t s_cnt[LZ_TBL];       // counts -> bucket starts
 	__shared__ __attribute__((aligned(16))) uint16_t s_bucket[4096];      // positions sorted by (hash, position)
-	__shared__ __attribute__((aligned(16))) uint16_t s_idx[4096];         // rank -> index in s_bucket -> match token
-	__shared__ __attribute__((aligned(16))) uint8_t  s_out[LZNT1_SLOT];
-	__shared__ uint32_t s_mbits[128];                                      // "position has a match" bits
-	__shared__ uint32_t s_grpflag[16];
-	__shared__ uint32_t s_wsum[4];
-	__shared__ uint32_t s_total;
+	__shared__ __attribute__((aligned(16))) uint16_t s_idx[4096];         // rank -> index of the position in s_bucket
+	__shared__ uint32_t s_flagacc[16];                                     // flag bits of the groups in flight
+	__shared__ uint32_t s_flagpos[16];                                     // their byte position in the image
 
-	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+	const uint32_t lane = threadIdx.x;
 	const uint32_t c = blockIdx.x;
 	const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, c);
 	const u64 coff = (u64)(c - bt.chunk_prefix[u]) * 4096u;
 	const u64 left = bt.in_len[u] - coff;
 	const uint32_t n = left < 4096u ? (uint32_t)left : 4096u;
 	const uint8_t* __restrict__ src = d_in + bt.in_off[u] + coff;
+	uint8_t* __restrict__ img = slots + (u64)c * LZNT1_SLOT;              // chunk image: 2-byte header + payload
 
 	LZ_T0
 	// ---- A. stage the chunk, clear the count table -----------------------------------------------------------
 	{
 		const uint32_t nvec = (((uintptr_t)src & 15u) == 0) ? (n & ~15u) : 0u;
-		for (uint32_t i = tid * 16u; i < nvec; i += 4096u) {
+		for (uint32_t i = lane * 16u; i < nvec; i += 1024u) {
 			*reinterpret_cast<uint4*>(s_data + i) = *reinterpret_cast<const uint4*>(src + i);
 		}
-		for (uint32_t i = nvec + tid; i < n; i += 256u) { s_data[i] = src[i]; }
-		for (uint32_t i = n + tid; i < 4096u + 32u; i += 256u) { s_data[i] = 0; }
-		for (uint32_t i = tid * 8u; i < LZ_TBL; i += 2048u) { *reinterpret_cast<uint4*>(s_cnt + i) = make_uint4(0, 0, 0, 0); }
+		for (uint32_t i = nvec + lane; i < n; i += 64u) { s_data[i] = src[i]; }
+		for (uint32_t i = n + lane; i < 4096u + 32u; i += 64u) { s_data[i] = 0; }
+		for (uint32_t i = lane * 8u; i < LZ_TBL; i += 512u) { *reinterpret_cast<uint4*>(s_cnt + i) = make_uint4(0, 0, 0, 0); }
+		if (lane < 16u) { s_flagacc[lane] = 0; }
 	}
 	__syncthreads();
 	LZ_T(0)
 
-	// ---- B1. rank[p] = number of earlier positions with the same hash (wave w owns hash class w) ---------------
+	// ---- B1. rank[p] = number of earlier positions with the same hash -------------------------------------------
 	const uint32_t nb = (n + 63u) >> 6;
 	for (uint32_t b = 0; b < nb; ++b) {
 		const uint32_t p = b * 64u + lane;
 		const uint32_t h = lz_hash(ld32(s_data + p) & 0xFFFFFFu);
-		const bool mine = (p + 2u < n) && ((h & 3u) == wv);
+		const bool mine = p + 2u < n;
 		uint32_t old = 0;
 		if (mine) { old = wld16(&s_cnt[h]); wst16(&s_bucket[h], lane); }   // s_bucket doubles as conflict detector
 		wave_fence();
@@ -135,33 +164,26 @@ __global__ __launch_bounds__(256) void lznt1_chunk_kernel(const uint8_t* __restr
 	__syncthreads();
 	LZ_T(1)
 
-	// ---- B2. exclusive scan of the 4096 counts -> bucket starts (16 bins per thread) ---------------------------
+	// ---- B2. exclusive scan of the 4096 counts -> bucket starts: 8 coalesced rounds of 8 bins per lane ---------
 	{
-		uint4 a = reinterpret_cast<uint4*>(s_cnt)[tid * 2u], b = reinterpret_cast<uint4*>(s_cnt)[tid * 2u + 1u];
-		uint32_t w[8] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
-		uint32_t sum = 0;
-		#pragma unroll
-		for (int k = 0; k < 8; ++k) { sum += (w[k] & 0xFFFFu) + (w[k] >> 16); }
-		uint32_t incl = sum;
-		#pragma unroll
-		for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) { incl += o; } }
-		if (lane == 63) { s_wsum[wv] = incl; }
-		__syncthreads();
-		uint32_t run = incl - sum;
-		for (uint32_t k = 0; k < wv; ++k) { run += s_wsum[k]; }
-		#pragma unroll
-		for (int k = 0; k < 8; ++k) {
-			const uint32_t lo = w[k] & 0xFFFFu, hi = w[k] >> 16;
-			w[k] = run | ((run + lo) << 16);
-			run += lo + hi;
+		uint32_t run = 0;
+		for (uint32_t k = 0; k < 8u; ++k) {
+			uint4 a = reinterpret_cast<uint4*>(s_cnt)[k * 64u + lane];
+			uint32_t w[4] = { a.x, a.y, a.z, a.w };
+			uint32_t sum = 0;
+			#pragma unroll
+			for (int i = 0; i < 4; ++i) { sum += (w[i] & 0xFFFFu) + (w[i] >> 16); }
+			const uint32_t incl = wave_incl_scan_add_u32(sum);
+			uint32_t r = run + incl - sum;
+			#pragma unroll
+			for (int i = 0; i < 4; ++i) { const uint32_t lo = w[i] & 0xFFFFu, hi = w[i] >> 16; w[i] = r | ((r + lo) << 16); r += lo + hi; }
+			reinterpret_cast<uint4*>(s_cnt)[k * 64u + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+			run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 		}
-		reinterpret_cast<uint4*>(s_cnt)[tid * 2u] = make_uint4(w[0], w[1], w[2], w[3]);
-		reinterpret_cast<uint4*>(s_cnt)[tid * 2u + 1u] = make_uint4(w[4], w[5], w[6], w[7]);
 	}
 	__syncthreads();
-
 	// ---- B3. scatter: bucket[start[h] + rank[p]] = p ------------------------------------------------------------
-	for (uint32_t p = tid; p + 2u < n; p += 256u) {
+	for (uint32_t p = lane; p + 2u < n; p += 64u) {
 		const uint32_t h = lz_hash(ld32(s_data + p) & 0xFFFFFFu);
 		const uint32_t a = (uint32_t)s_cnt[h] + (uint32_t)s_idx[p];
 		s_bucket[a] = (uint16_t)p;
@@ -170,20 +192,25 @@ __global__ __launch_bounds__(256) void lznt1_chunk_kernel(const uint8_t* __restr
 	__syncthreads();
 	LZ_T(2)
 
-	// ---- C. Find for every position: wave w takes windows w, w+4, ... -------------------------------------------
+	// ---- C. lazy windows: Find -> greedy walk (finishing positions on demand) -> emit --------------------------------
+	uint32_t entry = 0, T = 0, S = 0;                            // next token start, tokens so far, sum of token sizes so far
+	bool raw = false;
 	const uint32_t nw = (n + 63u) >> 6;
-	for (uint32_t w = wv; w < nw; w += 4u) {
-		const uint32_t p = w * 64u + lane;
-		const uint32_t own4 = ld32(s_data + p);
+	for (uint32_t w = 0; w < nw; ++w) {
+		const uint32_t wbase = w * 64u;
+		const uint32_t wend = (wbase + 64u < n) ? wbase + 64u : n;
+		if (entry >= wend) { continue; }                         // window wholly covered by a match
+		const uint32_t p = wbase + lane;
+		const uint32_t o0 = ld32(s_data + p), o1 = ld32(s_data + p + 4u), o2 = ld32(s_data + p + 8u), o3 = ld32(s_data + p + 12u);
 		const uint32_t shift = lz_shift(p);
 		uint32_t maxlen = 0, s = 0, cnt = 0;
-		if (p > 0 && p + 3u <= n) {
+		if (p >= entry && p > 0 && p + 3u <= n) {
 			const uint32_t mask3 = (1u << shift) + 2u;
 			maxlen = (n - p < mask3) ? n - p : mask3;
-			s = s_cnt[lz_hash(own4 & 0xFFFFFFu)];
+			s = s_cnt[lz_hash(o0 & 0xFFFFFFu)];
 			cnt = (uint32_t)s_idx[p] - s;
 		}
-		// phase 1: the oldest LZ_SELF candidates, in order, early exit at maxlen (LZNT1Dictionary.h:124-135)
+		// 1. the oldest LZ_SELF candidates, in order, early exit at maxlen (LZNT1Dictionary.h:124-135)
 		uint32_t key = 0;                                       // (len << 12) | (4095 - q): larger = longer, then older
 		bool done = (cnt == 0);
 		const uint32_t self_n = cnt < LZ_SELF ? cnt : LZ_SELF;
@@ -193,125 +220,109 @@ __global__ __launch_bounds__(256) void lznt1_chunk_kernel(const uint8_t* __restr
 			#pragma unroll
 			for (int k = 0; k < 4; ++k) { q[k] = (j + k < self_n) ? (uint32_t)s_bucket[s + j + k] : p; }
 			#pragma unroll
-			for (int k = 0; k < 4; ++k) { x[k] = ld32(s_data + q[k]) ^ own4; }
+			for (int k = 0; k < 4; ++k) { x[k] = ld32(s_data + q[k]) ^ o0; }
 			#pragma unroll
 			for (int k = 0; k < 4; ++k) {
 				if (!done && j + k < self_n && (x[k] & 0xFFFFFFu) == 0) {
-					const uint32_t l = lz_lcp(s_data, q[k], p, maxlen, x[k] >> 24);
+					const uint32_t l = lz_lcp(s_data, q[k], p, maxlen, x[k] >> 24, o1, o2, o3);
 					if (l > (key >> 12)) { key = (l << 12) | (4095u - q[k]); if (l == maxlen) { done = true; } }
 				}
 			}
 		}
-		// phase 2: positions with more candidates are finished by the whole wave, 64 candidates per step
-		const uint32_t rem = done ? 0u : cnt - self_n;
-		u64 hm = __ballot(rem != 0);
-		while (hm) {
-			const int L = (int)ctz64(hm);
-			hm &= hm - 1;
-			const uint32_t pL = w * 64u + (uint32_t)L;
-			const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)s, L) + LZ_SELF;
-			const uint32_t remL = (uint32_t)__builtin_amdgcn_readlane((int)rem, L);
-			const uint32_t maxL = (uint32_t)__builtin_amdgcn_readlane((int)maxlen, L);
-			const uint32_t ownL = (uint32_t)__builtin_amdgcn_readlane((int)own4, L);
-			uint32_t kbest = (uint32_t)__builtin_amdgcn_readlane((int)key, L);
-			for (uint32_t base = 0; base < remL; base += 64u) {
-				uint32_t k2 = 0;
-				if (base + lane < remL) {
-					const uint32_t q = s_bucket[sL + base + lane];
-					const uint32_t x = ld32(s_data + q) ^ ownL;
-					if ((x & 0xFFFFFFu) == 0) { k2 = (lz_lcp(s_data, q, pL, maxL, x >> 24) << 12) | (4095u - q); }
+		uint32_t rem = done ? 0u : cnt - self_n;                 // candidates nobody has looked at yet
+		LZ_T(3)
+		// 2. greedy walk; positions with rem != 0 are finished by the whole wave when (and only when) the walk lands on them
+		u64 un = __ballot(rem != 0);                             // unresolved positions
+		u64 mm = __ballot(rem == 0 && (key >> 12) >= 3u);        // resolved positions that have a match
+		u64 tokmask = 0, matchmask = 0;
+		uint32_t cur = entry;
+		while (cur < wend) {
+			const uint32_t rel = cur - wbase;
+			const u64 rest = (un | mm) >> rel;
+			if (rest == 0) { tokmask |= (~(u64)0) << rel; cur = wend; break; }
+			const uint32_t j = ctz64(rest);
+			const uint32_t mp = rel + j;
+			if ((un >> mp) & (u64)1) {
+				// finish position wbase+mp: candidates [nextc, endc) of its bucket, oldest first, 64 per step
+				const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)s, (int)mp);
+				const uint32_t cL = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)mp);
+				const uint32_t maxL = (uint32_t)__builtin_amdgcn_readlane((int)maxlen, (int)mp);
+				const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)o0, (int)mp), a1 = (uint32_t)__builtin_amdgcn_readlane((int)o1, (int)mp);
+				const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)o2, (int)mp), a3 = (uint32_t)__builtin_amdgcn_readlane((int)o3, (int)mp);
+				uint32_t kbest = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)mp);
+				const uint32_t pL = wbase + mp;
+				for (uint32_t base = LZ_SELF; base < cL; base += 64u) {
+					uint32_t k2 = 0;
+					if (base + lane < cL) {
+						const uint32_t q = s_bucket[sL + base + lane];
+						const uint32_t x = ld32(s_data + q) ^ a0;
+						if ((x & 0xFFFFFFu) == 0) { k2 = (lz_lcp(s_data, q, pL, maxL, x >> 24, a1, a2, a3) << 12) | (4095u - q); }
+					}
+					LZ_CNT(9, 1)
+					const uint32_t m = wave_max_u32(k2);
+					if ((m >> 12) > (kbest >> 12)) { kbest = m; }    // strictly longer only: older blocks win ties
+					if ((kbest >> 12) == maxL) { break; }             // oldest candidate reaching max_len: stop
 				}
-				const uint32_t m = wave_max_u32(k2);
-				if ((m >> 12) > (kbest >> 12)) { kbest = m; }    // strictly longer only: older blocks win ties
-				if ((kbest >> 12) == maxL) { break; }             // oldest candidate reaching max_len: stop
+				if (lane == mp) { key = kbest; rem = 0; }
+				un &= ~(((u64)1) << mp);
+				if ((kbest >> 12) >= 3u) { mm |= ((u64)1) << mp; }
+				continue;                                          // re-evaluate from the same cur
 			}
-			if ((int)lane == L) { key = kbest; }
+			tokmask |= ((((u64)2) << j) - (u64)1) << rel;        // j literals + the match start
+			matchmask |= ((u64)1) << mp;
+			cur = wbase + mp + ((uint32_t)__builtin_amdgcn_readlane((int)key, (int)mp) >> 12);
 		}
-		// result -> token (lznt1_compress.cpp:72); match bit per position
-		const uint32_t best = key >> 12;
-		const bool is_match = best >= 3u;
-		if (is_match) { s_idx[p] = (uint16_t)(((p - (4095u - (key & 0xFFFu)) - 1u) << shift) | (best - 3u)); }
-		const u64 mb = __ballot(is_match);
-		if (lane == 0) { s_mbits[2u * w] = (uint32_t)mb; s_mbits[2u * w + 1u] = (uint32_t)(mb >> 32); }
-	}
-	__syncthreads();
-	LZ_T(3)
+		if (wend - wbase < 64u) { tokmask &= (((u64)1) << (wend - wbase)) - (u64)1; }
+		entry = cur;
+		LZ_T(4)
 
-	// ---- D. greedy parse + emit (wave 0) -------------------------------------------------------------------------
-	if (wv == 0) {
-		uint32_t entry = 0, T = 0, S = 0;
-		bool raw = false;
-		for (uint32_t w = 0; w < nw; ++w) {
-			const uint32_t wbase = w * 64u;
-			const uint32_t wend = (wbase + 64u < n) ? wbase + 64u : n;
-			if (entry >= wend) { continue; }                     // window wholly covered by a match
-			const uint32_t p = wbase + lane;
-			const uint32_t shift = lz_shift(p);
-			const uint32_t tok = s_idx[p];
-			const uint32_t mlen = (tok & ((1u << shift) - 1u)) + 3u;
-			const u64 mm = ((u64)s_mbits[2u * w] | ((u64)s_mbits[2u * w + 1u] << 32));
-			u64 tokmask = 0, matchmask = 0;
-			uint32_t cur = entry;
-			while (cur < wend) {
-				const uint32_t rel = cur - wbase;
-				const u64 rest = mm >> rel;
-				if (rest == 0) { tokmask |= (~(u64)0) << rel; cur = wend; break; }
-				const uint32_t j = ctz64(rest);
-				const uint32_t mpos = rel + j;
-				tokmask |= ((((u64)2) << j) - (u64)1) << rel;   // j literals + the match start
-				matchmask |= ((u64)1) << mpos;
-				cur = wbase + mpos + (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)mpos);
-			}
-			if (wend - wbase < 64u) { tokmask &= (((u64)1) << (wend - wbase)) - (u64)1; }
-			entry = cur;
-
-			// emit: pos(t) = 2 (header) + (t div 8 + 1) + sum size(u<t)
-			const bool is_tok = (tokmask >> lane) & (u64)1;
-			const bool is_m = (matchmask >> lane) & (u64)1;
-			const uint32_t tb = popc_below(tokmask), mbl = popc_below(matchmask);
-			const uint32_t t = T + tb;
-			const uint32_t pos = 3u + (t >> 3) + S + tb + mbl;
-			if (is_tok) {
-				if ((t & 7u) == 0) { s_out[pos - 1u] = 0; s_grpflag[(t >> 3) & 15u] = pos - 1u; }
-				if (is_m) { s_out[pos] = (uint8_t)tok; s_out[pos + 1u] = (uint8_t)(tok >> 8); }
-				else { s_out[pos] = s_data[p]; }
-			}
-			wave_fence();
+		// 3. emit: pos(t) = 2 (header) + (t div 8 + 1) + sum size(u<t)
+		const bool is_tok = (tokmask >> lane) & (u64)1;
+		const bool is_m = (matchmask >> lane) & (u64)1;
+		const uint32_t tb = popc_below(tokmask), mbl = popc_below(matchmask);
+		const uint32_t t = T + tb;
+		const uint32_t pos = 3u + (t >> 3) + S + tb + mbl;
+		if (is_tok) {
+			if ((t & 7u) == 0) { wst32(&s_flagpos[(t >> 3) & 15u], pos - 1u); }
 			if (is_m) {
-				const uint32_t fp = __hip_atomic_load(&s_grpflag[(t >> 3) & 15u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-				atomicOr(reinterpret_cast<uint32_t*>(s_out + (fp & ~3u)), (1u << (t & 7u)) << ((fp & 3u) * 8u));
-			}
-			wave_fence();
-			const uint32_t nt = (uint32_t)__popcll(tokmask), nm = (uint32_t)__popcll(matchmask);
-			T += nt; S += nt + nm;
-			if (((T + 7u) >> 3) + S >= n) { raw = true; break; }  // running size reached n (:85-86) => store raw
+				const uint32_t best = key >> 12;
+				const uint32_t tok = ((p - (4095u - (key & 0xFFFu)) - 1u) << shift) | (best - 3u);
+				img[pos] = (uint8_t)tok; img[pos + 1u] = (uint8_t)(tok >> 8);
+			} else { img[pos] = (uint8_t)o0; }
 		}
-		const uint32_t csize = ((T + 7u) >> 3) + S;
-		const bool compressed = !raw && csize < n;
-		if (lane == 0) {
-			if (compressed) { st16(s_out, 0xB000u | (csize - 1u)); }
-			s_total = compressed ? 2u + csize : 0u;
+		if (is_m) { atomicOr(&s_flagacc[(t >> 3) & 15u], 1u << (t & 7u)); }
+		wave_fence();
+		const uint32_t nt = (uint32_t)__popcll(tokmask), nm = (uint32_t)__popcll(matchmask);
+		// groups completed in this window: their flag byte is final
+		if (is_tok && (t & 7u) == 7u) {
+			const uint32_t g = (t >> 3) & 15u;
+			img[wld32(&s_flagpos[g])] = (uint8_t)wld32(&s_flagacc[g]);
+			wst32(&s_flagacc[g], 0u);
 		}
+		wave_fence();
+		T += nt; S += nt + nm;
+		LZ_T(5)
+		if (((T + 7u) >> 3) + S >= n) { raw = true; break; }    // running size reached n (:85-86) => store raw
 	}
-	__syncthreads();
-	LZ_T(4)
 
-	// ---- E. chunk image -> scratch slot --------------------------------------------------------------------------
-	uint32_t total = s_total;
-	if (total == 0) {                                           // raw chunk: header 0x3000 | (n-1), then the bytes
+	// ---- D. header / raw chunk -----------------------------------------------------------------------------------------
+	const uint32_t csize = ((T + 7u) >> 3) + S;
+	uint32_t total;
+	if (!raw && csize < n) {
+		if (lane == 0) {
+			if (T & 7u) { const uint32_t g = (T >> 3) & 15u; img[s_flagpos[g]] = (uint8_t)s_flagacc[g]; }   // the last, partial group
+			img[0] = (uint8_t)(0xB000u | (csize - 1u)); img[1] = (uint8_t)((0xB000u | (csize - 1u)) >> 8);
+		}
+		total = 2u + csize;
+	} else {
 		const uint32_t hdr = 0x3000u | (n - 1u);
-		for (uint32_t k = tid; k < (n + 2u + 3u) / 4u; k += 256u) {
-			reinterpret_cast<uint32_t*>(s_out)[k] = (k == 0) ? (hdr | (ld16(s_data) << 16)) : ld32(s_data + 4u * k - 2u);
+		for (uint32_t k = lane; k < (n + 2u + 3u) / 4u; k += 64u) {
+			reinterpret_cast<uint32_t*>(img)[k] = (k == 0) ? (hdr | (ld16(s_data) << 16)) : ld32(s_data + 4u * k - 2u);
 		}
 		total = 2u + n;
-		__syncthreads();
 	}
-	uint8_t* __restrict__ slot = slots + (u64)c * LZNT1_SLOT;
-	for (uint32_t i = tid * 16u; i < total; i += 4096u) {
-		*reinterpret_cast<uint4*>(slot + i) = *reinterpret_cast<const uint4*>(s_out + i);
-	}
-	if (tid == 0) { slot_size[c] = total; }
-	LZ_T(5)
+	if (lane == 0) { slot_size[c] = total; }
+	LZ_T(6)
 }
 #ifdef LZ_PROFILE
 extern "C" void mscomp_amd_debug_lz_prof(unsigned long long* out, int reset)
@@ -324,7 +335,7 @@ extern "C" void mscomp_amd_debug_lz_prof(unsigned long long* out, int reset)
 void launch_lznt1_chunks(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* slots, uint32_t* slot_size)
 {
 	if (bt.n_chunks == 0) { return; }
-	hipLaunchKernelGGL(lznt1_chunk_kernel, dim3(bt.n_chunks), dim3(256), 0, st, d_in, bt, slots, slot_size);
+	hipLaunchKernelGGL(lznt1_chunk_kernel, dim3(bt.n_chunks), dim3(64), 0, st, d_in, bt, slots, slot_size);
 }
 
 } // namespace msc

@@ -4,7 +4,7 @@ import numpy as np, torch
 import ms_compress_amd as m
 from ms_compress_amd import corpus
 lib = m.load_library()
-names = ["A load", "B1 rank", "B2/3 scan+scatter", "C find", "D parse", "E out"]
+names = ["A load", "B1 rank", "B2/3 scan+scatter", "C1 self-scan", "C2 walk+finish", "C3 emit", "D out"]
 for name in sys.argv[1:]:
     data = corpus.by_name(name); n = len(data)
     ctx = m.Context(); dev = torch.device("cuda", 0)
@@ -18,5 +18,6 @@ for name in sys.argv[1:]:
     plan.execute(d_in, d_out, d_len, d_st); torch.cuda.synchronize()
     lib.mscomp_amd_debug_lz_prof(buf, 1)
     nch = (n + 4095) // 4096
-    tot = sum(buf[:6])
+    tot = sum(buf[:7])
+    print("   finish steps per chunk: %.0f" % (buf[9] / nch))
     print(name, "chunks", nch, "avg cycles/chunk %.0f" % (tot / nch), " | ".join("%s %.0f (%.0f%%)" % (nm, buf[i] / nch, 100.0 * buf[i] / tot) for i, nm in enumerate(names)))
