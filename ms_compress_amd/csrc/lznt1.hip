@@ -54,7 +54,7 @@ __device__ __forceinline__ void     wst16(uint16_t* p, uint32_t v) { __hip_atomi
 __device__ __forceinline__ uint32_t wld16(uint16_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 __device__ __forceinline__ void     wst32(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 __device__ __forceinline__ uint32_t wld32(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
-__device__ __forceinline__ void     wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+__device__ __forceinline__ void     wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local"); }
 
 // DPP scans over the 64 lanes: row_shr 1,2,4,8 then row_bcast 15/31
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)

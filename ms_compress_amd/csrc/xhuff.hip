@@ -448,7 +448,7 @@ __global__ __launch_bounds__(64) void xh_encode_kernel(const uint8_t* __restrict
 		}
 		T += (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
 		R += (uint32_t)__builtin_amdgcn_readlane((int)ir, 63);
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
 		// store the words that are complete now
 		const uint32_t wcomplete = T >> 4;
 		for (uint32_t base = Wdone; base < wcomplete; base += 64u) {
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64) void xh_encode_kernel(const uint8_t* __restrict
 			}
 		}
 		if (wcomplete > Wdone) { Wdone = wcomplete; }
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
 	}
 	// Finish (Bitstream.h:142-147): the current word (zero padded) and one zero word
 	const uint32_t fe = XH_F(T);

@@ -158,9 +158,9 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 			}
 			if ((t & 31u) == 0) { __hip_atomic_store(&s_fpos[(t >> 5) & 3u], (uint32_t)(pos - 4u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 		}
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
 		if (is_m) { atomicOr(&s_facc[(t >> 5) & 3u], 1u << (31u - (uint32_t)(t & 31u))); }
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
 		const u64 N2 = N + (uint32_t)__popcll(tokmask);
 		for (u64 g = N / 32u; g < N2 / 32u; ++g) {                // flag words completed in this window
 			if (lane == 0) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 				__hip_atomic_store(&s_facc[g & 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 			}
 		}
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
 		// carry
 		if (longmask) {
 			const uint32_t ll = 63u - (uint32_t)__builtin_clzll(longmask);        // last long match of the window

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64) void xp_links_kernel(const uint8_t* __restrict_
 				pred = __hip_atomic_load(&s_head[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 				__hip_atomic_store(&s_tmp[h & 4095u], (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
 			const bool loser = valid && __hip_atomic_load(&s_tmp[h & 4095u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) != lane;
 			bool writer = valid;
 			u64 lm = __ballot(loser);
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64) void xp_links_kernel(const uint8_t* __restrict_
 				lk[o] = (uint16_t)pred;
 				if (writer) { __hip_atomic_store(&s_head[h], (uint16_t)o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
 		}
 	}
 	__syncthreads();
