@@ -3,12 +3,13 @@
 // Replaces: lznt1_compress / lznt1_compress_chunk (/root/reference/src/lznt1_compress.cpp:233-273, :49-94) and
 // LZNT1Dictionary::Fill/Find (/root/reference/include/mscomp/LZNT1Dictionary.h:93-106, :114-143).
 //
-// One wavefront (64-thread block) = one 4 KiB chunk, everything staged in LDS (~29 KiB -> 5 chunks in flight per CU):
+// One wavefront (64-thread block) = one 4 KiB chunk, everything staged in LDS (22.5 KiB -> 7 chunks in flight per CU):
 //   A. coalesced 16 B/lane load of the chunk into LDS;
 //   B. dictionary = the reference's per-key position arrays as ONE position-sorted bucket array in LDS, built by a stable
-//      counting sort on a 12-bit hash of the 3-byte key: rank[p] = #earlier positions with the same hash in 64 ascending
-//      batches (one LDS gather + scatter per batch, intra-batch conflicts resolved with ballots), exclusive scan of the
-//      counts (DPP), scatter bucket[start+rank] = p;
+//      counting sort on a 12-bit hash of the 3-byte key: histogram by LDS atomics, exclusive scan of the counts (DPP),
+//      then an ORDERED scatter in 64 ascending batches (one LDS gather + scatter of the bucket cursors per batch,
+//      intra-batch conflicts resolved with ballots). Afterwards cursor[h] = end of bucket h, so the candidates of a
+//      position are simply the entries of its bucket that are smaller than the position itself;
 //   C. window by window (64 positions, lane = position), LAZILY like the reference (Find runs only where the greedy parse
 //      can start a token):
 //        1. every lane at or after the parse position scans the 8 OLDEST candidates of its position itself (4 loads in
@@ -27,13 +28,15 @@ namespace msc {
 
 #ifdef LZ_PROFILE   // dev-only phase timers (s_memtime cycles summed over blocks); not in the production build
 __device__ unsigned long long g_lz_prof[16];
-#define LZ_T(i) if (lane == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_lz_prof[i], t_ - t_prev); t_prev = t_; }
-#define LZ_T0   unsigned long long t_prev = __builtin_readcyclecounter();
-#define LZ_CNT(i, v) if (lane == 0) { atomicAdd(&g_lz_prof[i], (unsigned long long)(v)); }
+#define LZ_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); t_acc[i] += t_ - t_prev; t_prev = t_; }
+#define LZ_T0   unsigned long long t_prev = __builtin_readcyclecounter(); unsigned long long t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define LZ_CNT(i, v) { t_acc[i] += (unsigned long long)(v); }
+#define LZ_TEND if (lane == 0) { for (int i_ = 0; i_ < 10; ++i_) { atomicAdd(&g_lz_prof[i_], t_acc[i_]); } }
 #else
 #define LZ_T(i)
 #define LZ_T0
 #define LZ_CNT(i, v)
+#define LZ_TEND
 #endif
 
 #define LZ_TBL_BITS 12
@@ -74,31 +77,20 @@ __device__ __forceinline__ uint32_t wave_incl_scan_add_u32(uint32_t v)
 	return v;
 }
 
-// Common prefix of d[q..] and the string whose first 16 bytes are o0..o3 (at d[p..]), limited to maxlen (>= 3).
-// The caller has verified the first 3 bytes; x0 = ld32(d+q) ^ o0.
+// Common prefix of d[q..] and the string at d[p..] whose first 16 bytes are o0..o3, limited to maxlen (>= 3); 0 when the
+// first 3 bytes differ (hash collision). The first 16 bytes are compared straight-line (4 independent LDS loads).
 __device__ __forceinline__ uint32_t lz_lcp(const uint8_t* d, uint32_t q, uint32_t p, uint32_t maxlen,
-                                           uint32_t x0, uint32_t o1, uint32_t o2, uint32_t o3)
+                                           uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3)
 {
-	uint32_t l;
-	if (x0) { l = 3u; }
-	else {
-		uint32_t x = ld32(d + q + 4u) ^ o1;
-		if (x || maxlen <= 8u) { l = x ? 4u + ((uint32_t)__builtin_ctz(x) >> 3) : 8u; }
-		else {
-			x = ld32(d + q + 8u) ^ o2;
-			if (x || maxlen <= 12u) { l = x ? 8u + ((uint32_t)__builtin_ctz(x) >> 3) : 12u; }
-			else {
-				x = ld32(d + q + 12u) ^ o3;
-				if (x) { l = 12u + ((uint32_t)__builtin_ctz(x) >> 3); }
-				else {
-					l = 16u;
-					while (l < maxlen) {
-						x = ld32(d + q + l) ^ ld32(d + p + l);
-						if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
-						l += 4u;
-					}
-				}
-			}
+	const uint32_t x0 = ld32(d + q) ^ o0, x1 = ld32(d + q + 4u) ^ o1, x2 = ld32(d + q + 8u) ^ o2, x3 = ld32(d + q + 12u) ^ o3;
+	if (x0 & 0xFFFFFFu) { return 0u; }
+	uint32_t l = x0 ? 3u : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3)
+	                         : x3 ? 12u + ((uint32_t)__builtin_ctz(x3) >> 3) : 16u;
+	if (l == 16u && maxlen > 16u) {
+		while (l < maxlen) {
+			const uint32_t x = ld32(d + q + l) ^ ld32(d + p + l);
+			if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
+			l += 4u;
 		}
 	}
 	return l < maxlen ? l : maxlen;
@@ -108,9 +100,9 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
                                                         uint8_t* __restrict__ slots, uint32_t* __restrict__ slot_size)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t  s_data[4096 + 32];
-	__shared__ __attribute__((aligned(16))) uint16_t s_cnt[LZ_TBL];       // counts -> bucket starts
+	__shared__ __attribute__((aligned(16))) uint16_t s_cnt[LZ_TBL];       // counts -> bucket cursors -> bucket ends
 	__shared__ __attribute__((aligned(16))) uint16_t s_bucket[4096];      // positions sorted by (hash, position)
-	__shared__ __attribute__((aligned(16))) uint16_t s_idx[4096];         // rank -> index of the position in s_bucket
+	__shared__ uint8_t s_tmp[2048];                                        // intra-batch conflict detector (keyed by hash & 2047)
 	__shared__ uint32_t s_flagacc[16];                                     // flag bits of the groups in flight
 	__shared__ uint32_t s_flagpos[16];                                     // their byte position in the image
 
@@ -138,32 +130,17 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 	__syncthreads();
 	LZ_T(0)
 
-	// ---- B1. rank[p] = number of earlier positions with the same hash -------------------------------------------
+	// ---- B1. histogram of the position hashes (two u16 counters per dword) --------------------------------------------
 	const uint32_t nb = (n + 63u) >> 6;
 	for (uint32_t b = 0; b < nb; ++b) {
 		const uint32_t p = b * 64u + lane;
-		const uint32_t h = lz_hash(ld32(s_data + p) & 0xFFFFFFu);
-		const bool mine = p + 2u < n;
-		uint32_t old = 0;
-		if (mine) { old = wld16(&s_cnt[h]); wst16(&s_bucket[h], lane); }   // s_bucket doubles as conflict detector
-		wave_fence();
-		const bool loser = mine && wld16(&s_bucket[h]) != lane;
-		uint32_t rank = old, newcnt = old + 1u;
-		bool writer = mine;
-		u64 lm = __ballot(loser);
-		while (lm) {                                            // one iteration per hash value owned by >1 lane
-			const uint32_t hh = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)ctz64(lm));
-			const bool grp = mine && h == hh;
-			const u64 g = __ballot(grp);
-			if (grp) { rank = old + popc_below(g); newcnt = old + (uint32_t)__popcll(g); writer = (lane == ctz64(g)); }
-			lm &= ~g;
+		if (p + 2u < n) {
+			const uint32_t h = lz_hash(ld32(s_data + p) & 0xFFFFFFu);
+			atomicAdd(reinterpret_cast<uint32_t*>(s_cnt) + (h >> 1), (h & 1u) ? 0x10000u : 1u);
 		}
-		if (mine) { s_idx[p] = (uint16_t)rank; if (writer) { wst16(&s_cnt[h], newcnt); } }
-		wave_fence();
 	}
 	__syncthreads();
 	LZ_T(1)
-
 	// ---- B2. exclusive scan of the 4096 counts -> bucket starts: 8 coalesced rounds of 8 bins per lane ---------
 	{
 		uint32_t run = 0;
@@ -182,12 +159,27 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 		}
 	}
 	__syncthreads();
-	// ---- B3. scatter: bucket[start[h] + rank[p]] = p ------------------------------------------------------------
-	for (uint32_t p = lane; p + 2u < n; p += 64u) {
+	// ---- B3. ordered scatter: bucket[cursor[h]++] = p, 64 positions per step in ascending order ----------------------
+	for (uint32_t b = 0; b < nb; ++b) {
+		const uint32_t p = b * 64u + lane;
 		const uint32_t h = lz_hash(ld32(s_data + p) & 0xFFFFFFu);
-		const uint32_t a = (uint32_t)s_cnt[h] + (uint32_t)s_idx[p];
-		s_bucket[a] = (uint16_t)p;
-		s_idx[p] = (uint16_t)a;
+		const bool mine = p + 2u < n;
+		uint32_t cur0 = 0;
+		if (mine) { cur0 = wld16(&s_cnt[h]); __hip_atomic_store(&s_tmp[h & 2047u], (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+		wave_fence();
+		const bool loser = mine && __hip_atomic_load(&s_tmp[h & 2047u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) != lane;
+		uint32_t slot = cur0, newcur = cur0 + 1u;
+		bool writer = mine;
+		u64 lm = __ballot(loser);
+		while (lm) {                                            // one iteration per hash value shared by >1 lane of the batch
+			const uint32_t hh = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)ctz64(lm));
+			const bool grp = mine && h == hh;
+			const u64 g = __ballot(grp);
+			if (grp) { slot = cur0 + popc_below(g); newcur = cur0 + (uint32_t)__popcll(g); writer = (lane == ctz64(g)); }
+			lm &= ~g;
+		}
+		if (mine) { s_bucket[slot] = (uint16_t)p; if (writer) { wst16(&s_cnt[h], newcur); } }
+		wave_fence();
 	}
 	__syncthreads();
 	LZ_T(2)
@@ -203,37 +195,35 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 		const uint32_t p = wbase + lane;
 		const uint32_t o0 = ld32(s_data + p), o1 = ld32(s_data + p + 4u), o2 = ld32(s_data + p + 8u), o3 = ld32(s_data + p + 12u);
 		const uint32_t shift = lz_shift(p);
-		uint32_t maxlen = 0, s = 0, cnt = 0;
+		uint32_t maxlen = 0, s = 0, e = 0;                        // my candidates: bucket[s..e) entries that are < p (ascending)
 		if (p >= entry && p > 0 && p + 3u <= n) {
 			const uint32_t mask3 = (1u << shift) + 2u;
 			maxlen = (n - p < mask3) ? n - p : mask3;
-			s = s_cnt[lz_hash(o0 & 0xFFFFFFu)];
-			cnt = (uint32_t)s_idx[p] - s;
+			const uint32_t h = lz_hash(o0 & 0xFFFFFFu);
+			e = s_cnt[h];                                          // after B3 the cursor of bucket h is its end
+			s = h ? (uint32_t)s_cnt[h - 1u] : 0u;
 		}
 		// 1. the oldest LZ_SELF candidates, in order, early exit at maxlen (LZNT1Dictionary.h:124-135)
 		uint32_t key = 0;                                       // (len << 12) | (4095 - q): larger = longer, then older
-		bool done = (cnt == 0);
-		const uint32_t self_n = cnt < LZ_SELF ? cnt : LZ_SELF;
+		bool done = false;
+		uint32_t q[LZ_SELF + 1u];
+		#pragma unroll
+		for (uint32_t j = 0; j <= LZ_SELF; ++j) { q[j] = (s + j < e) ? (uint32_t)s_bucket[s + j] : 4096u; }   // 4096 = none (>= p)
+		#pragma unroll
 		for (uint32_t j = 0; j < LZ_SELF; j += 4u) {
-			if (j >= self_n || done) { continue; }
-			uint32_t q[4], x[4];
+			uint32_t l[4];
 			#pragma unroll
-			for (int k = 0; k < 4; ++k) { q[k] = (j + k < self_n) ? (uint32_t)s_bucket[s + j + k] : p; }
-			#pragma unroll
-			for (int k = 0; k < 4; ++k) { x[k] = ld32(s_data + q[k]) ^ o0; }
+			for (int k = 0; k < 4; ++k) { l[k] = (q[j + k] < p) ? lz_lcp(s_data, q[j + k], p, maxlen, o0, o1, o2, o3) : 0u; }
 			#pragma unroll
 			for (int k = 0; k < 4; ++k) {
-				if (!done && j + k < self_n && (x[k] & 0xFFFFFFu) == 0) {
-					const uint32_t l = lz_lcp(s_data, q[k], p, maxlen, x[k] >> 24, o1, o2, o3);
-					if (l > (key >> 12)) { key = (l << 12) | (4095u - q[k]); if (l == maxlen) { done = true; } }
-				}
+				if (!done && l[k] > (key >> 12)) { key = (l[k] << 12) | (4095u - q[j + k]); if (l[k] == maxlen) { done = true; } }
 			}
 		}
-		uint32_t rem = done ? 0u : cnt - self_n;                 // candidates nobody has looked at yet
+		bool unres = !done && q[LZ_SELF] < p;                    // a 9th older candidate exists and max_len was not reached
 		LZ_T(3)
 		// 2. greedy walk; positions with rem != 0 are finished by the whole wave when (and only when) the walk lands on them
-		u64 un = __ballot(rem != 0);                             // unresolved positions
-		u64 mm = __ballot(rem == 0 && (key >> 12) >= 3u);        // resolved positions that have a match
+		u64 un = __ballot(unres);                                // unresolved positions
+		u64 mm = __ballot(!unres && (key >> 12) >= 3u);          // resolved positions that have a match
 		u64 tokmask = 0, matchmask = 0;
 		uint32_t cur = entry;
 		while (cur < wend) {
@@ -243,27 +233,27 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 			const uint32_t j = ctz64(rest);
 			const uint32_t mp = rel + j;
 			if ((un >> mp) & (u64)1) {
-				// finish position wbase+mp: candidates [nextc, endc) of its bucket, oldest first, 64 per step
+				// finish position wbase+mp: the candidates after the first LZ_SELF of its bucket, oldest first, 64 per step
 				const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)s, (int)mp);
-				const uint32_t cL = (uint32_t)__builtin_amdgcn_readlane((int)cnt, (int)mp);
+				const uint32_t eL = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)mp);
 				const uint32_t maxL = (uint32_t)__builtin_amdgcn_readlane((int)maxlen, (int)mp);
 				const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)o0, (int)mp), a1 = (uint32_t)__builtin_amdgcn_readlane((int)o1, (int)mp);
 				const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)o2, (int)mp), a3 = (uint32_t)__builtin_amdgcn_readlane((int)o3, (int)mp);
 				uint32_t kbest = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)mp);
 				const uint32_t pL = wbase + mp;
-				for (uint32_t base = LZ_SELF; base < cL; base += 64u) {
+				for (uint32_t base = sL + LZ_SELF; base < eL; base += 64u) {
 					uint32_t k2 = 0;
-					if (base + lane < cL) {
-						const uint32_t q = s_bucket[sL + base + lane];
-						const uint32_t x = ld32(s_data + q) ^ a0;
-						if ((x & 0xFFFFFFu) == 0) { k2 = (lz_lcp(s_data, q, pL, maxL, x >> 24, a1, a2, a3) << 12) | (4095u - q); }
+					bool past = true;                                  // this lane is at or beyond pL's own entry
+					if (base + lane < eL) {
+						const uint32_t qq = s_bucket[base + lane];
+						if (qq < pL) { past = false; k2 = (lz_lcp(s_data, qq, pL, maxL, a0, a1, a2, a3) << 12) | (4095u - qq); }
 					}
 					LZ_CNT(9, 1)
 					const uint32_t m = wave_max_u32(k2);
 					if ((m >> 12) > (kbest >> 12)) { kbest = m; }    // strictly longer only: older blocks win ties
-					if ((kbest >> 12) == maxL) { break; }             // oldest candidate reaching max_len: stop
+					if ((kbest >> 12) == maxL || __ballot(past)) { break; }   // max_len reached / all older candidates seen
 				}
-				if (lane == mp) { key = kbest; rem = 0; }
+				if (lane == mp) { key = kbest; }
 				un &= ~(((u64)1) << mp);
 				if ((kbest >> 12) >= 3u) { mm |= ((u64)1) << mp; }
 				continue;                                          // re-evaluate from the same cur
@@ -323,6 +313,7 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 	}
 	if (lane == 0) { slot_size[c] = total; }
 	LZ_T(6)
+	LZ_TEND
 }
 #ifdef LZ_PROFILE
 extern "C" void mscomp_amd_debug_lz_prof(unsigned long long* out, int reset)

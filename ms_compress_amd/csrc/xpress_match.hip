@@ -11,7 +11,7 @@
 //                     scatter; the predecessor links leave as coalesced u16 stores. pred(p) restricted to the chunk;
 //                     the chunk's final head table is exported so the NEXT chunk can continue a chain into it
 //                     (a chain never needs to reach further back than one chunk: 65535 / 8192 byte windows).
-//   xp_find_kernel  : one thread per position: walks <= 11 links (MaxChain, Level 3) while inside the window,
+//   xp_find_kernel  : 4096-position tiles, the tile's window staged in LDS; per position: walks <= 11 links (MaxChain, Level 3) while inside the window,
 //                     candidates must share the first 2 bytes, length by 4-byte XOR compares, strictly-longer wins
 //                     (nearest on ties), stop at >= 48 (NiceLength). Lengths are CAPPED at 48 here: the candidate
 //                     choice never depends on more (48 ends the walk); the parse kernels extend the chosen match.
@@ -113,73 +113,115 @@ __global__ __launch_bounds__(64) void xp_links_kernel(const uint8_t* __restrict_
 	}
 }
 
-// One thread per position. max_off = 0x2000 (Xpress) / 0xFFFF (Xpress+Huffman); clip != 0: positions with fewer than
-// 3 bytes left in their 64 KiB chunk get no match (xpress_huff_compress.cpp:90).
-__global__ __launch_bounds__(256) void xp_find_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
+// Find for a tile of 4096 positions per 256-thread block. The tile's whole match window is staged in LDS:
+//   data  [P0-WINDOW, P0+4096+64)  (WINDOW = 8192 for Xpress, 65536 for Xpress+Huffman; clipped at the unit start),
+//   links of the same positions when they fit (Xpress: 24 KiB; Xpress+Huffman would need 136 KiB -> read from L2),
+// so the chain walk (<= 11 dependent steps) and the byte compares are LDS gathers instead of L2 gathers.
+// clip != 0: positions with fewer than 3 bytes left in their 64 KiB chunk get no match (xpress_huff_compress.cpp:90).
+#define XP_TILE 4096u
+template <uint32_t WINDOW, bool LDS_LINKS, uint32_t NT>
+__global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                      const uint16_t* __restrict__ links, const uint16_t* __restrict__ lasthead,
                                                      uint16_t* __restrict__ mlen3, uint16_t* __restrict__ moff,
                                                      uint32_t max_off, int clip)
 {
-	const uint32_t lc = blockIdx.x >> 8;
-	const uint32_t o = ((blockIdx.x & 255u) << 8) + threadIdx.x;
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	uint8_t* const s_data = smem;                                             // WINDOW + XP_TILE + 64 bytes
+	uint16_t* const s_links = reinterpret_cast<uint16_t*>(smem + WINDOW + XP_TILE + 64u);   // WINDOW + XP_TILE entries
+
+	const uint32_t tid = threadIdx.x;
+	const uint32_t lc = blockIdx.x >> 4;
+	const uint32_t tstart = (blockIdx.x & 15u) * XP_TILE;                     // tile start inside the chunk
 	const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, lc);
 	const uint32_t k = lc - bt.chunk_prefix[u];
 	const u64 n = bt.in_len[u];
 	const u64 cbase = (u64)k * 65536u;
 	const uint32_t cn = (n - cbase < 65536u) ? (uint32_t)(n - cbase) : 65536u;
-	if (o >= cn) { return; }
-	const u64 P = cbase + o;
-	const u64 gi = (u64)lc * 65536u + o;
-	uint32_t best = 2, boff = 0;
-	const bool can = (P + 2u < n) && (!clip || cn - o >= 3u);
-	if (can) {
-		const uint8_t* __restrict__ d = d_in + bt.in_off[u];
-		const uint16_t* __restrict__ lk = links + (u64)lc * 65536u;
-		const uint32_t w = ldg32_safe(d, P, n);
-		const uint32_t h = xp_hash3(w);
-		const u64 lim = n - P - 1u;
-		const uint32_t cap = lim < 48u ? (uint32_t)lim : 48u;
-		uint32_t chain = 11;
-		// The exported head table of the previous chunk cannot distinguish "none" from position 65535 (both 0xFFFF):
-		// 65535 is the head exactly when that chunk's last position has this hash.
-		const bool prev_last = (k > 0) && (xp_hash3(ldg32_safe(d, cbase - 1u, n)) == h);
-		bool inprev = false;
-		uint32_t x = lk[o];
-		bool alive = true;
-		if (x == 0xFFFFu) {
-			if (k == 0) { alive = false; }
-			else { x = lasthead[(u64)(lc - 1u) * 32768u + h]; inprev = true; alive = (x != 0xFFFFu) || prev_last; }
-		}
-		while (alive) {
-			const u64 X = inprev ? cbase - 65536u + x : cbase + x;
-			if (P - X > max_off) { break; }
-			if (ld16(d + X) == (w & 0xFFFFu)) {
-				uint32_t l = 0;
-				while (l < cap) {
-					const uint32_t a = ldg32_safe(d, X + l, n) ^ ldg32_safe(d, P + l, n);
-					if (a) { l += (uint32_t)__builtin_ctz(a) >> 3; break; }
-					l += 4;
-				}
-				if (l > cap) { l = cap; }
-				if (l > best) { best = l; boff = (uint32_t)(P - X); if (best >= 48u) { break; } }
-			}
-			if (--chain == 0) { break; }
-			if (!inprev) {
-				x = lk[x];
-				if (x == 0xFFFFu) {
-					if (k == 0) { break; }
-					x = lasthead[(u64)(lc - 1u) * 32768u + h]; inprev = true;
-					if (x == 0xFFFFu && !prev_last) { break; }
-				}
-			} else {
-				x = links[(u64)(lc - 1u) * 65536u + x];     // a link is always < its position, so 0xFFFF is unambiguous here
-				if (x == 0xFFFFu) { break; }
+	if (tstart >= cn) { return; }
+	const uint8_t* __restrict__ d = d_in + bt.in_off[u];
+	const u64 P0 = cbase + tstart;                                            // unit position of the tile start
+	const u64 wstart = P0 >= WINDOW ? P0 - WINDOW : 0;                        // unit position of s_data[0]
+	const u64 wend = (P0 + XP_TILE + 64u < n) ? P0 + XP_TILE + 64u : n;       // staged bytes: [wstart, wend), zero beyond
+	const uint32_t wlen = (uint32_t)(wend - wstart);
+
+	// ---- stage data (16 B / thread when aligned) and links ------------------------------------------------------
+	{
+		const uint8_t* __restrict__ src = d + wstart;
+		const uint32_t nvec = (((uintptr_t)src & 15u) == 0) ? (wlen & ~15u) : 0u;
+		for (uint32_t i = tid * 16u; i < nvec; i += NT * 16u) { *reinterpret_cast<uint4*>(s_data + i) = *reinterpret_cast<const uint4*>(src + i); }
+		for (uint32_t i = nvec + tid; i < wlen; i += NT) { s_data[i] = src[i]; }
+		for (uint32_t i = wlen + tid; i < WINDOW + XP_TILE + 64u; i += NT) { s_data[i] = 0; }
+		if (LDS_LINKS) {
+			const uint32_t npos = (uint32_t)((P0 + XP_TILE < cbase + cn ? P0 + XP_TILE : cbase + cn) - wstart);
+			for (uint32_t r = tid; r < npos; r += NT) {
+				const u64 pos = wstart + r;
+				s_links[r] = links[(u64)(bt.chunk_prefix[u] + (uint32_t)(pos >> 16)) * 65536u + (uint32_t)(pos & 65535u)];
 			}
 		}
 	}
-	const bool m = best >= 3u;
-	mlen3[gi] = (uint16_t)(m ? best - 3u : 0u);
-	moff[gi] = (uint16_t)(m ? boff : 0u);
+	__syncthreads();
+
+	const uint16_t* __restrict__ lk_cur = links + (u64)lc * 65536u;
+	const uint16_t* __restrict__ lk_prev = links + (u64)(lc - (k ? 1u : 0u)) * 65536u;
+	const u64 prevbase = cbase - (k ? 65536u : 0u);
+	const uint32_t tn = (cn - tstart < XP_TILE) ? cn - tstart : XP_TILE;
+	// 65535 as the previous chunk's head is indistinguishable from "none" (0xFFFF): decide by that position's hash
+	const uint32_t prev_last_hash = (k > 0) ? xp_hash3(ldg32_safe(d, cbase - 1u, n)) : 0xFFFFFFFFu;
+
+	for (uint32_t t = tid; t < tn; t += NT) {
+		const uint32_t o = tstart + t;                                          // offset in chunk
+		const u64 P = cbase + o;
+		const uint32_t pr = (uint32_t)(P - wstart);                             // LDS index of P
+		uint32_t best = 2, boff = 0;
+		const bool can = (P + 2u < n) && (!clip || cn - o >= 3u);
+		if (can) {
+			const uint32_t w = ld32(s_data + pr);
+			const uint32_t h = xp_hash3(w);
+			const u64 lim = n - P - 1u;
+			const uint32_t cap = lim < 48u ? (uint32_t)lim : 48u;
+			const bool prev_last = (prev_last_hash == h);
+			uint32_t chain = 11;
+			bool inprev = false;
+			uint32_t x = LDS_LINKS ? (uint32_t)s_links[pr] : (uint32_t)lk_cur[o];
+			bool alive = true;
+			if (x == 0xFFFFu) {
+				if (k == 0) { alive = false; }
+				else { x = lasthead[(u64)(lc - 1u) * 32768u + h]; inprev = true; alive = (x != 0xFFFFu) || prev_last; }
+			}
+			while (alive) {
+				const u64 X = inprev ? prevbase + x : cbase + x;
+				if (P - X > max_off) { break; }
+				const uint32_t xr = (uint32_t)(X - wstart);                         // in the staged window because P-X <= max_off <= WINDOW
+				if (ld16(s_data + xr) == (w & 0xFFFFu)) {
+					uint32_t l = 0;
+					while (l < cap) {
+						const uint32_t a = ld32(s_data + xr + l) ^ ld32(s_data + pr + l);
+						if (a) { l += (uint32_t)__builtin_ctz(a) >> 3; break; }
+						l += 4;
+					}
+					if (l > cap) { l = cap; }
+					if (l > best) { best = l; boff = (uint32_t)(P - X); if (best >= 48u) { break; } }
+				}
+				if (--chain == 0) { break; }
+				if (!inprev) {
+					x = LDS_LINKS ? (uint32_t)s_links[xr] : (uint32_t)lk_cur[x];
+					if (x == 0xFFFFu) {
+						if (k == 0) { break; }
+						x = lasthead[(u64)(lc - 1u) * 32768u + h]; inprev = true;
+						if (x == 0xFFFFu && !prev_last) { break; }
+					}
+				} else {
+					// a link is always < its position, so 0xFFFF is unambiguous here
+					x = (LDS_LINKS && X >= wstart) ? (uint32_t)s_links[xr] : (uint32_t)lk_prev[x];
+					if (x == 0xFFFFu) { break; }
+				}
+			}
+		}
+		const bool m = best >= 3u;
+		const u64 gi = (u64)lc * 65536u + o;
+		mlen3[gi] = (uint16_t)(m ? best - 3u : 0u);
+		moff[gi] = (uint16_t)(m ? boff : 0u);
+	}
 }
 
 void launch_xp_links(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead)
@@ -194,7 +236,19 @@ void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, 
                     uint16_t* mlen3, uint16_t* moff, uint32_t max_off, int clip)
 {
 	if (bt.n_chunks == 0) { return; }
-	hipLaunchKernelGGL(xp_find_kernel, dim3(bt.n_chunks * 256u), dim3(256), 0, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip);
+	static bool attr_set = false;
+	const uint32_t lds_xp = 0x2000u + XP_TILE + 64u + (0x2000u + XP_TILE) * 2u;      // data + links in LDS
+	const uint32_t lds_xh = 0x10000u + XP_TILE + 64u;                                 // data in LDS, links from L2
+	if (!attr_set) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x2000u, true, 512u>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xp);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x10000u, false, 1024u>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xh);
+		attr_set = true;
+	}
+	if (max_off <= 0x2000u) {
+		hipLaunchKernelGGL((xp_find_kernel<0x2000u, true, 512u>), dim3(bt.n_chunks * 16u), dim3(512), lds_xp, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip);
+	} else {
+		hipLaunchKernelGGL((xp_find_kernel<0x10000u, false, 1024u>), dim3(bt.n_chunks * 16u), dim3(1024), lds_xh, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip);
+	}
 }
 
 } // namespace msc
