@@ -68,6 +68,14 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 #undef MSC_DPP_MAX
 	return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+__device__ __forceinline__ uint32_t wave_incl_scan_max(uint32_t v)
+{
+#define MSC_DPP_MAX(ctrl, rmask) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false); v = o > v ? o : v; }
+	MSC_DPP_MAX(0x111, 0xf) MSC_DPP_MAX(0x112, 0xf) MSC_DPP_MAX(0x114, 0xf) MSC_DPP_MAX(0x118, 0xf)
+	MSC_DPP_MAX(0x142, 0xa) MSC_DPP_MAX(0x143, 0xc)
+#undef MSC_DPP_MAX
+	return v;
+}
 __device__ __forceinline__ uint32_t wave_incl_scan_add_u32(uint32_t v)
 {
 #define MSC_DPP_ADD(ctrl, rmask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, true);
@@ -224,14 +232,15 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 		// 2. greedy walk; positions with rem != 0 are finished by the whole wave when (and only when) the walk lands on them
 		u64 un = __ballot(unres);                                // unresolved positions
 		u64 mm = __ballot(!unres && (key >> 12) >= 3u);          // resolved positions that have a match
-		u64 tokmask = 0, matchmask = 0;
-		uint32_t cur = entry;
-		while (cur < wend) {
-			const uint32_t rel = cur - wbase;
+		// The serial loop only decides which candidates are TAKEN; everything else (which positions are literal tokens)
+		// is derived in parallel afterwards.
+		u64 matchmask = 0;
+		uint32_t rel = entry > wbase ? entry - wbase : 0u;       // next token start, relative to the window
+		const uint32_t wn = wend - wbase;
+		while (rel < wn) {
 			const u64 rest = (un | mm) >> rel;
-			if (rest == 0) { tokmask |= (~(u64)0) << rel; cur = wend; break; }
-			const uint32_t j = ctz64(rest);
-			const uint32_t mp = rel + j;
+			if (rest == 0) { break; }
+			const uint32_t mp = rel + ctz64(rest);
 			if ((un >> mp) & (u64)1) {
 				// finish position wbase+mp: the candidates after the first LZ_SELF of its bucket, oldest first, 64 per step
 				const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)s, (int)mp);
@@ -256,19 +265,25 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 				if (lane == mp) { key = kbest; }
 				un &= ~(((u64)1) << mp);
 				if ((kbest >> 12) >= 3u) { mm |= ((u64)1) << mp; }
-				continue;                                          // re-evaluate from the same cur
+				rel = mp;                                          // literals before mp are settled; re-evaluate mp itself
+				continue;
 			}
-			tokmask |= ((((u64)2) << j) - (u64)1) << rel;        // j literals + the match start
 			matchmask |= ((u64)1) << mp;
-			cur = wbase + mp + ((uint32_t)__builtin_amdgcn_readlane((int)key, (int)mp) >> 12);
+			rel = mp + ((uint32_t)__builtin_amdgcn_readlane((int)key, (int)mp) >> 12);
 		}
-		if (wend - wbase < 64u) { tokmask &= (((u64)1) << (wend - wbase)) - (u64)1; }
+		// tokens of the window = positions >= entry that no taken match covers: covered <=> the furthest end of the taken
+		// matches starting at or before me lies beyond me and I am not such a start myself
+		const bool is_m = (matchmask >> lane) & (u64)1;
+		const uint32_t mend = is_m ? p + (key >> 12) : 0u;
+		const uint32_t reach = wave_incl_scan_max(mend);
+		const bool is_tok = p >= entry && p < wend && (is_m || reach <= p);
+		const u64 tokmask = __ballot(is_tok);
+		const uint32_t wreach = (uint32_t)__builtin_amdgcn_readlane((int)reach, 63);
+		const uint32_t cur = wreach > wend ? wreach : wend;
 		entry = cur;
 		LZ_T(4)
 
 		// 3. emit: pos(t) = 2 (header) + (t div 8 + 1) + sum size(u<t)
-		const bool is_tok = (tokmask >> lane) & (u64)1;
-		const bool is_m = (matchmask >> lane) & (u64)1;
 		const uint32_t tb = popc_below(tokmask), mbl = popc_below(matchmask);
 		const uint32_t t = T + tb;
 		const uint32_t pos = 3u + (t >> 3) + S + tb + mbl;
