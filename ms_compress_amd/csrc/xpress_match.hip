@@ -6,9 +6,10 @@
 //
 // The reference keeps one head table (32768 pointers) + a predecessor ring for the whole buffer and inserts
 // positions serially. Here every 64 KiB slice ("link chunk") of a unit is independent:
-//   xp_links_kernel : one wavefront per link chunk, head table (32768 x u16 = 64 KiB) in LDS. Positions are inserted
-//                     64 at a time: one LDS gather of the heads, ballot-resolved intra-batch hash conflicts, one LDS
-//                     scatter; the predecessor links leave as coalesced u16 stores. pred(p) restricted to the chunk;
+//   xp_links_kernel : one 256-thread block per link chunk, head table (32768 x u16 = 64 KiB) in LDS. Positions are
+//                     inserted 64 at a time: ballot-resolved intra-batch hash conflicts (3 producer waves, no serial
+//                     dependency), then one LDS gather + scatter of the heads per 64 positions (1 consumer wave); the
+//                     predecessor links leave as coalesced u16 stores. pred(p) restricted to the chunk;
 //                     the chunk's final head table is exported so the NEXT chunk can continue a chain into it
 //                     (a chain never needs to reach further back than one chunk: 65535 / 8192 byte windows).
 //   xp_find_kernel  : 4096-position tiles, the tile's window staged in LDS; per position: walks <= 11 links (MaxChain, Level 3) while inside the window,
@@ -36,15 +37,34 @@ __device__ __forceinline__ uint32_t ldg32_safe(const uint8_t* __restrict__ d, u6
 	return v;
 }
 
-__global__ __launch_bounds__(64) void xp_links_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
-                                                     uint16_t* __restrict__ links, uint16_t* __restrict__ lasthead)
-{
-	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];          // 64 KiB heads + stage + conflict detector
-	uint16_t* const s_head = reinterpret_cast<uint16_t*>(smem);
-	uint8_t* const s_stage = smem + 65536u;
-	uint8_t* const s_tmp = smem + 65536u + 4096u + 16u;
+#ifdef XL_PROFILE
+__device__ unsigned long long g_xl_prof[8];
+extern "C" void mscomp_amd_debug_xl_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xl_prof), 64); unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xl_prof), z, 64); }
+#define XL_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); xl_acc[i] += t_ - xl_prev; xl_prev = t_; }
+#else
+#define XL_T(i)
+#endif
+// LDS of xp_links_kernel: heads | per-position info (2 tiles) | staged tile bytes | 14 conflict detectors
+#define XL_INFO_OFF   65536u
+#define XL_STAGE_OFF  (XL_INFO_OFF + 2u * 4096u * 4u)
+#define XL_TMP_OFF    (XL_STAGE_OFF + 4096u + 16u)
+#define XL_LDS_BYTES  (XL_TMP_OFF + 14u * 2048u)
 
-	const uint32_t lane = threadIdx.x;
+// One 256-thread block per 64 KiB link chunk, software-pipelined over 4096-position tiles:
+//   waves 2-15 (producers): hash of every position of tile t and the intra-batch (64 positions) conflict resolution -- which
+//       earlier lane of the batch has the same hash, which lane is the last one with it -- none of which depends on the
+//       serial head table; result = one info word per position;
+//   waves 0-1 (consumers, one per hash parity): the serial pass over tile t-1: per 64 positions ONE LDS gather of the heads (lanes without an
+//       in-batch predecessor), one coalesced store of the links, ONE LDS scatter (last lane of every hash).
+__global__ __launch_bounds__(1024) void xp_links_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
+                                                      uint16_t* __restrict__ links, uint16_t* __restrict__ lasthead)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	uint16_t* const s_head = reinterpret_cast<uint16_t*>(smem);
+	uint32_t* const s_info = reinterpret_cast<uint32_t*>(smem + XL_INFO_OFF);
+	uint8_t* const s_stage = smem + XL_STAGE_OFF;
+
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
 	const uint32_t lc = blockIdx.x;
 	const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, lc);
 	const uint32_t k = lc - bt.chunk_prefix[u];
@@ -55,61 +75,102 @@ __global__ __launch_bounds__(64) void xp_links_kernel(const uint8_t* __restrict_
 	const uint8_t* __restrict__ src = d_in + bt.in_off[u] + cbase;
 	const u64 avail = n - cbase;                                                          // readable bytes from src
 	uint16_t* __restrict__ lk = links + (u64)lc * 65536u;
+	uint8_t* const s_tmp = smem + XL_TMP_OFF + (wv >= 2u ? wv - 2u : 0u) * 2048u;
 
-	for (uint32_t i = lane * 8u; i < 32768u; i += 512u) { *reinterpret_cast<uint4*>(s_head + i) = make_uint4(~0u, ~0u, ~0u, ~0u); }
+	for (uint32_t i = tid * 8u; i < 32768u; i += 8192u) { *reinterpret_cast<uint4*>(s_head + i) = make_uint4(~0u, ~0u, ~0u, ~0u); }
 
-	for (uint32_t tbase = 0; tbase < ins; tbase += 4096u) {
-		__syncthreads();
-		// stage 4096+4 bytes (zero beyond the unit end)
-		const bool vec = (((uintptr_t)(src + tbase) & 15u) == 0);
-		for (uint32_t i = lane * 16u; i < 4096u + 16u; i += 1024u) {
-			uint4 v = make_uint4(0, 0, 0, 0);
-			if (vec && (u64)tbase + i + 16u <= avail) { v = *reinterpret_cast<const uint4*>(src + tbase + i); }
-			else {
-				uint32_t w[4] = { 0, 0, 0, 0 };
-				for (uint32_t b = 0; b < 16u; ++b) { if ((u64)tbase + i + b < avail) { w[b >> 2] |= (uint32_t)src[tbase + i + b] << (8u * (b & 3u)); } }
-				v = make_uint4(w[0], w[1], w[2], w[3]);
-			}
-			*reinterpret_cast<uint4*>(s_stage + i) = v;
-		}
-		__syncthreads();
-		const uint32_t tn = (ins - tbase < 4096u) ? ins - tbase : 4096u;
-		for (uint32_t b = 0; b * 64u < tn; ++b) {
-			const uint32_t r = b * 64u + lane;                    // position inside the tile
-			const uint32_t o = tbase + r;                          // position inside the chunk
-			const bool valid = r < tn;
-			const uint32_t h = xp_hash3(ld32(s_stage + r));
-			uint32_t pred = 0xFFFFu;
-			if (valid) {
-				pred = __hip_atomic_load(&s_head[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-				__hip_atomic_store(&s_tmp[h & 4095u], (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
-			const bool loser = valid && __hip_atomic_load(&s_tmp[h & 4095u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) != lane;
-			bool writer = valid;
-			u64 lm = __ballot(loser);
-			while (lm) {                                          // one iteration per hash shared by >1 lane of the batch
-				const uint32_t hh = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)ctz64(lm));
-				const bool grp = valid && h == hh;
-				const u64 g = __ballot(grp);
-				if (grp) {
-					const u64 below = g & ((((u64)1) << lane) - 1u);
-					if (below) { pred = tbase + b * 64u + (63u - (uint32_t)__builtin_clzll(below)); }   // nearest earlier lane
-					writer = (lane == 63u - (uint32_t)__builtin_clzll(g));                             // head = latest position
+	if (wv < 2u) { __builtin_amdgcn_s_setprio(3); }            // the serial consumers are the critical path of the pipeline
+	const uint32_t ntiles = (ins + 4095u) >> 12;
+#ifdef XL_PROFILE
+	unsigned long long xl_acc[4] = {0, 0, 0, 0}, xl_prev = __builtin_readcyclecounter();
+#endif
+	for (uint32_t t = 0; t <= ntiles; ++t) {
+		const uint32_t tbase = t * 4096u;
+		XL_T(3)
+		if (t < ntiles) {                                         // stage 4096+16 bytes of tile t (zero beyond the unit end)
+			const bool vec = (((uintptr_t)(src + tbase) & 15u) == 0);
+			for (uint32_t i = tid * 16u; i < 4096u + 16u; i += 16384u) {
+				uint4 v = make_uint4(0, 0, 0, 0);
+				if (vec && (u64)tbase + i + 16u <= avail) { v = *reinterpret_cast<const uint4*>(src + tbase + i); }
+				else {
+					uint32_t w[4] = { 0, 0, 0, 0 };
+					for (uint32_t bb = 0; bb < 16u; ++bb) { if ((u64)tbase + i + bb < avail) { w[bb >> 2] |= (uint32_t)src[tbase + i + bb] << (8u * (bb & 3u)); } }
+					v = make_uint4(w[0], w[1], w[2], w[3]);
 				}
-				lm &= ~g;
+				*reinterpret_cast<uint4*>(s_stage + i) = v;
 			}
-			if (valid) {
-				lk[o] = (uint16_t)pred;
-				if (writer) { __hip_atomic_store(&s_head[h], (uint16_t)o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
-			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
 		}
+		__syncthreads();
+		XL_T(0)
+		if (wv >= 2u) {
+			if (t < ntiles) {                                     // ---- producers: info words of tile t
+				const uint32_t tn = (ins - tbase < 4096u) ? ins - tbase : 4096u;
+				uint32_t* const info = s_info + (t & 1u) * 4096u;
+				for (uint32_t b = wv - 2u; b * 64u < tn; b += 14u) {
+					const uint32_t r = b * 64u + lane;
+					const bool valid = r < tn;
+					const uint32_t h = xp_hash3(ld32(s_stage + r));
+					if (valid) { __hip_atomic_store(&s_tmp[h & 2047u], (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+					const bool loser = valid && __hip_atomic_load(&s_tmp[h & 2047u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) != lane;
+					// one iteration per hash shared by >1 lane of the batch: only capture the group's lane mask here
+					u64 mygrp = 0;
+					u64 lm = __ballot(loser);
+					while (lm) {
+						const uint32_t hh = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)ctz64(lm));
+						const u64 g = __ballot(valid && h == hh);
+						if (h == hh) { mygrp = g; }
+						lm &= ~g;
+					}
+					uint32_t prevlane = 0xFFu;
+					bool writer = valid;
+					if (mygrp) {
+						const u64 below = mygrp & ((((u64)1) << lane) - 1u);
+						if (below) { prevlane = 63u - (uint32_t)__builtin_clzll(below); }           // nearest earlier lane
+						writer = (lane == 63u - (uint32_t)__builtin_clzll(mygrp));                  // head = latest position
+					}
+					info[r] = h | ((uint32_t)writer << 15) | (prevlane << 16) | ((uint32_t)valid << 24);
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+				}
+			}
+		} else if (t > 0) {                                       // ---- consumer: serial head pass over tile t-1
+			// 4 batches per round: all info words first, then gather/scatter of the heads ISSUED in order without waiting
+			// (DS operations of a wave execute in order, so batch b+1's gather sees batch b's scatter); links stored last.
+			const uint32_t pbase = tbase - 4096u;
+			const uint32_t tn = (ins - pbase < 4096u) ? ins - pbase : 4096u;
+			const uint32_t* const info = s_info + ((t - 1u) & 1u) * 4096u;
+			for (uint32_t b0 = 0; b0 * 64u < tn; b0 += 8u) {
+				uint32_t w[8], pred[8];
+				#pragma unroll
+				for (int j = 0; j < 8; ++j) { w[j] = info[((b0 + j) * 64u + lane) & 4095u]; }          // unconditional: waits once
+				#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					if (((w[j] >> 24) == 0) || ((w[j] & 1u) != wv) || (b0 + j) * 64u + lane >= tn) { w[j] = 0; }   // stale / other consumer's class
+					const uint32_t h = w[j] & 0x7FFFu;
+					const uint32_t o = pbase + (b0 + j) * 64u + lane;
+					// unconditional gather (idle lanes read head[0] and ignore it): no wait between the 8 gather/scatter pairs
+					pred[j] = __hip_atomic_load(&s_head[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+					if (w[j] & 0x8000u) { __hip_atomic_store(&s_head[h], (uint16_t)o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+				}
+				#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					const uint32_t pl = (w[j] >> 16) & 0xFFu;
+					if (pl != 0xFFu) { pred[j] = pbase + (b0 + j) * 64u + pl; }
+				}
+				#pragma unroll
+				for (int j = 0; j < 8; ++j) { if (w[j]) { lk[pbase + (b0 + j) * 64u + lane] = (uint16_t)pred[j]; } }
+			}
+		}
+		XL_T(1)
+		__syncthreads();
+		XL_T(2)
 	}
-	__syncthreads();
+#ifdef XL_PROFILE
+	if (lane == 0 && (wv == 0 || wv == 2)) { for (int i_ = 0; i_ < 4; ++i_) { atomicAdd(&g_xl_prof[(wv >> 1) * 4 + i_], xl_acc[i_]); } }
+#endif
 	if (lc + 1u < bt.chunk_prefix[u + 1]) {                     // a later chunk of this unit continues chains into this one
 		uint16_t* __restrict__ lh = lasthead + (u64)lc * 32768u;
-		for (uint32_t i = lane * 8u; i < 32768u; i += 512u) { *reinterpret_cast<uint4*>(lh + i) = *reinterpret_cast<const uint4*>(s_head + i); }
+		for (uint32_t i = tid * 8u; i < 32768u; i += 8192u) { *reinterpret_cast<uint4*>(lh + i) = *reinterpret_cast<const uint4*>(s_head + i); }
 	}
 }
 
@@ -227,10 +288,10 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 void launch_xp_links(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead)
 {
 	if (bt.n_chunks == 0) { return; }
-	const uint32_t lds = 65536u + 4096u + 16u + 4096u;
+	const uint32_t lds = XL_LDS_BYTES;
 	static bool attr_set = false;
 	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_links_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-	hipLaunchKernelGGL(xp_links_kernel, dim3(bt.n_chunks), dim3(64), lds, st, d_in, bt, links, lasthead);
+	hipLaunchKernelGGL(xp_links_kernel, dim3(bt.n_chunks), dim3(1024), lds, st, d_in, bt, links, lasthead);
 }
 void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead,
                     uint16_t* mlen3, uint16_t* moff, uint32_t max_off, int clip)
