@@ -26,6 +26,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v)
 	return v;
 }
 
+__device__ __forceinline__ uint32_t wave_incl_scan_max_u32(uint32_t v)
+{
+#define MSC_DPP_MAX(ctrl, rmask) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false); v = o > v ? o : v; }
+	MSC_DPP_MAX(0x111, 0xf) MSC_DPP_MAX(0x112, 0xf) MSC_DPP_MAX(0x114, 0xf) MSC_DPP_MAX(0x118, 0xf)
+	MSC_DPP_MAX(0x142, 0xa) MSC_DPP_MAX(0x143, 0xc)
+#undef MSC_DPP_MAX
+	return v;
+}
+
 __device__ __forceinline__ uint32_t ldg32_lim(const uint8_t* __restrict__ d, u64 pos, u64 n)
 {
 	if (pos + 4u <= n) { return ld32(d + pos); }
@@ -77,33 +86,41 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 	u64 cur = 0, F = 0, S = 0, N = 0, R = 0;                      // next token start, filled, sum sizes, tokens, long matches
 	bool pend = false; u64 pend_pos = 0; uint32_t pend_low = 0;   // length nibble byte waiting for its high half
 
+	// software prefetch: the next window's (offset, length, byte) are loaded (unconditionally, clamped index) while the
+	// current window is parsed and emitted
+	uint32_t off_n = 0, L_n = 0, byte_n = 0;
+	if (n) { const u64 p0 = lane < n ? lane : n - 1u; off_n = moff[mbase + p0]; L_n = mlen3[mbase + p0]; byte_n = d[p0]; }
 	for (u64 wbase = 0; wbase < n; wbase += 64u) {
 		const u64 wend = (wbase + 64u < n) ? wbase + 64u : n;
-		if (cur >= wend) { continue; }                            // window wholly covered by a match
 		const u64 p = wbase + lane;
 		const bool inr = p < n;
-		uint32_t off = 0, L = 0, byte = 0;
-		if (inr) { off = moff[mbase + p]; L = mlen3[mbase + p]; byte = d[p]; }
+		uint32_t off = inr ? off_n : 0u, L = L_n;
+		const uint32_t byte = byte_n;
+		{
+			const u64 pn = p + 64u < n ? p + 64u : n - 1u;
+			off_n = moff[mbase + pn]; L_n = mlen3[mbase + pn]; byte_n = d[pn];
+		}
+		if (cur >= wend) { continue; }                            // window wholly covered by a match
 		const u64 mm = __ballot(inr && off != 0 && p >= cur);
-		u64 tokmask = 0, matchmask = 0;
+		// The serial loop only decides which candidates are TAKEN (incl. the lagging-fill rule); the token mask is derived
+		// in parallel afterwards.
+		u64 matchmask = 0;
+		const u64 cur_entry = cur;
 		while (cur < wend) {
 			if (cur < end2) {
 				if (F <= cur) { F = (F + 0x2000u < end2) ? F + 0x2000u : end2; }          // this token's lazy Fill (:269)
-				if (cur >= F) { tokmask |= ((u64)1) << (cur - wbase); ++cur; continue; }   // lagging fill => literal
+				if (cur >= F) { ++cur; continue; }                                         // lagging fill => literal
 			}
 			const uint32_t rel = (uint32_t)(cur - wbase);
 			const u64 rest = (mm >> rel);
 			if (rest == 0) {
-				tokmask |= (~(u64)0) << rel;
 				const u64 lastp = (wend - 1u < end2) ? wend - 1u : end2;              // fills done by the literal tokens up to wend
 				if (end2 && F <= lastp && lastp < end2) { F = (F + 0x2000u < end2) ? F + 0x2000u : end2; }
 				cur = wend;
 				break;
 			}
-			const uint32_t j = ctz64(rest);
-			const uint32_t mp = rel + j;
+			const uint32_t mp = rel + ctz64(rest);
 			const u64 pm = wbase + mp;
-			tokmask |= ((((u64)2) << j) - (u64)1) << rel;        // j literals + the match start
 			if (F <= pm) { F = (F + 0x2000u < end2) ? F + 0x2000u : end2; }            // fill by a token in (cur, pm]
 			matchmask |= ((u64)1) << mp;
 			u64 Lm = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)mp);
@@ -115,11 +132,14 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 			}
 			cur = pm + Lm + 3u;
 		}
-		if (wend - wbase < 64u) { tokmask &= (((u64)1) << (wend - wbase)) - (u64)1; }
+		// tokens = positions of the window at/after the entry that no taken match covers
+		const bool is_m = (matchmask >> lane) & (u64)1;
+		const uint32_t mend = is_m ? (L < 0xFFFFFFu ? lane + L + 3u : 0xFFFFFFFFu) : 0u;       // match end, relative to the window
+		const uint32_t reach = wave_incl_scan_max_u32(mend);
+		const bool is_tok = p >= cur_entry && inr && (is_m || reach <= lane);
+		const u64 tokmask = __ballot(is_tok);
 
 		// ---- emit ----------------------------------------------------------------------------------------------
-		const bool is_tok = (tokmask >> lane) & (u64)1;
-		const bool is_m = (matchmask >> lane) & (u64)1;
 		const bool lng = is_m && L >= 7u;
 		const u64 longmask = __ballot(lng);
 		const u64 r = R + popc_below(longmask);
