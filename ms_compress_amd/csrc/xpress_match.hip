@@ -253,7 +253,9 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 				const u64 X = inprev ? prevbase + x : cbase + x;
 				if (P - X > max_off) { break; }
 				const uint32_t xr = (uint32_t)(X - wstart);                         // in the staged window because P-X <= max_off <= WINDOW
-				if (ld16(s_data + xr) == (w & 0xFFFFu)) {
+				// a candidate only matters if it is STRICTLY longer than the best so far: it must agree at index `best` too
+				// (the reference compares everything, XpressDictionary.h:164-176; the outcome is the same)
+				if (ld16(s_data + xr) == (w & 0xFFFFu) && s_data[xr + best] == s_data[pr + best]) {
 					uint32_t l = 0;
 					while (l < cap) {
 						const uint32_t a = ld32(s_data + xr + l) ^ ld32(s_data + pr + l);
