@@ -63,6 +63,13 @@ __device__ __forceinline__ u64 wave_extend(const uint8_t* __restrict__ d, u64 a,
 	return maxadd;
 }
 
+#ifdef XE_PROFILE
+__device__ unsigned long long g_xe_prof[8];
+extern "C" void mscomp_amd_debug_xe_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xe_prof), 64); unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xe_prof), z, 64); }
+#define XE_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); xe_acc[i] += t_ - xe_prev; xe_prev = t_; }
+#else
+#define XE_T(i)
+#endif
 __device__ __forceinline__ void put8(uint8_t* __restrict__ out, u64 cap, u64 pos, uint32_t v) { if (pos < cap) { out[pos] = (uint8_t)v; } }
 
 __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
@@ -86,26 +93,66 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 	u64 cur = 0, F = 0, S = 0, N = 0, R = 0;                      // next token start, filled, sum sizes, tokens, long matches
 	bool pend = false; u64 pend_pos = 0; uint32_t pend_low = 0;   // length nibble byte waiting for its high half
 
-	// software prefetch: the next window's (offset, length, byte) are loaded (unconditionally, clamped index) while the
-	// current window is parsed and emitted
-	uint32_t off_n = 0, L_n = 0, byte_n = 0;
-	if (n) { const u64 p0 = lane < n ? lane : n - 1u; off_n = moff[mbase + p0]; L_n = mlen3[mbase + p0]; byte_n = d[p0]; }
+	// Inputs are burst-loaded 8 windows (512 positions) at a time into a double-buffered LDS stage: one wait on global
+	// memory per 512 positions instead of one per window (loads are unconditional with a clamped index).
+	__shared__ uint16_t s_in_off[2][512];
+	__shared__ uint16_t s_in_len[2][512];
+	__shared__ uint8_t  s_in_byte[2][512];
+	uint32_t g_off[8], g_len[8], g_byte[8];
+#define XE_BURST_LOAD(gbase) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { \
+		const u64 q_ = (gbase) + (u64)k_ * 64u + lane; const u64 c_ = q_ < n ? q_ : n - 1u; \
+		g_off[k_] = moff[mbase + c_]; g_len[k_] = mlen3[mbase + c_]; g_byte[k_] = d[c_]; } }
+#define XE_BURST_STORE(buf) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { \
+		s_in_off[buf][k_ * 64 + lane] = (uint16_t)g_off[k_]; s_in_len[buf][k_ * 64 + lane] = (uint16_t)g_len[k_]; s_in_byte[buf][k_ * 64 + lane] = (uint8_t)g_byte[k_]; } }
+	if (n) { XE_BURST_LOAD((u64)0) }
+#ifdef XE_PROFILE
+	unsigned long long xe_acc[6] = {0, 0, 0, 0, 0, 0}, xe_prev = __builtin_readcyclecounter();
+#endif
 	for (u64 wbase = 0; wbase < n; wbase += 64u) {
+		XE_T(5)
+		const uint32_t wi = (uint32_t)((wbase >> 6) & 7u), buf = (uint32_t)((wbase >> 9) & 1u);
+		if (wi == 0) {                                            // group start: publish this group's inputs, start loading the next
+			XE_BURST_STORE(buf)
+			if (wbase + 512u < n) { XE_BURST_LOAD(wbase + 512u) }
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+		}
 		const u64 wend = (wbase + 64u < n) ? wbase + 64u : n;
 		const u64 p = wbase + lane;
 		const bool inr = p < n;
-		uint32_t off = inr ? off_n : 0u, L = L_n;
-		const uint32_t byte = byte_n;
-		{
-			const u64 pn = p + 64u < n ? p + 64u : n - 1u;
-			off_n = moff[mbase + pn]; L_n = mlen3[mbase + pn]; byte_n = d[pn];
-		}
 		if (cur >= wend) { continue; }                            // window wholly covered by a match
+		uint32_t off = inr ? (uint32_t)s_in_off[buf][wi * 64u + lane] : 0u, L = s_in_len[buf][wi * 64u + lane];
+		const uint32_t byte = s_in_byte[buf][wi * 64u + lane];
 		const u64 mm = __ballot(inr && off != 0 && p >= cur);
+		XE_T(0)
 		// The serial loop only decides which candidates are TAKEN (incl. the lagging-fill rule); the token mask is derived
 		// in parallel afterwards.
 		u64 matchmask = 0;
 		const u64 cur_entry = cur;
+		const uint32_t wn = (uint32_t)(wend - wbase);
+		// Fast path (all but ~1 window in 128): `filled` (F) lies beyond this window and no token of it can reach F, so the
+		// lazy-Fill rule cannot fire (F > position for every token start in the window) -- plain 32-bit walk.
+		// F only moves when a token start reaches it; a match that ends beyond F is handled by the exact loop below.
+		if (F > wend || wbase >= end2) {
+			uint32_t rel = (uint32_t)(cur - wbase);
+			bool far = false;
+			while (rel < wn) {
+				const u64 rest = mm >> rel;
+				if (rest == 0) { rel = wn; break; }
+				const uint32_t mp = rel + ctz64(rest);
+				matchmask |= ((u64)1) << mp;
+				uint32_t Lm = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)mp);
+				if (Lm == 45u) {                                  // the finder capped this match at 48: extend it
+					const u64 pm = wbase + mp;
+					const u64 x = pm - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
+					const u64 ext = 45u + wave_extend(d, x + 48u, pm + 48u, n - pm - 1u - 48u, n, lane);
+					if (lane == mp) { L = (uint32_t)ext; }
+					if (ext > 0x10000u) { cur = pm + ext + 3u; far = true; break; }
+					Lm = (uint32_t)ext;
+				}
+				rel = mp + Lm + 3u;
+			}
+			if (!far) { cur = wbase + rel; }
+		} else
 		while (cur < wend) {
 			if (cur < end2) {
 				if (F <= cur) { F = (F + 0x2000u < end2) ? F + 0x2000u : end2; }          // this token's lazy Fill (:269)
@@ -132,6 +179,7 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 			}
 			cur = pm + Lm + 3u;
 		}
+		XE_T(1)
 		// tokens = positions of the window at/after the entry that no taken match covers
 		const bool is_m = (matchmask >> lane) & (u64)1;
 		const uint32_t mend = is_m ? (L < 0xFFFFFFu ? lane + L + 3u : 0xFFFFFFFFu) : 0u;       // match end, relative to the window
@@ -178,6 +226,7 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 			}
 			if ((t & 31u) == 0) { __hip_atomic_store(&s_fpos[(t >> 5) & 3u], (uint32_t)(pos - 4u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 		}
+		XE_T(2)
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
 		if (is_m) { atomicOr(&s_facc[(t >> 5) & 3u], 1u << (31u - (uint32_t)(t & 31u))); }
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
@@ -206,7 +255,11 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 		}
 		N = N2;
 		S += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		XE_T(3)
 	}
+#ifdef XE_PROFILE
+	if (lane == 0) { for (int i_ = 0; i_ < 6; ++i_) { atomicAdd(&g_xe_prof[i_], xe_acc[i_]); } }
+#endif
 
 	// ---- final flag word (:343-344), size, status ----------------------------------------------------------------
 	const u64 gf = N / 32u;

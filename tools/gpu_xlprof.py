@@ -12,7 +12,7 @@ d_in = torch.from_numpy(data).to(dev); d_out = torch.empty(tot + 16, dtype=torch
 d_len = torch.zeros(len(lens), dtype=torch.int64, device=dev); d_st = torch.zeros(len(lens), dtype=torch.int32, device=dev)
 plan = m.Plan(ctx, 3, in_off, lens, out_off, caps)
 plan.execute(d_in, d_out, d_len, d_st); torch.cuda.synchronize()
-buf = (C.c_ulonglong * 8)(); lib.mscomp_amd_debug_xl_prof(buf)
-plan.execute(d_in, d_out, d_len, d_st); torch.cuda.synchronize(); lib.mscomp_amd_debug_xl_prof(buf)
+buf = (C.c_ulonglong * 8)(); lib.mscomp_amd_debug_xe_prof(buf)
+plan.execute(d_in, d_out, d_len, d_st); torch.cuda.synchronize(); lib.mscomp_amd_debug_xe_prof(buf)
 nc = len(lens)
-print("per chunk cycles: wave0(consumer): stage %.0f work %.0f barrier-wait %.0f other %.0f | wave1(producer): stage %.0f work %.0f barrier-wait %.0f other %.0f" % tuple(buf[i] / nc for i in range(8)))
+print("per unit cycles: read %.0f walk %.0f emit %.0f flags+carry %.0f - %.0f looptop %.0f" % tuple(buf[i] / nc for i in range(6)))
