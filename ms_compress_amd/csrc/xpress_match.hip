@@ -180,7 +180,7 @@ __global__ __launch_bounds__(1024) void xp_links_kernel(const uint8_t* __restric
 // so the chain walk (<= 11 dependent steps) and the byte compares are LDS gathers instead of L2 gathers.
 // clip != 0: positions with fewer than 3 bytes left in their 64 KiB chunk get no match (xpress_huff_compress.cpp:90).
 #define XP_TILE 4096u
-template <uint32_t WINDOW, bool LDS_LINKS, uint32_t NT>
+template <uint32_t WINDOW, uint32_t LINKW, uint32_t NT>   // LINKW: how many positions before the tile have their links in LDS
 __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                      const uint16_t* __restrict__ links, const uint16_t* __restrict__ lasthead,
                                                      uint16_t* __restrict__ mlen3, uint16_t* __restrict__ moff,
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	uint8_t* const s_data = smem;                                             // WINDOW + XP_TILE + 64 bytes
-	uint16_t* const s_links = reinterpret_cast<uint16_t*>(smem + WINDOW + XP_TILE + 64u);   // WINDOW + XP_TILE entries
+	uint16_t* const s_links = reinterpret_cast<uint16_t*>(smem + WINDOW + XP_TILE + 64u);   // LINKW + XP_TILE entries
 
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lc = blockIdx.x >> 4;
@@ -204,6 +204,7 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 	const u64 wstart = P0 >= WINDOW ? P0 - WINDOW : 0;                        // unit position of s_data[0]
 	const u64 wend = (P0 + XP_TILE + 64u < n) ? P0 + XP_TILE + 64u : n;       // staged bytes: [wstart, wend), zero beyond
 	const uint32_t wlen = (uint32_t)(wend - wstart);
+	const u64 lwstart = P0 >= LINKW ? P0 - LINKW : 0;                         // unit position of s_links[0] (>= wstart)
 
 	// ---- stage data (16 B / thread when aligned) and links ------------------------------------------------------
 	{
@@ -212,10 +213,10 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 		for (uint32_t i = tid * 16u; i < nvec; i += NT * 16u) { *reinterpret_cast<uint4*>(s_data + i) = *reinterpret_cast<const uint4*>(src + i); }
 		for (uint32_t i = nvec + tid; i < wlen; i += NT) { s_data[i] = src[i]; }
 		for (uint32_t i = wlen + tid; i < WINDOW + XP_TILE + 64u; i += NT) { s_data[i] = 0; }
-		if (LDS_LINKS) {
-			const uint32_t npos = (uint32_t)((P0 + XP_TILE < cbase + cn ? P0 + XP_TILE : cbase + cn) - wstart);
+		{
+			const uint32_t npos = (uint32_t)((P0 + XP_TILE < cbase + cn ? P0 + XP_TILE : cbase + cn) - lwstart);
 			for (uint32_t r = tid; r < npos; r += NT) {
-				const u64 pos = wstart + r;
+				const u64 pos = lwstart + r;
 				s_links[r] = links[(u64)(bt.chunk_prefix[u] + (uint32_t)(pos >> 16)) * 65536u + (uint32_t)(pos & 65535u)];
 			}
 		}
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 			const bool prev_last = (prev_last_hash == h);
 			uint32_t chain = 11;
 			bool inprev = false;
-			uint32_t x = LDS_LINKS ? (uint32_t)s_links[pr] : (uint32_t)lk_cur[o];
+			uint32_t x = s_links[(uint32_t)(P - lwstart)];
 			bool alive = true;
 			if (x == 0xFFFFu) {
 				if (k == 0) { alive = false; }
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 				}
 				if (--chain == 0) { break; }
 				if (!inprev) {
-					x = LDS_LINKS ? (uint32_t)s_links[xr] : (uint32_t)lk_cur[x];
+					x = (X >= lwstart) ? (uint32_t)s_links[(uint32_t)(X - lwstart)] : (uint32_t)lk_cur[x];
 					if (x == 0xFFFFu) {
 						if (k == 0) { break; }
 						x = lasthead[(u64)(lc - 1u) * 32768u + h]; inprev = true;
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 					}
 				} else {
 					// a link is always < its position, so 0xFFFF is unambiguous here
-					x = (LDS_LINKS && X >= wstart) ? (uint32_t)s_links[xr] : (uint32_t)lk_prev[x];
+					x = (X >= lwstart) ? (uint32_t)s_links[(uint32_t)(X - lwstart)] : (uint32_t)lk_prev[x];
 					if (x == 0xFFFFu) { break; }
 				}
 			}
@@ -300,17 +301,18 @@ void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, 
 {
 	if (bt.n_chunks == 0) { return; }
 	static bool attr_set = false;
-	const uint32_t lds_xp = 0x2000u + XP_TILE + 64u + (0x2000u + XP_TILE) * 2u;      // data + links in LDS
-	const uint32_t lds_xh = 0x10000u + XP_TILE + 64u;                                 // data in LDS, links from L2
+	const uint32_t XH_LINKW = 0u;                                                      // (28 K links in LDS = 1 block/CU was slower)
+	const uint32_t lds_xp = 0x2000u + XP_TILE + 64u + (0x2000u + XP_TILE) * 2u;      // data + all links of the window in LDS
+	const uint32_t lds_xh = 0x10000u + XP_TILE + 64u + (XH_LINKW + XP_TILE) * 2u;     // data + the tile's own links in LDS (2 blocks/CU), older links from L2
 	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x2000u, true, 512u>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xp);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x10000u, false, 1024u>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xh);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x2000u, 0x2000u, 512u>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xp);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x10000u, 0u, 1024u>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xh);
 		attr_set = true;
 	}
 	if (max_off <= 0x2000u) {
-		hipLaunchKernelGGL((xp_find_kernel<0x2000u, true, 512u>), dim3(bt.n_chunks * 16u), dim3(512), lds_xp, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip);
+		hipLaunchKernelGGL((xp_find_kernel<0x2000u, 0x2000u, 512u>), dim3(bt.n_chunks * 16u), dim3(512), lds_xp, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip);
 	} else {
-		hipLaunchKernelGGL((xp_find_kernel<0x10000u, false, 1024u>), dim3(bt.n_chunks * 16u), dim3(1024), lds_xh, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip);
+		hipLaunchKernelGGL((xp_find_kernel<0x10000u, 0u, 1024u>), dim3(bt.n_chunks * 16u), dim3(1024), lds_xh, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip);
 	}
 }
 
