@@ -147,8 +147,8 @@ __global__ __launch_bounds__(64) void xh_parse_kernel(const uint8_t* __restrict_
 // Huffman lengths (heap), size, canonical codes
 // ===================================================================================================================
 struct HuffLds {
-	uint32_t w[1024];      // node weights: (count<<8)|depth ; w[0] = 0 sentinel
-	uint16_t heap[516];
+	__attribute__((aligned(16))) u64 heap[516];   // entry = (weight << 16) | node ; weight = (count<<8)|depth ; heap[0] = 0 sentinel
+	uint32_t wleaf[512];   // leaf weights (kept for the >15-bit rescale loop)
 	uint16_t parent[1024];
 	uint32_t cnt[512];
 	uint8_t  lens[512];
@@ -156,51 +156,57 @@ struct HuffLds {
 	uint32_t flag;
 };
 
-// HEAP_PUSH / HEAP_POP (HuffmanEncoder.h:31-55), executed by ONE lane
-__device__ __forceinline__ void hh_push(HuffLds& h, uint32_t& hl, uint32_t x)
+// HEAP_PUSH / HEAP_POP (HuffmanEncoder.h:31-55), executed by ONE lane. Keys are compared on the weight only, exactly
+// like the reference (`weights[x] < weights[heap[j>>1]]`); carrying the weight inside the heap entry makes every sift
+// level a single LDS read (the two children of a node are one aligned 16-byte read).
+__device__ __forceinline__ void hh_push(HuffLds& h, uint32_t& hl, u64 e)
 {
 	uint32_t j = ++hl;
-	const uint32_t wx = h.w[x];
-	while (wx < h.w[h.heap[j >> 1]]) { h.heap[j] = h.heap[j >> 1]; j >>= 1; }
-	h.heap[j] = (uint16_t)x;
+	const uint32_t we = (uint32_t)(e >> 16);
+	for (;;) {
+		const u64 par = h.heap[j >> 1];
+		if (!(we < (uint32_t)(par >> 16))) { break; }
+		h.heap[j] = par; j >>= 1;
+	}
+	h.heap[j] = e;
 }
-__device__ __forceinline__ uint32_t hh_pop(HuffLds& h, uint32_t& hl)
+__device__ __forceinline__ u64 hh_pop(HuffLds& h, uint32_t& hl)
 {
-	const uint32_t top = h.heap[1], t = h.heap[hl--];
-	const uint32_t wt = h.w[t];
+	const u64 top = h.heap[1], t = h.heap[hl--];
+	const uint32_t wt = (uint32_t)(t >> 16);
 	uint32_t i = 1;
 	for (;;) {
 		uint32_t j = i << 1;
 		if (j > hl) { break; }
-		uint32_t cj = h.heap[j], wj = h.w[cj];
-		if (j < hl) { const uint32_t c2 = h.heap[j + 1], w2 = h.w[c2]; if (w2 < wj) { ++j; cj = c2; wj = w2; } }
-		if (wt < wj) { break; }
-		h.heap[i] = (uint16_t)cj; i = j;
+		const ulonglong2 ch = *reinterpret_cast<const ulonglong2*>(&h.heap[j]);   // children j and j+1 (j is even: 16 B aligned)
+		u64 c = ch.x;
+		if (j < hl && (uint32_t)(ch.y >> 16) < (uint32_t)(c >> 16)) { ++j; c = ch.y; }
+		if (wt < (uint32_t)(c >> 16)) { break; }
+		h.heap[i] = c; i = j;
 	}
-	h.heap[i] = (uint16_t)t;
+	h.heap[i] = t;
 	return top;
 }
 
 // CreateCodes lengths from h.cnt -> h.lens (whole wave enters; lane 0 runs the heap)
 __device__ void huff_lengths_fast(HuffLds& h, uint32_t lane)
 {
-	for (uint32_t i = lane; i < 512u; i += 64u) { const uint32_t c = h.cnt[i]; h.w[i + 1u] = (c ? c : 1u) << 8; }   // :69
-	if (lane == 0) { h.w[0] = 0; }
+	for (uint32_t i = lane; i < 512u; i += 64u) { const uint32_t c = h.cnt[i]; h.wleaf[i] = (c ? c : 1u) << 8; }   // :69
 	__syncthreads();
 	for (;;) {
 		for (uint32_t i = lane; i < 1024u; i += 64u) { h.parent[i] = 0; }
 		__syncthreads();
 		if (lane == 0) {
 			uint32_t hl = 0; h.heap[0] = 0;
-			for (uint32_t i = 1; i <= 512u; ++i) { hh_push(h, hl, i); }
+			for (uint32_t i = 1; i <= 512u; ++i) { hh_push(h, hl, ((u64)h.wleaf[i - 1u] << 16) | i); }
 			uint32_t nn = 512;
 			while (hl > 1) {
-				const uint32_t a = hh_pop(h, hl), b = hh_pop(h, hl);
-				const uint32_t wa = h.w[a], wb = h.w[b];
+				const u64 ea = hh_pop(h, hl), eb = hh_pop(h, hl);
+				const uint32_t wa = (uint32_t)(ea >> 16), wb = (uint32_t)(eb >> 16);
 				const uint32_t da = wa & 0xFFu, db = wb & 0xFFu;
-				++nn; h.parent[a] = (uint16_t)nn; h.parent[b] = (uint16_t)nn;
-				h.w[nn] = ((wa & ~0xFFu) + (wb & ~0xFFu)) | (1u + (da > db ? da : db));
-				hh_push(h, hl, nn);
+				++nn; h.parent[ea & 0xFFFFu] = (uint16_t)nn; h.parent[eb & 0xFFFFu] = (uint16_t)nn;
+				const uint32_t wn = ((wa & ~0xFFu) + (wb & ~0xFFu)) | (1u + (da > db ? da : db));
+				hh_push(h, hl, ((u64)wn << 16) | nn);
 			}
 		}
 		__syncthreads();
@@ -213,7 +219,7 @@ __device__ void huff_lengths_fast(HuffLds& h, uint32_t lane)
 		}
 		if (!__ballot(too_long)) { break; }
 		__syncthreads();
-		for (uint32_t i = lane + 1u; i <= 512u; i += 64u) { h.w[i] = (1u + (h.w[i] >> 9)) << 8; }    // :100-105
+		for (uint32_t i = lane; i < 512u; i += 64u) { h.wleaf[i] = (1u + (h.wleaf[i] >> 9)) << 8; }    // :100-105
 		__syncthreads();
 	}
 	__syncthreads();
