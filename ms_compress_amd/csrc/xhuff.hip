@@ -87,29 +87,49 @@ __global__ __launch_bounds__(64) void xh_parse_kernel(const uint8_t* __restrict_
 	for (uint32_t i = lane; i < 512u; i += 64u) { s_cnt[i] = 0; }
 	__syncthreads();
 
+	// Inputs are burst-loaded 8 windows (512 positions) at a time into a double-buffered LDS stage (one wait on global
+	// memory per 512 positions; unconditional loads with a clamped index).
+	__shared__ uint16_t s_in_off[2][512];
+	__shared__ uint16_t s_in_len[2][512];
+	__shared__ uint8_t  s_in_byte[2][512];
+	uint32_t g_off[8], g_len[8], g_byte[8];
+#define XP_BURST_LOAD(gb) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { \
+		const uint32_t q_ = (gb) + (uint32_t)k_ * 64u + lane; const uint32_t c_ = q_ < g.cn ? q_ : g.cn - 1u; \
+		g_off[k_] = moff[gbase + c_]; g_len[k_] = mlen3[gbase + c_]; g_byte[k_] = d[g.cbase + c_]; } }
+#define XP_BURST_STORE(buf) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { \
+		s_in_off[buf][k_ * 64 + lane] = (uint16_t)g_off[k_]; s_in_len[buf][k_ * 64 + lane] = (uint16_t)g_len[k_]; s_in_byte[buf][k_ * 64 + lane] = (uint8_t)g_byte[k_]; } }
+	XP_BURST_LOAD(0u)
+
 	uint32_t cur = 0, xtra = 0;                                  // next token start (offset in chunk), sum of raw length bytes
 	for (uint32_t wbase = 0; wbase < g.cn; wbase += 64u) {
+		const uint32_t wi = (wbase >> 6) & 7u, buf = (wbase >> 9) & 1u;
+		if (wi == 0) {
+			XP_BURST_STORE(buf)
+			if (wbase + 512u < g.cn) { XP_BURST_LOAD(wbase + 512u) }
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+		}
 		const uint32_t wend = (wbase + 64u < g.cn) ? wbase + 64u : g.cn;
 		if (cur >= wend) { if (lane == 0) { tokbits[(u64)lc * 1024u + (wbase >> 6)] = 0; } continue; }
 		const uint32_t o = wbase + lane;
 		const bool inr = o < g.cn;
-		uint32_t off = 0, L = 0, byte = 0;
-		if (inr) { off = moff[gbase + o]; L = mlen3[gbase + o]; byte = d[g.cbase + o]; }
+		const uint32_t off = inr ? (uint32_t)s_in_off[buf][wi * 64u + lane] : 0u;
+		uint32_t L = s_in_len[buf][wi * 64u + lane];
+		const uint32_t byte = s_in_byte[buf][wi * 64u + lane];
 		const u64 mm = __ballot(inr && off != 0 && o >= cur);
-		u64 tokmask = 0, matchmask = 0;
-		while (cur < wend) {
-			const uint32_t rel = cur - wbase;
+		// the serial loop only decides which candidates are TAKEN; the token mask is derived in parallel afterwards
+		u64 matchmask = 0;
+		const uint32_t entry = cur;
+		const uint32_t wn = wend - wbase;
+		uint32_t rel = cur - wbase;
+		while (rel < wn) {
 			const u64 rest = mm >> rel;
-			if (rest == 0) { tokmask |= (~(u64)0) << rel; cur = wend; break; }
-			const uint32_t j = ctz64(rest);
-			const uint32_t mp = rel + j;
-			const uint32_t om = wbase + mp;
-			tokmask |= ((((u64)2) << j) - (u64)1) << rel;
+			if (rest == 0) { rel = wn; break; }
+			const uint32_t mp = rel + ctz64(rest);
 			matchmask |= ((u64)1) << mp;
 			uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)mp) + 3u;
-			const uint32_t rem = g.cn - om;                        // bytes left in the chunk (>= 3 for a candidate)
+			const uint32_t rem = g.cn - (wbase + mp);             // bytes left in the chunk (>= 3 for a candidate)
 			if (len == 48u && rem > 48u) {                         // capped by the finder: extend, at most to the chunk end
-				const u64 P = g.cbase + om;
+				const u64 P = g.cbase + wbase + mp;
 				const u64 X = P - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
 				const u64 lim = g.n - P - 1u;                      // never count the buffer's final byte
 				const uint32_t maxadd = (uint32_t)((lim < rem ? lim : rem) - 48u);
@@ -117,11 +137,20 @@ __global__ __launch_bounds__(64) void xh_parse_kernel(const uint8_t* __restrict_
 			}
 			if (len > rem) { len = rem; }                          // :93
 			if (lane == mp) { L = len - 3u; }
-			cur = om + len;
+			rel = mp + len;
 		}
-		if (wend - wbase < 64u) { tokmask &= (((u64)1) << (wend - wbase)) - (u64)1; }
-		const bool is_tok = (tokmask >> lane) & (u64)1;
+		cur = wbase + rel;
 		const bool is_m = (matchmask >> lane) & (u64)1;
+		const uint32_t mend = is_m ? lane + L + 3u : 0u;          // match end, relative to the window
+		uint32_t reach = mend;
+		{
+#define MSC_DPP_MAX(ctrl, rmask) { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp((int)reach, (int)reach, ctrl, rmask, 0xf, false); reach = o_ > reach ? o_ : reach; }
+			MSC_DPP_MAX(0x111, 0xf) MSC_DPP_MAX(0x112, 0xf) MSC_DPP_MAX(0x114, 0xf) MSC_DPP_MAX(0x118, 0xf)
+			MSC_DPP_MAX(0x142, 0xa) MSC_DPP_MAX(0x143, 0xc)
+#undef MSC_DPP_MAX
+		}
+		const bool is_tok = o >= entry && inr && (is_m || reach <= lane);
+		const u64 tokmask = __ballot(is_tok);
 		if (is_m) { mlen3[gbase + o] = (uint16_t)L; }
 		if (lane == 0) { tokbits[(u64)lc * 1024u + (wbase >> 6)] = tokmask; }
 		uint32_t raw = 0;
@@ -134,8 +163,9 @@ __global__ __launch_bounds__(64) void xh_parse_kernel(const uint8_t* __restrict_
 			}
 			atomicAdd(&s_cnt[sym], 1u);
 		}
-		xtra += xh_wave_sum(raw);
+		xtra += raw;                                              // per-lane partial sums, reduced once at the end
 	}
+	xtra = xh_wave_sum(xtra);
 	__syncthreads();
 	if (g.last && lane == 0) { s_cnt[0x100] += 1u; }               // EOS (:127-144)
 	__syncthreads();
