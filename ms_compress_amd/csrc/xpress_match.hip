@@ -191,8 +191,13 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 	uint16_t* const s_links = reinterpret_cast<uint16_t*>(smem + WINDOW + XP_TILE + 64u);   // LINKW + XP_TILE entries
 
 	const uint32_t tid = threadIdx.x;
-	const uint32_t lc = blockIdx.x >> 4;
-	const uint32_t tstart = (blockIdx.x & 15u) * XP_TILE;                     // tile start inside the chunk
+	// XCD-aware tile order: consecutive workgroup ids go to different XCDs (private L2s). Inside every group of 128 ids
+	// (= 8 chunks x 16 tiles) XCD x takes the 16 tiles of chunk x, which re-stage the same window, so they share one L2;
+	// across groups the chunks stay round-robin over the XCDs (cheap and expensive files are spread evenly).
+	uint32_t bid = blockIdx.x;
+	if ((bid | 127u) < gridDim.x) { const uint32_t wi = bid & 127u; bid = (bid & ~127u) + (wi & 7u) * 16u + (wi >> 3); }
+	const uint32_t lc = bid >> 4;
+	const uint32_t tstart = (bid & 15u) * XP_TILE;                            // tile start inside the chunk
 	const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, lc);
 	const uint32_t k = lc - bt.chunk_prefix[u];
 	const u64 n = bt.in_len[u];
