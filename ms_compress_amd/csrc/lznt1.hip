@@ -39,7 +39,7 @@ __device__ unsigned long long g_lz_prof[16];
 #define LZ_TEND
 #endif
 
-#define LZ_TBL_BITS 12
+#define LZ_TBL_BITS 11
 #define LZ_TBL      (1u << LZ_TBL_BITS)
 #define LZ_SELF     8u       // candidates each lane scans by itself before the wave cooperates
 
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 	__shared__ __attribute__((aligned(16))) uint8_t  s_data[4096 + 32];
 	__shared__ __attribute__((aligned(16))) uint16_t s_cnt[LZ_TBL];       // counts -> bucket cursors -> bucket ends
 	__shared__ __attribute__((aligned(16))) uint16_t s_bucket[4096];      // positions sorted by (hash, position)
-	__shared__ uint8_t s_tmp[2048];                                        // intra-batch conflict detector (keyed by hash & 2047)
+	__shared__ uint8_t s_tmp[1024];                                        // intra-batch conflict detector (keyed by hash & 1023)
 	__shared__ uint32_t s_flagacc[16];                                     // flag bits of the groups in flight
 	__shared__ uint32_t s_flagpos[16];                                     // their byte position in the image
 
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 	// ---- B2. exclusive scan of the 4096 counts -> bucket starts: 8 coalesced rounds of 8 bins per lane ---------
 	{
 		uint32_t run = 0;
-		for (uint32_t k = 0; k < 8u; ++k) {
+		for (uint32_t k = 0; k < LZ_TBL / 512u; ++k) {
 			uint4 a = reinterpret_cast<uint4*>(s_cnt)[k * 64u + lane];
 			uint32_t w[4] = { a.x, a.y, a.z, a.w };
 			uint32_t sum = 0;
@@ -173,9 +173,9 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 		const uint32_t h = lz_hash(ld32(s_data + p) & 0xFFFFFFu);
 		const bool mine = p + 2u < n;
 		uint32_t cur0 = 0;
-		if (mine) { cur0 = wld16(&s_cnt[h]); __hip_atomic_store(&s_tmp[h & 2047u], (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+		if (mine) { cur0 = wld16(&s_cnt[h]); __hip_atomic_store(&s_tmp[h & 1023u], (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 		wave_fence();
-		const bool loser = mine && __hip_atomic_load(&s_tmp[h & 2047u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) != lane;
+		const bool loser = mine && __hip_atomic_load(&s_tmp[h & 1023u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) != lane;
 		uint32_t slot = cur0, newcur = cur0 + 1u;
 		bool writer = mine;
 		u64 lm = __ballot(loser);
