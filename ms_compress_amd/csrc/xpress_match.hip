@@ -230,35 +230,40 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 
 	const uint16_t* __restrict__ lk_cur = links + (u64)lc * 65536u;
 	const uint16_t* __restrict__ lk_prev = links + (u64)(lc - (k ? 1u : 0u)) * 65536u;
-	const u64 prevbase = cbase - (k ? 65536u : 0u);
+	const uint16_t* __restrict__ lh_prev = lasthead + (u64)(lc - (k ? 1u : 0u)) * 32768u;
 	const uint32_t tn = (cn - tstart < XP_TILE) ? cn - tstart : XP_TILE;
 	// 65535 as the previous chunk's head is indistinguishable from "none" (0xFFFF): decide by that position's hash
 	const uint32_t prev_last_hash = (k > 0) ? xp_hash3(ldg32_safe(d, cbase - 1u, n)) : 0xFFFFFFFFu;
+	// everything below is 32-bit and relative to the staged window (s_data[0] = unit position wstart)
+	const int32_t crel = (int32_t)(uint32_t)(cbase - wstart);                 // start of this chunk   (>= 0)
+	const int32_t prel = crel - 65536;                                        // start of the previous chunk (may be < 0)
+	const uint32_t lrel = (uint32_t)(lwstart - wstart);                       // first position whose link is in s_links
+	const uint32_t p0r = (uint32_t)(P0 - wstart);
+	const u64 tail = n - P0;                                                  // bytes from the tile start to the unit end
 
 	for (uint32_t t = tid; t < tn; t += NT) {
 		const uint32_t o = tstart + t;                                          // offset in chunk
-		const u64 P = cbase + o;
-		const uint32_t pr = (uint32_t)(P - wstart);                             // LDS index of P
+		const uint32_t pr = p0r + t;                                            // window-relative position of P
 		uint32_t best = 2, boff = 0;
-		const bool can = (P + 2u < n) && (!clip || cn - o >= 3u);
+		const bool can = ((u64)t + 2u < tail) && (!clip || cn - o >= 3u);
 		if (can) {
 			const uint32_t w = ld32(s_data + pr);
 			const uint32_t h = xp_hash3(w);
-			const u64 lim = n - P - 1u;
+			const u64 lim = tail - t - 1u;                                          // n - P - 1: never count the buffer's final byte
 			const uint32_t cap = lim < 48u ? (uint32_t)lim : 48u;
 			const bool prev_last = (prev_last_hash == h);
 			uint32_t chain = 11;
 			bool inprev = false;
-			uint32_t x = s_links[(uint32_t)(P - lwstart)];
+			uint32_t x = s_links[pr - lrel];
 			bool alive = true;
 			if (x == 0xFFFFu) {
 				if (k == 0) { alive = false; }
-				else { x = lasthead[(u64)(lc - 1u) * 32768u + h]; inprev = true; alive = (x != 0xFFFFu) || prev_last; }
+				else { x = lh_prev[h]; inprev = true; alive = (x != 0xFFFFu) || prev_last; }
 			}
 			while (alive) {
-				const u64 X = inprev ? prevbase + x : cbase + x;
-				if (P - X > max_off) { break; }
-				const uint32_t xr = (uint32_t)(X - wstart);                         // in the staged window because P-X <= max_off <= WINDOW
+				const int32_t xr = (inprev ? prel : crel) + (int32_t)x;            // window-relative candidate position
+				const uint32_t dist = (uint32_t)((int32_t)pr - xr);
+				if (dist > max_off) { break; }                                      // (also catches xr < 0: outside the window)
 				// a candidate only matters if it is STRICTLY longer than the best so far: it must agree at index `best` too
 				// (the reference compares everything, XpressDictionary.h:164-176; the outcome is the same)
 				if (ld16(s_data + xr) == (w & 0xFFFFu) && s_data[xr + best] == s_data[pr + best]) {
@@ -269,19 +274,19 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 						l += 4;
 					}
 					if (l > cap) { l = cap; }
-					if (l > best) { best = l; boff = (uint32_t)(P - X); if (best >= 48u) { break; } }
+					if (l > best) { best = l; boff = dist; if (best >= 48u) { break; } }
 				}
 				if (--chain == 0) { break; }
 				if (!inprev) {
-					x = (X >= lwstart) ? (uint32_t)s_links[(uint32_t)(X - lwstart)] : (uint32_t)lk_cur[x];
+					x = ((uint32_t)xr >= lrel) ? (uint32_t)s_links[(uint32_t)xr - lrel] : (uint32_t)lk_cur[x];
 					if (x == 0xFFFFu) {
 						if (k == 0) { break; }
-						x = lasthead[(u64)(lc - 1u) * 32768u + h]; inprev = true;
+						x = lh_prev[h]; inprev = true;
 						if (x == 0xFFFFu && !prev_last) { break; }
 					}
 				} else {
 					// a link is always < its position, so 0xFFFF is unambiguous here
-					x = (X >= lwstart) ? (uint32_t)s_links[(uint32_t)(X - lwstart)] : (uint32_t)lk_prev[x];
+					x = (xr >= (int32_t)lrel) ? (uint32_t)s_links[(uint32_t)xr - lrel] : (uint32_t)lk_prev[x];
 					if (x == 0xFFFFu) { break; }
 				}
 			}
