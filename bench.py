@@ -168,6 +168,7 @@ def main():
     ap.add_argument("--codec", default="lznt1", choices=["lznt1", "xpress", "xpress_huff"])
     ap.add_argument("--all", action="store_true", help="also time the other codecs (default at N=1)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--replicas", type=int, default=1, help="tile the workload R times per GPU (BASELINE config 5 uses 16x Silesia over 8 GPUs)")
     args = ap.parse_args()
 
     import torch
@@ -180,6 +181,12 @@ def main():
     fmt = m.FORMATS[args.codec]
     which = {"lznt1": "mozilla", "xpress": "silesia_units64k", "xpress_huff": "silesia_files"}[args.codec]
     blob, in_off, in_len, desc = build_workload(m, corpus, fmt, which)
+    if args.replicas > 1:
+        R = args.replicas
+        in_off = np.concatenate([in_off + np.uint64(r * len(blob)) for r in range(R)])
+        in_len = np.tile(in_len, R)
+        blob = np.tile(blob, R)
+        desc += " x%d replicas" % R
     job = Job(m, ctx, fmt, blob, in_off, in_len)
     dt, prof = timed(job, args.steps, args.warmup, sharding)
     out_bytes = job.out_bytes()

@@ -56,6 +56,14 @@ extern "C" void mscomp_amd_debug_xl_prof(unsigned long long* out) { (void)hipMem
 //       serial head table; result = one info word per position;
 //   waves 0-1 (consumers, one per hash parity): the serial pass over tile t-1: per 64 positions ONE LDS gather of the heads (lanes without an
 //       in-batch predecessor), one coalesced store of the links, ONE LDS scatter (last lane of every hash).
+__device__ __forceinline__ uint4 ld128(const uint8_t* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }   // any alignment (LDS)
+// index of the first differing byte of two 16-byte blocks given their XOR (16 if equal)
+__device__ __forceinline__ uint32_t first_diff16(const uint4 x)
+{
+	return x.x ? ((uint32_t)__builtin_ctz(x.x) >> 3) : x.y ? 4u + ((uint32_t)__builtin_ctz(x.y) >> 3)
+	     : x.z ? 8u + ((uint32_t)__builtin_ctz(x.z) >> 3) : x.w ? 12u + ((uint32_t)__builtin_ctz(x.w) >> 3) : 16u;
+}
+
 __global__ __launch_bounds__(1024) void xp_links_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                       uint16_t* __restrict__ links, uint16_t* __restrict__ lasthead)
 {
@@ -247,7 +255,8 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 		uint32_t best = 2, boff = 0;
 		const bool can = ((u64)t + 2u < tail) && (!clip || cn - o >= 3u);
 		if (can) {
-			const uint32_t w = ld32(s_data + pr);
+			const uint4 oa = ld128(s_data + pr), ob = ld128(s_data + pr + 16), oc = ld128(s_data + pr + 32);
+			const uint32_t w = oa.x;
 			const uint32_t h = xp_hash3(w);
 			const u64 lim = tail - t - 1u;                                          // n - P - 1: never count the buffer's final byte
 			const uint32_t cap = lim < 48u ? (uint32_t)lim : 48u;
@@ -267,11 +276,16 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 				// a candidate only matters if it is STRICTLY longer than the best so far: it must agree at index `best` too
 				// (the reference compares everything, XpressDictionary.h:164-176; the outcome is the same)
 				if (ld16(s_data + xr) == (w & 0xFFFFu) && s_data[xr + best] == s_data[pr + best]) {
-					uint32_t l = 0;
-					while (l < cap) {
-						const uint32_t a = ld32(s_data + xr + l) ^ ld32(s_data + pr + l);
-						if (a) { l += (uint32_t)__builtin_ctz(a) >> 3; break; }
-						l += 4;
+					// 16 bytes per step against my own 48 bytes held in registers (lengths are capped at 48 here)
+					uint4 c = ld128(s_data + xr);
+					uint32_t l = first_diff16(make_uint4(c.x ^ oa.x, c.y ^ oa.y, c.z ^ oa.z, c.w ^ oa.w));
+					if (l == 16u && cap > 16u) {
+						c = ld128(s_data + xr + 16);
+						l = 16u + first_diff16(make_uint4(c.x ^ ob.x, c.y ^ ob.y, c.z ^ ob.z, c.w ^ ob.w));
+						if (l == 32u && cap > 32u) {
+							c = ld128(s_data + xr + 32);
+							l = 32u + first_diff16(make_uint4(c.x ^ oc.x, c.y ^ oc.y, c.z ^ oc.z, c.w ^ oc.w));
+						}
 					}
 					if (l > cap) { l = cap; }
 					if (l > best) { best = l; boff = dist; if (best >= 48u) { break; } }
