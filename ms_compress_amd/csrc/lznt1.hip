@@ -95,10 +95,16 @@ __device__ __forceinline__ uint32_t lz_lcp(const uint8_t* d, uint32_t q, uint32_
 	uint32_t l = x0 ? 3u : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3)
 	                         : x3 ? 12u + ((uint32_t)__builtin_ctz(x3) >> 3) : 16u;
 	if (l == 16u && maxlen > 16u) {
-		while (l < maxlen) {
-			const uint32_t x = ld32(d + q + l) ^ ld32(d + p + l);
-			if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
-			l += 4u;
+		while (l < maxlen) {                                    // 16 bytes per step
+			uint4 a, b;
+			__builtin_memcpy(&a, d + q + l, 16); __builtin_memcpy(&b, d + p + l, 16);
+			const uint32_t y0 = a.x ^ b.x, y1 = a.y ^ b.y, y2 = a.z ^ b.z, y3 = a.w ^ b.w;
+			if (y0 | y1 | y2 | y3) {
+				l += y0 ? ((uint32_t)__builtin_ctz(y0) >> 3) : y1 ? 4u + ((uint32_t)__builtin_ctz(y1) >> 3)
+				   : y2 ? 8u + ((uint32_t)__builtin_ctz(y2) >> 3) : 12u + ((uint32_t)__builtin_ctz(y3) >> 3);
+				break;
+			}
+			l += 16u;
 		}
 	}
 	return l < maxlen ? l : maxlen;
