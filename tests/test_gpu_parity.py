@@ -130,3 +130,35 @@ def test_batch_exact_capacities(oracle, gpu_ctx):
                 assert s == m.MSCOMP_BUF_ERROR and g is None
             else:
                 assert s == 0 and g == e, (f, i)
+
+
+@pytest.mark.parametrize("fmt", list(FMTS))
+def test_unaligned_unit_offsets(oracle, gpu_ctx, fmt):
+    """Units packed back to back with NO alignment (odd input and output offsets): exercises the byte-granular loaders."""
+    import torch
+    import ms_compress_amd as m
+    f = FMTS[fmt]
+    units = cases.edge_cases(sizes=[1, 7, 100, 4097, 8191, 20001, 65537, 70001], kinds=["words", "lz", "run"])
+    lens = [len(u) for u in units]
+    in_off, in_total = m.pack_offsets(lens, align=1)
+    in_off = in_off + np.uint64(3)                                # first unit at an odd address too
+    caps = [m.max_compressed_size(f, n) + 2 for n in lens]
+    out_off, out_total = m.pack_offsets(caps, align=1)
+    out_off = out_off + np.uint64(5)
+    blob = np.zeros(in_total + 32, dtype=np.uint8)
+    for u, o in zip(units, in_off):
+        blob[int(o): int(o) + len(u)] = np.frombuffer(u, dtype=np.uint8)
+    dev = torch.device("cuda", gpu_ctx.device)
+    d_in = torch.from_numpy(blob).to(dev)
+    d_out = torch.zeros(out_total + 32, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(len(units), dtype=torch.int64, device=dev)
+    d_st = torch.zeros(len(units), dtype=torch.int32, device=dev)
+    plan = m.Plan(gpu_ctx, f, in_off, lens, out_off, caps)
+    plan.execute(d_in, d_out, d_len, d_st)
+    torch.cuda.synchronize()
+    plan.close()
+    h_out, h_len, h_st = d_out.cpu().numpy(), d_len.cpu().numpy(), d_st.cpu().numpy()
+    for i, u in enumerate(units):
+        exp = oracle.oracle_compress(f, u)[1]
+        got = bytes(h_out[int(out_off[i]): int(out_off[i]) + int(h_len[i])])
+        assert h_st[i] == 0 and got == exp, (fmt, i, len(u))
