@@ -3,17 +3,17 @@
 // Replaces: lznt1_compress / lznt1_compress_chunk (/root/reference/src/lznt1_compress.cpp:233-273, :49-94) and
 // LZNT1Dictionary::Fill/Find (/root/reference/include/mscomp/LZNT1Dictionary.h:93-106, :114-143).
 //
-// One wavefront (64-thread block) = one 4 KiB chunk, everything staged in LDS (22.5 KiB -> 7 chunks in flight per CU):
+// One wavefront (64-thread block) = one 4 KiB chunk, everything staged in LDS (17.6 KiB -> 9 chunks in flight per CU):
 //   A. coalesced 16 B/lane load of the chunk into LDS;
 //   B. dictionary = the reference's per-key position arrays as ONE position-sorted bucket array in LDS, built by a stable
-//      counting sort on a 12-bit hash of the 3-byte key: histogram by LDS atomics, exclusive scan of the counts (DPP),
+//      counting sort on an 11-bit hash of the 3-byte key: histogram by LDS atomics, exclusive scan of the counts (DPP),
 //      then an ORDERED scatter in 64 ascending batches (one LDS gather + scatter of the bucket cursors per batch,
 //      intra-batch conflicts resolved with ballots). Afterwards cursor[h] = end of bucket h, so the candidates of a
 //      position are simply the entries of its bucket that are smaller than the position itself;
 //   C. window by window (64 positions, lane = position), LAZILY like the reference (Find runs only where the greedy parse
 //      can start a token):
-//        1. every lane at or after the parse position scans the 8 OLDEST candidates of its position itself (4 loads in
-//           flight, own bytes in registers, strictly-longer wins, early exit at max_len);
+//        1. every lane at or after the parse position scans the 4 OLDEST candidates of its position itself (unconditional
+//           loads in flight together, own bytes in registers, 16-byte compares, strictly-longer wins, early exit at max_len);
 //        2. the greedy walk runs on the scalar unit over ballot masks (s_ff1 over literal runs). When it lands on a
 //           position that still has unexamined candidates, the whole wave finishes that ONE position: 64 candidates per
 //           step, DPP max of (len, -position) = longest, oldest on ties, stop when max_len is reached. Positions covered
@@ -85,28 +85,36 @@ __device__ __forceinline__ uint32_t wave_incl_scan_add_u32(uint32_t v)
 	return v;
 }
 
+// Common prefix beyond the first 16 (equal) bytes of d[q..] and d[p..]: 16 bytes per step; the result may exceed maxlen
+// (callers clamp).
+__device__ __forceinline__ uint32_t lz_lcp_tail(const uint8_t* d, uint32_t q, uint32_t p, uint32_t maxlen)
+{
+	uint32_t l = 16u;
+	while (l < maxlen) {
+		uint4 a, b;
+		__builtin_memcpy(&a, d + q + l, 16); __builtin_memcpy(&b, d + p + l, 16);
+		const uint32_t y0 = a.x ^ b.x, y1 = a.y ^ b.y, y2 = a.z ^ b.z, y3 = a.w ^ b.w;
+		if (y0 | y1 | y2 | y3) {
+			l += y0 ? ((uint32_t)__builtin_ctz(y0) >> 3) : y1 ? 4u + ((uint32_t)__builtin_ctz(y1) >> 3)
+			   : y2 ? 8u + ((uint32_t)__builtin_ctz(y2) >> 3) : 12u + ((uint32_t)__builtin_ctz(y3) >> 3);
+			break;
+		}
+		l += 16u;
+	}
+	return l;
+}
 // Common prefix of d[q..] and the string at d[p..] whose first 16 bytes are o0..o3, limited to maxlen (>= 3); 0 when the
-// first 3 bytes differ (hash collision). The first 16 bytes are compared straight-line (4 independent LDS loads).
+// first 3 bytes differ (hash collision).
 __device__ __forceinline__ uint32_t lz_lcp(const uint8_t* d, uint32_t q, uint32_t p, uint32_t maxlen,
                                            uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3)
 {
-	const uint32_t x0 = ld32(d + q) ^ o0, x1 = ld32(d + q + 4u) ^ o1, x2 = ld32(d + q + 8u) ^ o2, x3 = ld32(d + q + 12u) ^ o3;
+	uint4 c;
+	__builtin_memcpy(&c, d + q, 16);
+	const uint32_t x0 = c.x ^ o0, x1 = c.y ^ o1, x2 = c.z ^ o2, x3 = c.w ^ o3;
 	if (x0 & 0xFFFFFFu) { return 0u; }
 	uint32_t l = x0 ? 3u : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3)
 	                         : x3 ? 12u + ((uint32_t)__builtin_ctz(x3) >> 3) : 16u;
-	if (l == 16u && maxlen > 16u) {
-		while (l < maxlen) {                                    // 16 bytes per step
-			uint4 a, b;
-			__builtin_memcpy(&a, d + q + l, 16); __builtin_memcpy(&b, d + p + l, 16);
-			const uint32_t y0 = a.x ^ b.x, y1 = a.y ^ b.y, y2 = a.z ^ b.z, y3 = a.w ^ b.w;
-			if (y0 | y1 | y2 | y3) {
-				l += y0 ? ((uint32_t)__builtin_ctz(y0) >> 3) : y1 ? 4u + ((uint32_t)__builtin_ctz(y1) >> 3)
-				   : y2 ? 8u + ((uint32_t)__builtin_ctz(y2) >> 3) : 12u + ((uint32_t)__builtin_ctz(y3) >> 3);
-				break;
-			}
-			l += 16u;
-		}
-	}
+	if (l == 16u && maxlen > 16u) { l = lz_lcp_tail(d, q, p, maxlen); }
 	return l < maxlen ? l : maxlen;
 }
 
@@ -220,14 +228,28 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 		// 1. the oldest LZ_SELF candidates, in order, early exit at maxlen (LZNT1Dictionary.h:124-135)
 		uint32_t key = 0;                                       // (len << 12) | (4095 - q): larger = longer, then older
 		bool done = false;
+		// All loads are UNCONDITIONAL (clamped index) so that they issue back to back and are waited for once; lanes and
+		// candidates that do not exist are masked afterwards.
 		uint32_t q[LZ_SELF + 1u];
 		#pragma unroll
-		for (uint32_t j = 0; j <= LZ_SELF; ++j) { q[j] = (s + j < e) ? (uint32_t)s_bucket[s + j] : 4096u; }   // 4096 = none (>= p)
+		for (uint32_t j = 0; j <= LZ_SELF; ++j) { q[j] = s_bucket[(s + j) & 4095u]; }
+		#pragma unroll
+		for (uint32_t j = 0; j <= LZ_SELF; ++j) { if (s + j >= e) { q[j] = 4096u; } }                          // 4096 = none (>= p)
 		#pragma unroll
 		for (uint32_t j = 0; j < LZ_SELF; j += 4u) {
+			uint4 c[4];
+			#pragma unroll
+			for (int k = 0; k < 4; ++k) { __builtin_memcpy(&c[k], s_data + (q[j + k] < p ? q[j + k] : 0u), 16); }
 			uint32_t l[4];
 			#pragma unroll
-			for (int k = 0; k < 4; ++k) { l[k] = (q[j + k] < p) ? lz_lcp(s_data, q[j + k], p, maxlen, o0, o1, o2, o3) : 0u; }
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t x0 = c[k].x ^ o0, x1 = c[k].y ^ o1, x2 = c[k].z ^ o2, x3 = c[k].w ^ o3;
+				uint32_t lk = x0 ? 3u : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3)
+				                 : x3 ? 12u + ((uint32_t)__builtin_ctz(x3) >> 3) : 16u;
+				if ((x0 & 0xFFFFFFu) != 0 || q[j + k] >= p) { lk = 0; }            // hash collision / no such candidate
+				if (lk == 16u && maxlen > 16u) { lk = lz_lcp_tail(s_data, q[j + k], p, maxlen); }   // rare: long match
+				l[k] = lk < maxlen ? lk : maxlen;
+			}
 			#pragma unroll
 			for (int k = 0; k < 4; ++k) {
 				if (!done && l[k] > (key >> 12)) { key = (l[k] << 12) | (4095u - q[j + k]); if (l[k] == maxlen) { done = true; } }
