@@ -29,9 +29,9 @@ namespace msc {
 #ifdef LZ_PROFILE   // dev-only phase timers (s_memtime cycles summed over blocks); not in the production build
 __device__ unsigned long long g_lz_prof[16];
 #define LZ_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); t_acc[i] += t_ - t_prev; t_prev = t_; }
-#define LZ_T0   unsigned long long t_prev = __builtin_readcyclecounter(); unsigned long long t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define LZ_T0   unsigned long long t_prev = __builtin_readcyclecounter(); unsigned long long t_acc[16] = {0};
 #define LZ_CNT(i, v) { t_acc[i] += (unsigned long long)(v); }
-#define LZ_TEND if (lane == 0) { for (int i_ = 0; i_ < 10; ++i_) { atomicAdd(&g_lz_prof[i_], t_acc[i_]); } }
+#define LZ_TEND if (lane == 0) { for (int i_ = 0; i_ < 16; ++i_) { atomicAdd(&g_lz_prof[i_], t_acc[i_]); } }
 #else
 #define LZ_T(i)
 #define LZ_T0
@@ -259,6 +259,7 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 		LZ_T(3)
 		// 2. greedy walk; positions with rem != 0 are finished by the whole wave when (and only when) the walk lands on them
 		u64 un = __ballot(unres);                                // unresolved positions
+		LZ_CNT(10, __popcll(un))
 		u64 mm = __ballot(!unres && (key >> 12) >= 3u);          // resolved positions that have a match
 		// The serial loop only decides which candidates are TAKEN; everything else (which positions are literal tokens)
 		// is derived in parallel afterwards.
@@ -278,6 +279,12 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 				const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)o2, (int)mp), a3 = (uint32_t)__builtin_amdgcn_readlane((int)o3, (int)mp);
 				uint32_t kbest = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)mp);
 				const uint32_t pL = wbase + mp;
+				LZ_CNT(11, 1)
+#ifdef LZ_PROFILE
+				const unsigned long long tf0 = __builtin_readcyclecounter();
+#endif
+				LZ_CNT(12, (eL - sL - LZ_SELF > 16u) ? 1 : 0)
+				LZ_CNT(13, (eL - sL - LZ_SELF > 64u) ? 1 : 0)
 				for (uint32_t base = sL + LZ_SELF; base < eL; base += 64u) {
 					uint32_t k2 = 0;
 					bool past = true;                                  // this lane is at or beyond pL's own entry
@@ -290,9 +297,12 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 					if ((m >> 12) > (kbest >> 12)) { kbest = m; }    // strictly longer only: older blocks win ties
 					if ((kbest >> 12) == maxL || __ballot(past)) { break; }   // max_len reached / all older candidates seen
 				}
+#ifdef LZ_PROFILE
+				t_acc[15] += __builtin_readcyclecounter() - tf0;
+#endif
 				if (lane == mp) { key = kbest; }
 				un &= ~(((u64)1) << mp);
-				if ((kbest >> 12) >= 3u) { mm |= ((u64)1) << mp; }
+				if ((kbest >> 12) >= 3u) { mm |= ((u64)1) << mp; LZ_CNT(14, 1) }
 				rel = mp;                                          // literals before mp are settled; re-evaluate mp itself
 				continue;
 			}

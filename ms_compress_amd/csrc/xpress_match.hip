@@ -56,7 +56,16 @@ extern "C" void mscomp_amd_debug_xl_prof(unsigned long long* out) { (void)hipMem
 //       serial head table; result = one info word per position;
 //   waves 0-1 (consumers, one per hash parity): the serial pass over tile t-1: per 64 positions ONE LDS gather of the heads (lanes without an
 //       in-batch predecessor), one coalesced store of the links, ONE LDS scatter (last lane of every hash).
-__device__ __forceinline__ uint4 ld128(const uint8_t* p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }   // any alignment (LDS)
+// 16 bytes at ANY byte address of an LDS array whose base is 4-byte aligned. A byte-misaligned ds_read_b128 is replayed
+// (SQ_LDS_UNALIGNED_STALL was 77 % of this kernel's LDS cycles), so read 5 ALIGNED dwords and funnel-shift (v_alignbyte).
+__device__ __forceinline__ uint4 ld128(const uint8_t* base, uint32_t off)
+{
+	const uint32_t* a = reinterpret_cast<const uint32_t*>(base + (off & ~3u));
+	const uint32_t sh = off & 3u;
+	const uint32_t w0 = a[0], w1 = a[1], w2 = a[2], w3 = a[3], w4 = a[4];
+	return make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+	                  __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh));
+}
 // index of the first differing byte of two 16-byte blocks given their XOR (16 if equal)
 __device__ __forceinline__ uint32_t first_diff16(const uint4 x)
 {
@@ -188,6 +197,13 @@ __global__ __launch_bounds__(1024) void xp_links_kernel(const uint8_t* __restric
 // so the chain walk (<= 11 dependent steps) and the byte compares are LDS gathers instead of L2 gathers.
 // clip != 0: positions with fewer than 3 bytes left in their 64 KiB chunk get no match (xpress_huff_compress.cpp:90).
 #define XP_TILE 4096u
+#ifdef XF_PROFILE
+__device__ unsigned long long g_xf_prof[8];
+extern "C" void mscomp_amd_debug_xf_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xf_prof), 64); unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xf_prof), z, 64); }
+#define XF_CNT(i, v) xf_acc[i] += (v);
+#else
+#define XF_CNT(i, v)
+#endif
 template <uint32_t WINDOW, uint32_t LINKW, uint32_t NT>   // LINKW: how many positions before the tile have their links in LDS
 __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                      const uint16_t* __restrict__ links, const uint16_t* __restrict__ lasthead,
@@ -249,13 +265,16 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 	const uint32_t p0r = (uint32_t)(P0 - wstart);
 	const u64 tail = n - P0;                                                  // bytes from the tile start to the unit end
 
+#ifdef XF_PROFILE
+	unsigned long long xf_acc[8] = {0};
+#endif
 	for (uint32_t t = tid; t < tn; t += NT) {
 		const uint32_t o = tstart + t;                                          // offset in chunk
 		const uint32_t pr = p0r + t;                                            // window-relative position of P
 		uint32_t best = 2, boff = 0;
 		const bool can = ((u64)t + 2u < tail) && (!clip || cn - o >= 3u);
 		if (can) {
-			const uint4 oa = ld128(s_data + pr), ob = ld128(s_data + pr + 16), oc = ld128(s_data + pr + 32);
+			const uint4 oa = ld128(s_data, pr), ob = ld128(s_data, pr + 16u), oc = ld128(s_data, pr + 32u);
 			const uint32_t w = oa.x;
 			const uint32_t h = xp_hash3(w);
 			const u64 lim = tail - t - 1u;                                          // n - P - 1: never count the buffer's final byte
@@ -269,7 +288,10 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 				if (k == 0) { alive = false; }
 				else { x = lh_prev[h]; inprev = true; alive = (x != 0xFFFFu) || prev_last; }
 			}
+			XF_CNT(0, 1)
 			while (alive) {
+				XF_CNT(1, 1)
+				if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(__ballot(1))) { XF_CNT(2, 64) }
 				const int32_t xr = (inprev ? prel : crel) + (int32_t)x;            // window-relative candidate position
 				const uint32_t dist = (uint32_t)((int32_t)pr - xr);
 				if (dist > max_off) { break; }                                      // (also catches xr < 0: outside the window)
@@ -277,13 +299,14 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 				// (the reference compares everything, XpressDictionary.h:164-176; the outcome is the same)
 				if (ld16(s_data + xr) == (w & 0xFFFFu) && s_data[xr + best] == s_data[pr + best]) {
 					// 16 bytes per step against my own 48 bytes held in registers (lengths are capped at 48 here)
-					uint4 c = ld128(s_data + xr);
+					XF_CNT(3, 1)
+					uint4 c = ld128(s_data, (uint32_t)xr);
 					uint32_t l = first_diff16(make_uint4(c.x ^ oa.x, c.y ^ oa.y, c.z ^ oa.z, c.w ^ oa.w));
 					if (l == 16u && cap > 16u) {
-						c = ld128(s_data + xr + 16);
+						c = ld128(s_data, (uint32_t)xr + 16u);
 						l = 16u + first_diff16(make_uint4(c.x ^ ob.x, c.y ^ ob.y, c.z ^ ob.z, c.w ^ ob.w));
 						if (l == 32u && cap > 32u) {
-							c = ld128(s_data + xr + 32);
+							c = ld128(s_data, (uint32_t)xr + 32u);
 							l = 32u + first_diff16(make_uint4(c.x ^ oc.x, c.y ^ oc.y, c.z ^ oc.z, c.w ^ oc.w));
 						}
 					}
@@ -309,7 +332,11 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 		const u64 gi = (u64)lc * 65536u + o;
 		mlen3[gi] = (uint16_t)(m ? best - 3u : 0u);
 		moff[gi] = (uint16_t)(m ? boff : 0u);
+		XF_CNT(4, m ? 1 : 0)
 	}
+#ifdef XF_PROFILE
+	for (int i_ = 0; i_ < 5; ++i_) { if (xf_acc[i_]) { atomicAdd(&g_xf_prof[i_], xf_acc[i_]); } }
+#endif
 }
 
 void launch_xp_links(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead)
