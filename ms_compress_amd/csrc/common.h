@@ -27,6 +27,18 @@ __device__ __forceinline__ uint32_t ld16(const uint8_t* p) { uint16_t v; __built
 __device__ __forceinline__ void     st16(uint8_t* p, uint32_t v) { uint16_t w = (uint16_t)v; __builtin_memcpy(p, &w, 2); }
 __device__ __forceinline__ void     st32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
+// Index of the first non-zero byte of the 16-byte value x (little endian), 16 when x == 0. Branch-free, 10 VALU:
+// v_ffbl_b32 returns 0xFFFFFFFF for a zero dword (the builtin ctz is undefined there, so the instruction is named
+// directly), the saturating adds keep it there, and the unsigned minimum picks the first hit.
+__device__ __forceinline__ uint32_t ffbl_raw(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { const uint32_t t = a < b ? a : b; return t < c ? t : c; }
+__device__ __forceinline__ uint32_t first_nz_byte16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
+{
+	const uint32_t a = __builtin_elementwise_add_sat(ffbl_raw(x1), 32u), b = __builtin_elementwise_add_sat(ffbl_raw(x2), 64u);
+	const uint32_t c = __builtin_elementwise_add_sat(ffbl_raw(x3), 96u);
+	return min3u(min3u(ffbl_raw(x0), a, b), c, 128u) >> 3;
+}
+
 // ---- batch tables (uploaded once per plan) ------------------------------------------------------------
 // unit u owns chunks [chunk_prefix[u], chunk_prefix[u+1]); input = in_off/in_len, output = out_off/out_cap.
 struct BatchTables {

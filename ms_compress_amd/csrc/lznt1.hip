@@ -59,61 +59,48 @@ __device__ __forceinline__ void     wst32(uint32_t* p, uint32_t v) { __hip_atomi
 __device__ __forceinline__ uint32_t wld32(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 __device__ __forceinline__ void     wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local"); }
 
-// DPP scans over the 64 lanes: row_shr 1,2,4,8 then row_bcast 15/31
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+__device__ __forceinline__ u64 sgpr64(u64 v)   // tell the compiler a wave-uniform 64-bit value lives in SGPRs
 {
-#define MSC_DPP_MAX(ctrl, rmask) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false); v = o > v ? o : v; }
-	MSC_DPP_MAX(0x111, 0xf) MSC_DPP_MAX(0x112, 0xf) MSC_DPP_MAX(0x114, 0xf) MSC_DPP_MAX(0x118, 0xf)
-	MSC_DPP_MAX(0x142, 0xa) MSC_DPP_MAX(0x143, 0xc)
-#undef MSC_DPP_MAX
-	return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+	return ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
-__device__ __forceinline__ uint32_t wave_incl_scan_max(uint32_t v)
-{
-#define MSC_DPP_MAX(ctrl, rmask) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false); v = o > v ? o : v; }
-	MSC_DPP_MAX(0x111, 0xf) MSC_DPP_MAX(0x112, 0xf) MSC_DPP_MAX(0x114, 0xf) MSC_DPP_MAX(0x118, 0xf)
-	MSC_DPP_MAX(0x142, 0xa) MSC_DPP_MAX(0x143, 0xc)
-#undef MSC_DPP_MAX
-	return v;
-}
-__device__ __forceinline__ uint32_t wave_incl_scan_add_u32(uint32_t v)
-{
-#define MSC_DPP_ADD(ctrl, rmask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, true);
-	MSC_DPP_ADD(0x111, 0xf) MSC_DPP_ADD(0x112, 0xf) MSC_DPP_ADD(0x114, 0xf) MSC_DPP_ADD(0x118, 0xf)
-	MSC_DPP_ADD(0x142, 0xa) MSC_DPP_ADD(0x143, 0xc)
-#undef MSC_DPP_ADD
-	return v;
-}
+// DPP scans over the 64 lanes: row_shr 1,2,4,8 then row_bcast 15/31, the max/add folded into the DPP instruction itself
+// (the builtin form costs v_mov + v_mov_dpp + op per step). A lane whose DPP source is out of range or whose row is
+// masked off keeps its value. Two wait states are required between a VALU write and a DPP read of the same VGPR.
+#define MSC_DPP_SCAN(op) \
+	"s_nop 1\n\t" op " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+	"s_nop 1\n\t" op " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+	"s_nop 1\n\t" op " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+	"s_nop 1\n\t" op " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+	"s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+	"s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+	"s_nop 1"
+__device__ __forceinline__ uint32_t wave_incl_scan_max(uint32_t v) { asm volatile(MSC_DPP_SCAN("v_max_u32_dpp") : "+v"(v)); return v; }
+__device__ __forceinline__ uint32_t wave_incl_scan_add_u32(uint32_t v) { asm volatile(MSC_DPP_SCAN("v_add_u32_dpp") : "+v"(v)); return v; }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_max(v), 63); }
 
 // Common prefix beyond the first 16 (equal) bytes of d[q..] and d[p..]: 16 bytes per step; the result may exceed maxlen
 // (callers clamp).
 __device__ __forceinline__ uint32_t lz_lcp_tail(const uint8_t* d, uint32_t q, uint32_t p, uint32_t maxlen)
 {
 	uint32_t l = 16u;
-	while (l < maxlen) {
+	for (;;) {
 		uint4 a, b;
 		__builtin_memcpy(&a, d + q + l, 16); __builtin_memcpy(&b, d + p + l, 16);
-		const uint32_t y0 = a.x ^ b.x, y1 = a.y ^ b.y, y2 = a.z ^ b.z, y3 = a.w ^ b.w;
-		if (y0 | y1 | y2 | y3) {
-			l += y0 ? ((uint32_t)__builtin_ctz(y0) >> 3) : y1 ? 4u + ((uint32_t)__builtin_ctz(y1) >> 3)
-			   : y2 ? 8u + ((uint32_t)__builtin_ctz(y2) >> 3) : 12u + ((uint32_t)__builtin_ctz(y3) >> 3);
-			break;
-		}
-		l += 16u;
+		const uint32_t f = first_nz_byte16(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
+		l += f;
+		if (f < 16u || l >= maxlen) { break; }
 	}
 	return l;
 }
 // Common prefix of d[q..] and the string at d[p..] whose first 16 bytes are o0..o3, limited to maxlen (>= 3); 0 when the
-// first 3 bytes differ (hash collision).
-__device__ __forceinline__ uint32_t lz_lcp(const uint8_t* d, uint32_t q, uint32_t p, uint32_t maxlen,
+// candidate does not exist (!valid) or the first 3 bytes differ (hash collision). Branch-free up to 16 bytes.
+__device__ __forceinline__ uint32_t lz_lcp(const uint8_t* d, uint32_t q, bool valid, uint32_t p, uint32_t maxlen,
                                            uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3)
 {
 	uint4 c;
-	__builtin_memcpy(&c, d + q, 16);
-	const uint32_t x0 = c.x ^ o0, x1 = c.y ^ o1, x2 = c.z ^ o2, x3 = c.w ^ o3;
-	if (x0 & 0xFFFFFFu) { return 0u; }
-	uint32_t l = x0 ? 3u : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3)
-	                         : x3 ? 12u + ((uint32_t)__builtin_ctz(x3) >> 3) : 16u;
+	__builtin_memcpy(&c, d + (valid ? q : 0u), 16);
+	const uint32_t f = first_nz_byte16(c.x ^ o0, c.y ^ o1, c.z ^ o2, c.w ^ o3);
+	uint32_t l = (valid && f >= 3u) ? f : 0u;
 	if (l == 16u && maxlen > 16u) { l = lz_lcp_tail(d, q, p, maxlen); }
 	return l < maxlen ? l : maxlen;
 }
@@ -240,19 +227,15 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 			uint4 c[4];
 			#pragma unroll
 			for (int k = 0; k < 4; ++k) { __builtin_memcpy(&c[k], s_data + (q[j + k] < p ? q[j + k] : 0u), 16); }
-			uint32_t l[4];
 			#pragma unroll
 			for (int k = 0; k < 4; ++k) {
-				const uint32_t x0 = c[k].x ^ o0, x1 = c[k].y ^ o1, x2 = c[k].z ^ o2, x3 = c[k].w ^ o3;
-				uint32_t lk = x0 ? 3u : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3)
-				                 : x3 ? 12u + ((uint32_t)__builtin_ctz(x3) >> 3) : 16u;
-				if ((x0 & 0xFFFFFFu) != 0 || q[j + k] >= p) { lk = 0; }            // hash collision / no such candidate
-				if (lk == 16u && maxlen > 16u) { lk = lz_lcp_tail(s_data, q[j + k], p, maxlen); }   // rare: long match
-				l[k] = lk < maxlen ? lk : maxlen;
-			}
-			#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				if (!done && l[k] > (key >> 12)) { key = (l[k] << 12) | (4095u - q[j + k]); if (l[k] == maxlen) { done = true; } }
+				const uint32_t f = first_nz_byte16(c[k].x ^ o0, c[k].y ^ o1, c[k].z ^ o2, c[k].w ^ o3);
+				uint32_t lk = (q[j + k] < p && f >= 3u) ? f : 0u;                  // no such candidate / hash collision
+				if (lk == 16u && maxlen > 16u) { lk = lz_lcp_tail(s_data, q[j + k], p, maxlen); }   // long match
+				lk = lk < maxlen ? lk : maxlen;
+				const bool take = !done && lk > (key >> 12);
+				key = take ? ((lk << 12) | (4095u - q[j + k])) : key;
+				done = done || (take && lk == maxlen);
 			}
 		}
 		bool unres = !done && q[LZ_SELF] < p;                    // a 9th older candidate exists and max_len was not reached
@@ -266,11 +249,50 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 		u64 matchmask = 0;
 		uint32_t rel = entry > wbase ? entry - wbase : 0u;       // next token start, relative to the window
 		const uint32_t wn = wend - wbase;
+		uint32_t klen = key >> 12;
 		while (rel < wn) {
-			const u64 rest = (un | mm) >> rel;
-			if (rest == 0) { break; }
-			const uint32_t mp = rel + ctz64(rest);
-			if ((un >> mp) & (u64)1) {
+			// Tight scalar walk over the resolved positions: hop from match to match (literals in between are skipped by
+			// the find-first-set) until the window ends (st = 0) or an unresolved position is reached (st = 1, rel = it).
+			// Hand-written: the compiler's version of this loop had 5 taken branches per token. v_readlane needs 4 wait
+			// states after the SALU write of its lane select.
+			un = sgpr64(un); mm = sgpr64(mm); matchmask = sgpr64(matchmask);
+			rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)rel);
+#ifdef LZ_PROFILE
+			const unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
+			const u64 any = un | mm;
+			const uint32_t wn_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wn);
+			uint32_t st, k_; u64 t_;
+			asm volatile(
+				"1:\n\t"
+				"s_lshr_b64 %[t], %[any], %[rel]\n\t"
+				"s_cmp_eq_u64 %[t], 0\n\t"
+				"s_cbranch_scc1 2f\n\t"
+				"s_ff1_i32_b64 %[k], %[t]\n\t"
+				"s_add_i32 %[rel], %[rel], %[k]\n\t"
+				"s_bitcmp1_b64 %[un], %[rel]\n\t"
+				"s_cbranch_scc1 3f\n\t"
+				"s_bitset1_b64 %[mk], %[rel]\n\t"
+				"s_nop 2\n\t"
+				"v_readlane_b32 %[k], %[klen], %[rel]\n\t"
+				"s_add_i32 %[rel], %[rel], %[k]\n\t"
+				"s_cmp_lt_u32 %[rel], %[wn]\n\t"
+				"s_cbranch_scc1 1b\n\t"
+				"2:\n\t"
+				"s_mov_b32 %[st], 0\n\t"
+				"s_branch 4f\n\t"
+				"3:\n\t"
+				"s_mov_b32 %[st], 1\n\t"
+				"4:\n\t"
+				: [rel] "+s"(rel), [mk] "+s"(matchmask), [st] "=&s"(st), [k] "=&s"(k_), [t] "=&s"(t_)
+				: [any] "s"(any), [un] "s"(un), [wn] "s"(wn_s), [klen] "v"(klen)
+				: "scc");
+#ifdef LZ_PROFILE
+			t_acc[12] += __builtin_readcyclecounter() - tw0; t_acc[13] += 1;
+#endif
+			if (st == 0) { break; }
+			{
+				const uint32_t mp = rel;
 				// finish position wbase+mp: the candidates after the first LZ_SELF of its bucket, oldest first, 64 per step
 				const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)s, (int)mp);
 				const uint32_t eL = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)mp);
@@ -283,15 +305,13 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 #ifdef LZ_PROFILE
 				const unsigned long long tf0 = __builtin_readcyclecounter();
 #endif
-				LZ_CNT(12, (eL - sL - LZ_SELF > 16u) ? 1 : 0)
-				LZ_CNT(13, (eL - sL - LZ_SELF > 64u) ? 1 : 0)
 				for (uint32_t base = sL + LZ_SELF; base < eL; base += 64u) {
-					uint32_t k2 = 0;
-					bool past = true;                                  // this lane is at or beyond pL's own entry
-					if (base + lane < eL) {
-						const uint32_t qq = s_bucket[base + lane];
-						if (qq < pL) { past = false; k2 = (lz_lcp(s_data, qq, pL, maxL, a0, a1, a2, a3) << 12) | (4095u - qq); }
-					}
+					const uint32_t idx = base + lane;
+					const uint32_t qq = s_bucket[idx & 4095u];         // unconditional load, masked below
+					const bool valid = idx < eL && qq < pL;            // !valid: this lane is at or beyond pL's own entry
+					const uint32_t l2 = lz_lcp(s_data, qq, valid, pL, maxL, a0, a1, a2, a3);
+					const uint32_t k2 = l2 ? ((l2 << 12) | (4095u - qq)) : 0u;
+					const bool past = !valid;
 					LZ_CNT(9, 1)
 					const uint32_t m = wave_max_u32(k2);
 					if ((m >> 12) > (kbest >> 12)) { kbest = m; }    // strictly longer only: older blocks win ties
@@ -300,17 +320,15 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 #ifdef LZ_PROFILE
 				t_acc[15] += __builtin_readcyclecounter() - tf0;
 #endif
-				if (lane == mp) { key = kbest; }
+				if (lane == mp) { key = kbest; klen = kbest >> 12; }
 				un &= ~(((u64)1) << mp);
-				if ((kbest >> 12) >= 3u) { mm |= ((u64)1) << mp; LZ_CNT(14, 1) }
-				rel = mp;                                          // literals before mp are settled; re-evaluate mp itself
-				continue;
+				if ((kbest >> 12) >= 3u) { mm |= ((u64)1) << mp; }
+				// rel stays at mp: literals before it are settled; mp itself is re-evaluated as a resolved position
 			}
-			matchmask |= ((u64)1) << mp;
-			rel = mp + ((uint32_t)__builtin_amdgcn_readlane((int)key, (int)mp) >> 12);
 		}
 		// tokens of the window = positions >= entry that no taken match covers: covered <=> the furthest end of the taken
 		// matches starting at or before me lies beyond me and I am not such a start myself
+		LZ_CNT(14, __popcll(matchmask))
 		const bool is_m = (matchmask >> lane) & (u64)1;
 		const uint32_t mend = is_m ? p + (key >> 12) : 0u;
 		const uint32_t reach = wave_incl_scan_max(mend);

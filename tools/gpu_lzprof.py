@@ -19,5 +19,6 @@ for name in sys.argv[1:]:
     lib.mscomp_amd_debug_lz_prof(buf, 1)
     nch = (n + 4095) // 4096
     tot = sum(buf[:7])
+    print("   per chunk: asm-walk cycles %.0f in %.0f calls, taken matches %.0f" % (buf[12] / nch, buf[13] / nch, buf[14] / nch))
     print("   per chunk: finish steps %.0f, unresolved %.0f, finishes %.0f (>16 cand: %.0f, >64: %.0f), finishes with match %.0f, cycles in finish loops %.0f" % tuple(buf[i] / nch for i in (9, 10, 11, 12, 13, 14, 15)))
     print(name, "chunks", nch, "avg cycles/chunk %.0f" % (tot / nch), " | ".join("%s %.0f (%.0f%%)" % (nm, buf[i] / nch, 100.0 * buf[i] / tot) for i, nm in enumerate(names)))
