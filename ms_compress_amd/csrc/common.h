@@ -20,6 +20,21 @@ __device__ __forceinline__ uint32_t popc_below(u64 m)
 __device__ __forceinline__ uint32_t ctz64(u64 m) { return (uint32_t)__builtin_ctzll(m); }
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// DPP scans over the 64 lanes: row_shr 1,2,4,8 then row_bcast 15/31, the max/add folded into the DPP instruction itself
+// (the builtin form costs v_mov + v_mov_dpp + op per step). A lane whose DPP source is out of range or whose row is
+// masked off keeps its value. Two wait states are required between a VALU write and a DPP read of the same VGPR.
+#define MSC_DPP_SCAN(op) \
+	"s_nop 1\n\t" op " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+	"s_nop 1\n\t" op " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+	"s_nop 1\n\t" op " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+	"s_nop 1\n\t" op " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+	"s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+	"s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+	"s_nop 1"
+__device__ __forceinline__ uint32_t wave_incl_scan_max(uint32_t v) { asm volatile(MSC_DPP_SCAN("v_max_u32_dpp") : "+v"(v)); return v; }
+__device__ __forceinline__ uint32_t wave_incl_scan_add_u32(uint32_t v) { asm volatile(MSC_DPP_SCAN("v_add_u32_dpp") : "+v"(v)); return v; }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_max(v), 63); }
+
 // ---- LDS / global byte-granular access ----------------------------------------------------------------
 // gfx950 has unaligned DS access enabled: a misaligned 4-byte LDS read is ONE ds_read_b32.
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }

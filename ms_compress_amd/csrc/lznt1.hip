@@ -63,21 +63,6 @@ __device__ __forceinline__ u64 sgpr64(u64 v)   // tell the compiler a wave-unifo
 {
 	return ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
-// DPP scans over the 64 lanes: row_shr 1,2,4,8 then row_bcast 15/31, the max/add folded into the DPP instruction itself
-// (the builtin form costs v_mov + v_mov_dpp + op per step). A lane whose DPP source is out of range or whose row is
-// masked off keeps its value. Two wait states are required between a VALU write and a DPP read of the same VGPR.
-#define MSC_DPP_SCAN(op) \
-	"s_nop 1\n\t" op " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
-	"s_nop 1\n\t" op " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
-	"s_nop 1\n\t" op " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
-	"s_nop 1\n\t" op " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
-	"s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
-	"s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
-	"s_nop 1"
-__device__ __forceinline__ uint32_t wave_incl_scan_max(uint32_t v) { asm volatile(MSC_DPP_SCAN("v_max_u32_dpp") : "+v"(v)); return v; }
-__device__ __forceinline__ uint32_t wave_incl_scan_add_u32(uint32_t v) { asm volatile(MSC_DPP_SCAN("v_add_u32_dpp") : "+v"(v)); return v; }
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_max(v), 63); }
-
 // Common prefix beyond the first 16 (equal) bytes of d[q..] and d[p..]: 16 bytes per step; the result may exceed maxlen
 // (callers clamp).
 __device__ __forceinline__ uint32_t lz_lcp_tail(const uint8_t* d, uint32_t q, uint32_t p, uint32_t maxlen)

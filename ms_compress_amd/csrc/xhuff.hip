@@ -21,14 +21,7 @@
 
 namespace msc {
 
-__device__ __forceinline__ uint32_t xh_incl_scan_add(uint32_t v)
-{
-#define MSC_DPP_ADD(ctrl, rmask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, true);
-	MSC_DPP_ADD(0x111, 0xf) MSC_DPP_ADD(0x112, 0xf) MSC_DPP_ADD(0x114, 0xf) MSC_DPP_ADD(0x118, 0xf)
-	MSC_DPP_ADD(0x142, 0xa) MSC_DPP_ADD(0x143, 0xc)
-#undef MSC_DPP_ADD
-	return v;
-}
+__device__ __forceinline__ uint32_t xh_incl_scan_add(uint32_t v) { return wave_incl_scan_add_u32(v); }
 __device__ __forceinline__ uint32_t xh_wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)xh_incl_scan_add(v), 63); }
 
 __device__ __forceinline__ uint32_t xh_ldg32(const uint8_t* __restrict__ d, u64 pos, u64 n)
@@ -142,13 +135,7 @@ __global__ __launch_bounds__(64) void xh_parse_kernel(const uint8_t* __restrict_
 		cur = wbase + rel;
 		const bool is_m = (matchmask >> lane) & (u64)1;
 		const uint32_t mend = is_m ? lane + L + 3u : 0u;          // match end, relative to the window
-		uint32_t reach = mend;
-		{
-#define MSC_DPP_MAX(ctrl, rmask) { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp((int)reach, (int)reach, ctrl, rmask, 0xf, false); reach = o_ > reach ? o_ : reach; }
-			MSC_DPP_MAX(0x111, 0xf) MSC_DPP_MAX(0x112, 0xf) MSC_DPP_MAX(0x114, 0xf) MSC_DPP_MAX(0x118, 0xf)
-			MSC_DPP_MAX(0x142, 0xa) MSC_DPP_MAX(0x143, 0xc)
-#undef MSC_DPP_MAX
-		}
+		const uint32_t reach = wave_incl_scan_max(mend);
 		const bool is_tok = o >= entry && inr && (is_m || reach <= lane);
 		const u64 tokmask = __ballot(is_tok);
 		if (is_m) { mlen3[gbase + o] = (uint16_t)L; }

@@ -17,23 +17,8 @@
 
 namespace msc {
 
-__device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v)
-{
-#define MSC_DPP_ADD(ctrl, rmask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, true);
-	MSC_DPP_ADD(0x111, 0xf) MSC_DPP_ADD(0x112, 0xf) MSC_DPP_ADD(0x114, 0xf) MSC_DPP_ADD(0x118, 0xf)
-	MSC_DPP_ADD(0x142, 0xa) MSC_DPP_ADD(0x143, 0xc)
-#undef MSC_DPP_ADD
-	return v;
-}
-
-__device__ __forceinline__ uint32_t wave_incl_scan_max_u32(uint32_t v)
-{
-#define MSC_DPP_MAX(ctrl, rmask) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xf, false); v = o > v ? o : v; }
-	MSC_DPP_MAX(0x111, 0xf) MSC_DPP_MAX(0x112, 0xf) MSC_DPP_MAX(0x114, 0xf) MSC_DPP_MAX(0x118, 0xf)
-	MSC_DPP_MAX(0x142, 0xa) MSC_DPP_MAX(0x143, 0xc)
-#undef MSC_DPP_MAX
-	return v;
-}
+__device__ __forceinline__ uint32_t wave_incl_scan_add(uint32_t v) { return wave_incl_scan_add_u32(v); }
+__device__ __forceinline__ uint32_t wave_incl_scan_max_u32(uint32_t v) { return wave_incl_scan_max(v); }
 
 __device__ __forceinline__ uint32_t ldg32_lim(const uint8_t* __restrict__ d, u64 pos, u64 n)
 {

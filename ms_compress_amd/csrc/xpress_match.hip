@@ -67,11 +67,7 @@ __device__ __forceinline__ uint4 ld128(const uint8_t* base, uint32_t off)
 	                  __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh));
 }
 // index of the first differing byte of two 16-byte blocks given their XOR (16 if equal)
-__device__ __forceinline__ uint32_t first_diff16(const uint4 x)
-{
-	return x.x ? ((uint32_t)__builtin_ctz(x.x) >> 3) : x.y ? 4u + ((uint32_t)__builtin_ctz(x.y) >> 3)
-	     : x.z ? 8u + ((uint32_t)__builtin_ctz(x.z) >> 3) : x.w ? 12u + ((uint32_t)__builtin_ctz(x.w) >> 3) : 16u;
-}
+__device__ __forceinline__ uint32_t first_diff16(const uint4 x) { return first_nz_byte16(x.x, x.y, x.z, x.w); }
 
 __global__ __launch_bounds__(1024) void xp_links_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                       uint16_t* __restrict__ links, uint16_t* __restrict__ lasthead)
