@@ -238,7 +238,7 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 		for (uint32_t i = tid * 16u; i < nvec; i += NT * 16u) { *reinterpret_cast<uint4*>(s_data + i) = *reinterpret_cast<const uint4*>(src + i); }
 		for (uint32_t i = nvec + tid; i < wlen; i += NT) { s_data[i] = src[i]; }
 		for (uint32_t i = wlen + tid; i < WINDOW + XP_TILE + 64u; i += NT) { s_data[i] = 0; }
-		{
+		if (LINKW == WINDOW) {
 			const uint32_t npos = (uint32_t)((P0 + XP_TILE < cbase + cn ? P0 + XP_TILE : cbase + cn) - lwstart);
 			for (uint32_t r = tid; r < npos; r += NT) {
 				const u64 pos = lwstart + r;
@@ -248,8 +248,9 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 	}
 	__syncthreads();
 
-	const uint16_t* __restrict__ lk_cur = links + (u64)lc * 65536u;
-	const uint16_t* __restrict__ lk_prev = links + (u64)(lc - (k ? 1u : 0u)) * 65536u;
+	// links of this chunk; the previous chunk's array directly precedes it, so a window-relative position xr is entry
+	// lkg[xr - crel] for both (negative index = previous chunk)
+	const uint16_t* __restrict__ lkg = links + (u64)lc * 65536u;
 	const uint16_t* __restrict__ lh_prev = lasthead + (u64)(lc - (k ? 1u : 0u)) * 32768u;
 	const uint32_t tn = (cn - tstart < XP_TILE) ? cn - tstart : XP_TILE;
 	// 65535 as the previous chunk's head is indistinguishable from "none" (0xFFFF): decide by that position's hash
@@ -271,57 +272,60 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 		const bool can = ((u64)t + 2u < tail) && (!clip || cn - o >= 3u);
 		if (can) {
 			const uint4 oa = ld128(s_data, pr), ob = ld128(s_data, pr + 16u), oc = ld128(s_data, pr + 32u);
-			const uint32_t w = oa.x;
-			const uint32_t h = xp_hash3(w);
+			const uint32_t h = xp_hash3(oa.x);
 			const u64 lim = tail - t - 1u;                                          // n - P - 1: never count the buffer's final byte
 			const uint32_t cap = lim < 48u ? (uint32_t)lim : 48u;
 			const bool prev_last = (prev_last_hash == h);
 			uint32_t chain = 11;
-			bool inprev = false;
-			uint32_t x = s_links[pr - lrel];
-			bool alive = true;
-			if (x == 0xFFFFu) {
-				if (k == 0) { alive = false; }
-				else { x = lh_prev[h]; inprev = true; alive = (x != 0xFFFFu) || prev_last; }
+			// first candidate: my own link (an offset inside the chunk), else the previous chunk's last position with my hash
+			int32_t xr;
+			bool alive;
+			{
+				uint32_t x = (LINKW == WINDOW) ? (uint32_t)s_links[pr - lrel] : (uint32_t)lkg[o];
+				int32_t base = crel;
+				alive = true;
+				if (x == 0xFFFFu) {
+					if (k == 0) { alive = false; }
+					else { x = lh_prev[h]; base = prel; alive = (x != 0xFFFFu) || prev_last; }
+				}
+				xr = base + (int32_t)x;
+				alive = alive && (uint32_t)((int32_t)pr - xr) <= max_off;          // (also catches xr < 0: outside the window)
 			}
 			XF_CNT(0, 1)
+			// One candidate per iteration, straight-line: every live lane does the 16-byte compare (in a wave some lane
+			// always needs it, so a per-lane prefix filter only adds instructions); the reference compares everything too
+			// (XpressDictionary.h:164-176).
 			while (alive) {
 				XF_CNT(1, 1)
 				if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(__ballot(1))) { XF_CNT(2, 64) }
-				const int32_t xr = (inprev ? prel : crel) + (int32_t)x;            // window-relative candidate position
 				const uint32_t dist = (uint32_t)((int32_t)pr - xr);
-				if (dist > max_off) { break; }                                      // (also catches xr < 0: outside the window)
-				// a candidate only matters if it is STRICTLY longer than the best so far: it must agree at index `best` too
-				// (the reference compares everything, XpressDictionary.h:164-176; the outcome is the same)
-				if (ld16(s_data + xr) == (w & 0xFFFFu) && s_data[xr + best] == s_data[pr + best]) {
-					// 16 bytes per step against my own 48 bytes held in registers (lengths are capped at 48 here)
-					XF_CNT(3, 1)
-					uint4 c = ld128(s_data, (uint32_t)xr);
-					uint32_t l = first_diff16(make_uint4(c.x ^ oa.x, c.y ^ oa.y, c.z ^ oa.z, c.w ^ oa.w));
-					if (l == 16u && cap > 16u) {
-						c = ld128(s_data, (uint32_t)xr + 16u);
-						l = 16u + first_diff16(make_uint4(c.x ^ ob.x, c.y ^ ob.y, c.z ^ ob.z, c.w ^ ob.w));
-						if (l == 32u && cap > 32u) {
-							c = ld128(s_data, (uint32_t)xr + 32u);
-							l = 32u + first_diff16(make_uint4(c.x ^ oc.x, c.y ^ oc.y, c.z ^ oc.z, c.w ^ oc.w));
-						}
+				// 16 bytes per step against my own 48 bytes held in registers (lengths are capped at 48 here)
+				uint4 c = ld128(s_data, (uint32_t)xr);
+				uint32_t l = first_diff16(make_uint4(c.x ^ oa.x, c.y ^ oa.y, c.z ^ oa.z, c.w ^ oa.w));
+				if (l == 16u && cap > 16u) {
+					c = ld128(s_data, (uint32_t)xr + 16u);
+					l = 16u + first_diff16(make_uint4(c.x ^ ob.x, c.y ^ ob.y, c.z ^ ob.z, c.w ^ ob.w));
+					if (l == 32u && cap > 32u) {
+						c = ld128(s_data, (uint32_t)xr + 32u);
+						l = 32u + first_diff16(make_uint4(c.x ^ oc.x, c.y ^ oc.y, c.z ^ oc.z, c.w ^ oc.w));
 					}
-					if (l > cap) { l = cap; }
-					if (l > best) { best = l; boff = dist; if (best >= 48u) { break; } }
 				}
-				if (--chain == 0) { break; }
-				if (!inprev) {
-					x = ((uint32_t)xr >= lrel) ? (uint32_t)s_links[(uint32_t)xr - lrel] : (uint32_t)lk_cur[x];
-					if (x == 0xFFFFu) {
-						if (k == 0) { break; }
-						x = lh_prev[h]; inprev = true;
-						if (x == 0xFFFFu && !prev_last) { break; }
-					}
-				} else {
-					// a link is always < its position, so 0xFFFF is unambiguous here
-					x = (xr >= (int32_t)lrel) ? (uint32_t)s_links[(uint32_t)xr - lrel] : (uint32_t)lk_prev[x];
-					if (x == 0xFFFFu) { break; }
+				l = l < cap ? l : cap;
+				const bool better = l > best;                                       // strictly longer only: the nearer one wins ties
+				best = better ? l : best;
+				boff = better ? dist : boff;
+				// next candidate: the link of xr (an offset inside xr's chunk; a link is always < its position, so 0xFFFF is
+				// unambiguous there)
+				uint32_t x = (LINKW == WINDOW) ? (uint32_t)s_links[(uint32_t)xr - lrel] : (uint32_t)lkg[xr - crel];
+				const bool incur = xr >= crel;
+				int32_t base = incur ? crel : prel;
+				bool more = (best < 48u) && (--chain != 0u);
+				if (x == 0xFFFFu) {
+					if (incur && k != 0) { x = lh_prev[h]; base = prel; more = more && ((x != 0xFFFFu) || prev_last); }
+					else { more = false; }
 				}
+				xr = base + (int32_t)x;
+				alive = more && (uint32_t)((int32_t)pr - xr) <= max_off;
 			}
 		}
 		const bool m = best >= 3u;
@@ -348,9 +352,8 @@ void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, 
 {
 	if (bt.n_chunks == 0) { return; }
 	static bool attr_set = false;
-	const uint32_t XH_LINKW = 0u;                                                      // (28 K links in LDS = 1 block/CU was slower)
 	const uint32_t lds_xp = 0x2000u + XP_TILE + 64u + (0x2000u + XP_TILE) * 2u;      // data + all links of the window in LDS
-	const uint32_t lds_xh = 0x10000u + XP_TILE + 64u + (XH_LINKW + XP_TILE) * 2u;     // data + the tile's own links in LDS (2 blocks/CU), older links from L2
+	const uint32_t lds_xh = 0x10000u + XP_TILE + 64u;                               // data only (2 blocks/CU); links come from L2
 	if (!attr_set) {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x2000u, 0x2000u, 512u>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xp);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x10000u, 0u, 1024u>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xh);
