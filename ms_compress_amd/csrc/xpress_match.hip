@@ -299,6 +299,8 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 				XF_CNT(1, 1)
 				if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(__ballot(1))) { XF_CNT(2, 64) }
 				const uint32_t dist = (uint32_t)((int32_t)pr - xr);
+				// the link of xr is fetched first (L2 latency for Xpress+Huffman) and consumed after the compare
+				uint32_t x = (LINKW == WINDOW) ? (uint32_t)s_links[(uint32_t)xr - lrel] : (uint32_t)lkg[xr - crel];
 				// 16 bytes per step against my own 48 bytes held in registers (lengths are capped at 48 here)
 				uint4 c = ld128(s_data, (uint32_t)xr);
 				uint32_t l = first_diff16(make_uint4(c.x ^ oa.x, c.y ^ oa.y, c.z ^ oa.z, c.w ^ oa.w));
@@ -314,9 +316,7 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 				const bool better = l > best;                                       // strictly longer only: the nearer one wins ties
 				best = better ? l : best;
 				boff = better ? dist : boff;
-				// next candidate: the link of xr (an offset inside xr's chunk; a link is always < its position, so 0xFFFF is
-				// unambiguous there)
-				uint32_t x = (LINKW == WINDOW) ? (uint32_t)s_links[(uint32_t)xr - lrel] : (uint32_t)lkg[xr - crel];
+				// next candidate: x is an offset inside xr's chunk (a link is always < its position, so 0xFFFF is unambiguous)
 				const bool incur = xr >= crel;
 				int32_t base = incur ? crel : prel;
 				bool more = (best < 48u) && (--chain != 0u);
