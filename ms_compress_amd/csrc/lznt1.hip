@@ -94,9 +94,8 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
                                                         uint8_t* __restrict__ slots, uint32_t* __restrict__ slot_size)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t  s_data[4096 + 32];
-	__shared__ __attribute__((aligned(16))) uint16_t s_cnt[LZ_TBL];       // counts -> bucket cursors -> bucket ends
+	__shared__ __attribute__((aligned(16))) uint16_t s_cnt[LZ_TBL];       // counts -> bucket ends
 	__shared__ __attribute__((aligned(16))) uint16_t s_bucket[4096];      // positions sorted by (hash, position)
-	__shared__ uint8_t s_tmp[1024];                                        // intra-batch conflict detector (keyed by hash & 1023)
 	__shared__ uint32_t s_flagacc[16];                                     // flag bits of the groups in flight
 	__shared__ uint32_t s_flagpos[16];                                     // their byte position in the image
 
@@ -124,18 +123,29 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 	__syncthreads();
 	LZ_T(0)
 
-	// ---- B1. histogram of the position hashes (two u16 counters per dword) --------------------------------------------
+	// ---- B1. histogram of the position hashes (two u16 counters per dword); the value each atomic RETURNS is the
+	// position's rank inside its bucket: batches are issued in ascending position order, and within one DS instruction
+	// the LDS unit serialises same-address atomics in lane order (gfx950 behaviour, checked by tools/dev/lds_order_test.hip
+	// and, indirectly, by every parity test: a different order would change which candidate wins a tie) ------------------
 	const uint32_t nb = (n + 63u) >> 6;
-	for (uint32_t b = 0; b < nb; ++b) {
-		const uint32_t p = b * 64u + lane;
-		if (p + 2u < n) {
-			const uint32_t h = lz_hash(ld32(s_data + p) & 0xFFFFFFu);
-			atomicAdd(reinterpret_cast<uint32_t*>(s_cnt) + (h >> 1), (h & 1u) ? 0x10000u : 1u);
+	uint32_t rk[32];                                             // ranks of my 64 positions, two per register
+	#pragma unroll
+	for (uint32_t b = 0; b < 64u; ++b) {
+		uint32_t r = 0;
+		if (b < nb) {
+			const uint32_t p = b * 64u + lane;
+			if (p + 2u < n) {
+				const uint32_t h = lz_hash(ld32(s_data + p) & 0xFFFFFFu);
+				const uint32_t old = atomicAdd(reinterpret_cast<uint32_t*>(s_cnt) + (h >> 1), (h & 1u) ? 0x10000u : 1u);
+				r = (h & 1u) ? old >> 16 : old & 0xFFFFu;
+			}
 		}
+		rk[b >> 1] = (b & 1u) ? (rk[b >> 1] | (r << 16)) : r;
 	}
 	__syncthreads();
 	LZ_T(1)
-	// ---- B2. exclusive scan of the 4096 counts -> bucket starts: 8 coalesced rounds of 8 bins per lane ---------
+	// ---- B2. inclusive scan of the 2048 counts -> bucket ENDS (bucket h = [end[h-1], end[h])): coalesced rounds of 8
+	// bins per lane -----------------------------------------------------------------------------------------------------
 	{
 		uint32_t run = 0;
 		for (uint32_t k = 0; k < LZ_TBL / 512u; ++k) {
@@ -147,33 +157,24 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 			const uint32_t incl = wave_incl_scan_add_u32(sum);
 			uint32_t r = run + incl - sum;
 			#pragma unroll
-			for (int i = 0; i < 4; ++i) { const uint32_t lo = w[i] & 0xFFFFu, hi = w[i] >> 16; w[i] = r | ((r + lo) << 16); r += lo + hi; }
+			for (int i = 0; i < 4; ++i) { const uint32_t lo = w[i] & 0xFFFFu, hi = w[i] >> 16; w[i] = (r + lo) | ((r + lo + hi) << 16); r += lo + hi; }
 			reinterpret_cast<uint4*>(s_cnt)[k * 64u + lane] = make_uint4(w[0], w[1], w[2], w[3]);
 			run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 		}
 	}
 	__syncthreads();
-	// ---- B3. ordered scatter: bucket[cursor[h]++] = p, 64 positions per step in ascending order ----------------------
-	for (uint32_t b = 0; b < nb; ++b) {
-		const uint32_t p = b * 64u + lane;
-		const uint32_t h = lz_hash(ld32(s_data + p) & 0xFFFFFFu);
-		const bool mine = p + 2u < n;
-		uint32_t cur0 = 0;
-		if (mine) { cur0 = wld16(&s_cnt[h]); __hip_atomic_store(&s_tmp[h & 1023u], (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
-		wave_fence();
-		const bool loser = mine && __hip_atomic_load(&s_tmp[h & 1023u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) != lane;
-		uint32_t slot = cur0, newcur = cur0 + 1u;
-		bool writer = mine;
-		u64 lm = __ballot(loser);
-		while (lm) {                                            // one iteration per hash value shared by >1 lane of the batch
-			const uint32_t hh = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)ctz64(lm));
-			const bool grp = mine && h == hh;
-			const u64 g = __ballot(grp);
-			if (grp) { slot = cur0 + popc_below(g); newcur = cur0 + (uint32_t)__popcll(g); writer = (lane == ctz64(g)); }
-			lm &= ~g;
+	// ---- B3. scatter: bucket[start[h] + rank] = p (positions of a bucket end up in ascending order) --------------------
+	#pragma unroll
+	for (uint32_t b = 0; b < 64u; ++b) {
+		if (b < nb) {
+			const uint32_t p = b * 64u + lane;
+			if (p + 2u < n) {
+				const uint32_t h = lz_hash(ld32(s_data + p) & 0xFFFFFFu);
+				const uint32_t start = h ? (uint32_t)s_cnt[h - 1u] : 0u;
+				const uint32_t r = (b & 1u) ? rk[b >> 1] >> 16 : rk[b >> 1] & 0xFFFFu;
+				s_bucket[start + r] = (uint16_t)p;
+			}
 		}
-		if (mine) { s_bucket[slot] = (uint16_t)p; if (writer) { wst16(&s_cnt[h], newcur); } }
-		wave_fence();
 	}
 	__syncthreads();
 	LZ_T(2)
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 			const uint32_t mask3 = (1u << shift) + 2u;
 			maxlen = (n - p < mask3) ? n - p : mask3;
 			const uint32_t h = lz_hash(o0 & 0xFFFFFFu);
-			e = s_cnt[h];                                          // after B3 the cursor of bucket h is its end
+			e = s_cnt[h];                                          // bucket h = [end[h-1], end[h])
 			s = h ? (uint32_t)s_cnt[h - 1u] : 0u;
 		}
 		// 1. the oldest LZ_SELF candidates, in order, early exit at maxlen (LZNT1Dictionary.h:124-135)
