@@ -19,6 +19,10 @@ __device__ __forceinline__ uint32_t popc_below(u64 m)
 }
 __device__ __forceinline__ uint32_t ctz64(u64 m) { return (uint32_t)__builtin_ctzll(m); }
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ u64 sgpr64(u64 v)   // tell the compiler a wave-uniform 64-bit value lives in SGPRs
+{
+	return ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
 
 // DPP scans over the 64 lanes: row_shr 1,2,4,8 then row_bcast 15/31, the max/add folded into the DPP instruction itself
 // (the builtin form costs v_mov + v_mov_dpp + op per step). A lane whose DPP source is out of range or whose row is

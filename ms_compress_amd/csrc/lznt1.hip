@@ -59,10 +59,6 @@ __device__ __forceinline__ void     wst32(uint32_t* p, uint32_t v) { __hip_atomi
 __device__ __forceinline__ uint32_t wld32(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 __device__ __forceinline__ void     wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local"); }
 
-__device__ __forceinline__ u64 sgpr64(u64 v)   // tell the compiler a wave-uniform 64-bit value lives in SGPRs
-{
-	return ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-}
 // Common prefix beyond the first 16 (equal) bytes of d[q..] and d[p..]: 16 bytes per step; the result may exceed maxlen
 // (callers clamp).
 __device__ __forceinline__ uint32_t lz_lcp_tail(const uint8_t* d, uint32_t q, uint32_t p, uint32_t maxlen)

@@ -118,25 +118,57 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 		// lazy-Fill rule cannot fire (F > position for every token start in the window) -- plain 32-bit walk.
 		// F only moves when a token start reaches it; a match that ends beyond F is handled by the exact loop below.
 		if (F > wend || wbase >= end2) {
-			uint32_t rel = (uint32_t)(cur - wbase);
-			bool far = false;
-			while (rel < wn) {
+			// Every match lane precomputes where the walk goes after taking it: the first candidate at or after its end
+			// (relative to the window; >= wn leaves the window), so the scalar loop is one v_readlane per taken match.
+			const uint32_t nx = lane + L + 3u;
+			const u64 restl = nx < 64u ? mm >> nx : (u64)0;
+			const uint32_t J = nx >= wn ? nx : (restl ? nx + ctz64(restl) : wn);
+			u64 capm = sgpr64(__ballot(L == 45u) & mm);             // candidates the finder capped at 48: extended on demand
+			uint32_t mp;
+			{
+				const uint32_t rel = (uint32_t)(cur - wbase);
 				const u64 rest = mm >> rel;
-				if (rest == 0) { rel = wn; break; }
-				const uint32_t mp = rel + ctz64(rest);
-				matchmask |= ((u64)1) << mp;
-				uint32_t Lm = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)mp);
-				if (Lm == 45u) {                                  // the finder capped this match at 48: extend it
-					const u64 pm = wbase + mp;
-					const u64 x = pm - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
-					const u64 ext = 45u + wave_extend(d, x + 48u, pm + 48u, n - pm - 1u - 48u, n, lane);
-					if (lane == mp) { L = (uint32_t)ext; }
-					if (ext > 0x10000u) { cur = pm + ext + 3u; far = true; break; }
-					Lm = (uint32_t)ext;
-				}
-				rel = mp + Lm + 3u;
+				mp = rest ? rel + ctz64(rest) : wn;
 			}
-			if (!far) { cur = wbase + rel; }
+			mp = (uint32_t)__builtin_amdgcn_readfirstlane((int)mp);
+			const uint32_t wn_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wn);
+			bool far = false;
+			while (mp < wn_s) {
+				uint32_t st;
+				matchmask = sgpr64(matchmask);
+				// v_readlane needs 4 wait states after the write of its lane select (mp): on the loop edge the five scalar
+				// instructions in between provide them, on entry the s_nop does.
+				asm volatile(
+					"s_nop 3\n\t"
+					"1:\n\t"
+					"s_bitcmp1_b64 %[cap], %[mp]\n\t"
+					"s_cbranch_scc1 3f\n\t"
+					"s_bitset1_b64 %[mk], %[mp]\n\t"
+					"v_readlane_b32 %[mp], %[J], %[mp]\n\t"
+					"s_cmp_lt_u32 %[mp], %[wn]\n\t"
+					"s_cbranch_scc1 1b\n\t"
+					"s_mov_b32 %[st], 0\n\t"
+					"s_branch 4f\n\t"
+					"3:\n\t"
+					"s_mov_b32 %[st], 1\n\t"
+					"4:\n\t"
+					: [mp] "+s"(mp), [mk] "+s"(matchmask), [st] "=&s"(st)
+					: [cap] "s"(capm), [wn] "s"(wn_s), [J] "v"(J)
+					: "scc");
+				if (st == 0) { break; }
+				// the finder capped this match at 48: extend it
+				matchmask |= ((u64)1) << mp;
+				capm &= ~(((u64)1) << mp);
+				const u64 pm = wbase + mp;
+				const u64 x = pm - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
+				const u64 ext = 45u + wave_extend(d, x + 48u, pm + 48u, n - pm - 1u - 48u, n, lane);
+				if (lane == mp) { L = (uint32_t)ext; }
+				if (ext > 0x10000u) { cur = pm + ext + 3u; far = true; break; }
+				const uint32_t nxs = mp + (uint32_t)ext + 3u;
+				if (nxs >= wn_s) { mp = nxs; }
+				else { const u64 rest = mm >> nxs; mp = rest ? nxs + ctz64(rest) : wn_s; }
+			}
+			if (!far) { cur = wbase + mp; }
 		} else
 		while (cur < wend) {
 			if (cur < end2) {
