@@ -113,26 +113,63 @@ __global__ __launch_bounds__(64) void xh_parse_kernel(const uint8_t* __restrict_
 		u64 matchmask = 0;
 		const uint32_t entry = cur;
 		const uint32_t wn = wend - wbase;
-		uint32_t rel = cur - wbase;
-		while (rel < wn) {
+		// Every candidate lane clips its length to the chunk end (:93) and precomputes where the walk goes after taking it:
+		// the first candidate at or after its end (relative to the window; >= wn leaves the window). The scalar loop is
+		// then one v_readlane per taken match; candidates the finder capped at 48 are extended on demand.
+		const uint32_t remL = g.cn - o;                            // bytes left in the chunk (>= 3 for a candidate)
+		const bool cappedL = (L == 45u) && remL > 48u;
+		{ const uint32_t lc_ = (L + 3u < remL) ? L + 3u : remL; if (inr && off != 0) { L = lc_ - 3u; } }
+		const uint32_t nx = lane + L + 3u;
+		const u64 restl = nx < 64u ? mm >> nx : (u64)0;
+		const uint32_t J = nx >= wn ? nx : (restl ? nx + ctz64(restl) : wn);
+		u64 capm = sgpr64(__ballot(cappedL) & mm);
+		uint32_t mp;
+		{
+			const uint32_t rel = cur - wbase;
 			const u64 rest = mm >> rel;
-			if (rest == 0) { rel = wn; break; }
-			const uint32_t mp = rel + ctz64(rest);
+			mp = rest ? rel + ctz64(rest) : wn;
+		}
+		mp = (uint32_t)__builtin_amdgcn_readfirstlane((int)mp);
+		const uint32_t wn_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wn);
+		while (mp < wn_s) {
+			uint32_t st;
+			matchmask = sgpr64(matchmask);
+			// v_readlane needs 4 wait states after the write of its lane select (mp): on the loop edge the five scalar
+			// instructions in between provide them, on entry the s_nop does.
+			asm volatile(
+				"s_nop 3\n\t"
+				"1:\n\t"
+				"s_bitcmp1_b64 %[cap], %[mp]\n\t"
+				"s_cbranch_scc1 3f\n\t"
+				"s_bitset1_b64 %[mk], %[mp]\n\t"
+				"v_readlane_b32 %[mp], %[J], %[mp]\n\t"
+				"s_cmp_lt_u32 %[mp], %[wn]\n\t"
+				"s_cbranch_scc1 1b\n\t"
+				"s_mov_b32 %[st], 0\n\t"
+				"s_branch 4f\n\t"
+				"3:\n\t"
+				"s_mov_b32 %[st], 1\n\t"
+				"4:\n\t"
+				: [mp] "+s"(mp), [mk] "+s"(matchmask), [st] "=&s"(st)
+				: [cap] "s"(capm), [wn] "s"(wn_s), [J] "v"(J)
+				: "scc");
+			if (st == 0) { break; }
+			// capped by the finder: extend, at most to the chunk end
 			matchmask |= ((u64)1) << mp;
-			uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)mp) + 3u;
-			const uint32_t rem = g.cn - (wbase + mp);             // bytes left in the chunk (>= 3 for a candidate)
-			if (len == 48u && rem > 48u) {                         // capped by the finder: extend, at most to the chunk end
-				const u64 P = g.cbase + wbase + mp;
-				const u64 X = P - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
-				const u64 lim = g.n - P - 1u;                      // never count the buffer's final byte
-				const uint32_t maxadd = (uint32_t)((lim < rem ? lim : rem) - 48u);
-				len = 48u + xh_extend(d, X + 48u, P + 48u, maxadd, g.n, lane);
-			}
+			capm &= ~(((u64)1) << mp);
+			const uint32_t rem = g.cn - (wbase + mp);
+			const u64 P = g.cbase + wbase + mp;
+			const u64 X = P - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
+			const u64 lim = g.n - P - 1u;                          // never count the buffer's final byte
+			const uint32_t maxadd = (uint32_t)((lim < rem ? lim : rem) - 48u);
+			uint32_t len = 48u + xh_extend(d, X + 48u, P + 48u, maxadd, g.n, lane);
 			if (len > rem) { len = rem; }                          // :93
 			if (lane == mp) { L = len - 3u; }
-			rel = mp + len;
+			const uint32_t nxs = mp + len;
+			if (nxs >= wn_s) { mp = nxs; }
+			else { const u64 rest = mm >> nxs; mp = rest ? nxs + ctz64(rest) : wn_s; }
 		}
-		cur = wbase + rel;
+		cur = wbase + mp;
 		const bool is_m = (matchmask >> lane) & (u64)1;
 		const uint32_t mend = is_m ? lane + L + 3u : 0u;          // match end, relative to the window
 		const uint32_t reach = wave_incl_scan_max(mend);
