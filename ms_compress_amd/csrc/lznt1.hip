@@ -229,52 +229,51 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 		// The serial loop only decides which candidates are TAKEN; everything else (which positions are literal tokens)
 		// is derived in parallel afterwards.
 		u64 matchmask = 0;
-		uint32_t rel = entry > wbase ? entry - wbase : 0u;       // next token start, relative to the window
-		const uint32_t wn = wend - wbase;
-		uint32_t klen = key >> 12;
-		while (rel < wn) {
-			// Tight scalar walk over the resolved positions: hop from match to match (literals in between are skipped by
-			// the find-first-set) until the window ends (st = 0) or an unresolved position is reached (st = 1, rel = it).
-			// Hand-written: the compiler's version of this loop had 5 taken branches per token. v_readlane needs 4 wait
-			// states after the SALU write of its lane select.
-			un = sgpr64(un); mm = sgpr64(mm); matchmask = sgpr64(matchmask);
-			rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)rel);
+		const uint32_t wn = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wend - wbase));
+		// Every resolved match lane precomputes where the walk goes after taking it: the first stop (match or unresolved
+		// position) at or after its end, relative to the window (>= wn leaves it). The scalar walk is then one
+		// v_readlane per taken match; it leaves the asm block on an unresolved position (st = 1), which is finished by
+		// the whole wave. Stops are only ever removed at the walk's own position, so the table never goes stale ahead.
+		un = sgpr64(un); mm = sgpr64(mm);
+		const uint32_t nx = lane + (key >> 12);
+		const u64 restl = nx < 64u ? (un | mm) >> nx : (u64)0;
+		const uint32_t J = nx >= wn ? nx : (restl ? nx + ctz64(restl) : wn);
+		uint32_t mp;
+		{
+			const uint32_t rel = entry > wbase ? entry - wbase : 0u;   // next token start, relative to the window
+			const u64 rest = rel < 64u ? (un | mm) >> rel : (u64)0;
+			mp = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rest ? rel + ctz64(rest) : wn));
+		}
+		while (mp < wn) {
 #ifdef LZ_PROFILE
 			const unsigned long long tw0 = __builtin_readcyclecounter();
 #endif
-			const u64 any = un | mm;
-			const uint32_t wn_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wn);
-			uint32_t st, k_; u64 t_;
+			uint32_t st;
+			matchmask = sgpr64(matchmask);
+			// v_readlane needs 4 wait states after the write of its lane select (mp): on the loop edge the five scalar
+			// instructions in between provide them, on entry the s_nop does.
 			asm volatile(
+				"s_nop 3\n\t"
 				"1:\n\t"
-				"s_lshr_b64 %[t], %[any], %[rel]\n\t"
-				"s_cmp_eq_u64 %[t], 0\n\t"
-				"s_cbranch_scc1 2f\n\t"
-				"s_ff1_i32_b64 %[k], %[t]\n\t"
-				"s_add_i32 %[rel], %[rel], %[k]\n\t"
-				"s_bitcmp1_b64 %[un], %[rel]\n\t"
+				"s_bitcmp1_b64 %[un], %[mp]\n\t"
 				"s_cbranch_scc1 3f\n\t"
-				"s_bitset1_b64 %[mk], %[rel]\n\t"
-				"s_nop 2\n\t"
-				"v_readlane_b32 %[k], %[klen], %[rel]\n\t"
-				"s_add_i32 %[rel], %[rel], %[k]\n\t"
-				"s_cmp_lt_u32 %[rel], %[wn]\n\t"
+				"s_bitset1_b64 %[mk], %[mp]\n\t"
+				"v_readlane_b32 %[mp], %[J], %[mp]\n\t"
+				"s_cmp_lt_u32 %[mp], %[wn]\n\t"
 				"s_cbranch_scc1 1b\n\t"
-				"2:\n\t"
 				"s_mov_b32 %[st], 0\n\t"
 				"s_branch 4f\n\t"
 				"3:\n\t"
 				"s_mov_b32 %[st], 1\n\t"
 				"4:\n\t"
-				: [rel] "+s"(rel), [mk] "+s"(matchmask), [st] "=&s"(st), [k] "=&s"(k_), [t] "=&s"(t_)
-				: [any] "s"(any), [un] "s"(un), [wn] "s"(wn_s), [klen] "v"(klen)
+				: [mp] "+s"(mp), [mk] "+s"(matchmask), [st] "=&s"(st)
+				: [un] "s"(un), [wn] "s"(wn), [J] "v"(J)
 				: "scc");
 #ifdef LZ_PROFILE
 			t_acc[12] += __builtin_readcyclecounter() - tw0; t_acc[13] += 1;
 #endif
 			if (st == 0) { break; }
 			{
-				const uint32_t mp = rel;
 				// finish position wbase+mp: the candidates after the first LZ_SELF of its bucket, oldest first, 64 per step
 				const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)s, (int)mp);
 				const uint32_t eL = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)mp);
@@ -302,10 +301,13 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 #ifdef LZ_PROFILE
 				t_acc[15] += __builtin_readcyclecounter() - tf0;
 #endif
-				if (lane == mp) { key = kbest; klen = kbest >> 12; }
-				un &= ~(((u64)1) << mp);
-				if ((kbest >> 12) >= 3u) { mm |= ((u64)1) << mp; }
-				// rel stays at mp: literals before it are settled; mp itself is re-evaluated as a resolved position
+				if (lane == mp) { key = kbest; }
+				un = sgpr64(un & ~(((u64)1) << mp));
+				// literals before mp are settled; mp itself is now resolved: take its match, or step over it as a literal
+				uint32_t nxs = mp + 1u;
+				if ((kbest >> 12) >= 3u) { matchmask |= ((u64)1) << mp; nxs = mp + (kbest >> 12); }
+				const u64 rest = nxs < 64u ? (un | mm) >> nxs : (u64)0;
+				mp = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nxs >= wn ? nxs : (rest ? nxs + ctz64(rest) : wn)));
 			}
 		}
 		// tokens of the window = positions >= entry that no taken match covers: covered <=> the furthest end of the taken
