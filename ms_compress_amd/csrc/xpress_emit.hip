@@ -11,7 +11,7 @@
 // chosen match whose length hit the finder's cap (48) is extended by the whole wave, 256 bytes per step. Every
 // output byte position is a prefix sum (SURVEY.md 8a "scan layouts"):
 //   pos(t) = 4*(t div 32 + 1) + sum size(u<t),  size = 1 | 2 + [L>=7 and long-rank even] + [L>=22] + [L>=277]*(2|6)
-// evaluated with mbcnt popcounts and a DPP add-scan; flag bits are OR-ed into an LDS ring of 4 flag words.
+// evaluated with mbcnt popcounts and a DPP add-scan; the flag word in progress is kept in scalar registers.
 #include "common.h"
 #include "kernels.h"
 
@@ -57,12 +57,44 @@ extern "C" void mscomp_amd_debug_xe_prof(unsigned long long* out) { (void)hipMem
 #endif
 __device__ __forceinline__ void put8(uint8_t* __restrict__ out, u64 cap, u64 pos, uint32_t v) { if (pos < cap) { out[pos] = (uint8_t)v; } }
 
+// one unaligned 32-bit store (or four capacity-checked bytes when the window may cross the capacity)
+__device__ __forceinline__ void xe_store32(uint8_t* __restrict__ out, u64 cap, u64 pos, uint32_t v, bool chk)
+{
+	if (!chk) { st32(out + pos, v); }
+	else { put8(out, cap, pos, v); put8(out, cap, pos + 1u, v >> 8); put8(out, cap, pos + 2u, v >> 16); put8(out, cap, pos + 3u, v >> 24); }
+}
+// The bytes of this lane's token (:274-315). CHK = false: the whole window fits below the capacity (decided once, wave
+// uniform), plain stores and the 16-bit symbol in one store; CHK = true: byte stores, each checked against the capacity.
+template <bool CHK>
+__device__ __forceinline__ void xe_emit_tokens(uint8_t* __restrict__ out, u64 cap, u64 base, uint32_t posrel, bool is_tok, bool is_m,
+                                               uint32_t byte, uint32_t off, uint32_t L, bool lng, bool even, bool has_above,
+                                               uint32_t nib, uint32_t pnib, bool pend, u64 pend_pos, uint32_t pend_low, u64 longmask, uint32_t lane)
+{
+#define XE_PUT(q_, v_) { if (CHK) { put8(out, cap, base + (q_), (v_)); } else { ob[(q_)] = (uint8_t)(v_); } }
+	uint8_t* __restrict__ ob = out + base;
+	if (!is_tok) { return; }
+	if (!is_m) { XE_PUT(posrel, byte) return; }
+	const uint32_t sym = ((off - 1u) << 3) | (L < 7u ? L : 7u);
+	if (CHK) { put8(out, cap, base + posrel, sym); put8(out, cap, base + posrel + 1u, sym >> 8); } else { st16(ob + posrel, sym); }
+	uint32_t q = posrel + 2u;
+	if (lng) {
+		if (even) { XE_PUT(q, nib | (has_above ? pnib << 4 : 0u)) ++q; }
+		else if (pend && (longmask & ((((u64)1) << lane) - 1u)) == 0) { if (CHK) { put8(out, cap, pend_pos, pend_low | (nib << 4)); } else { out[pend_pos] = (uint8_t)(pend_low | (nib << 4)); } }
+		if (L >= 22u) {
+			XE_PUT(q, L - 22u < 255u ? L - 22u : 255u) ++q;
+			if (L >= 277u) {
+				if (L <= 0xFFFFu) { XE_PUT(q, L) XE_PUT(q + 1u, L >> 8) }
+				else { XE_PUT(q, 0) XE_PUT(q + 1u, 0) XE_PUT(q + 2u, L) XE_PUT(q + 3u, L >> 8) XE_PUT(q + 4u, L >> 16) XE_PUT(q + 5u, L >> 24) }
+			}
+		}
+	}
+#undef XE_PUT
+}
+
 __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                         const uint16_t* __restrict__ mlen3, const uint16_t* __restrict__ moff,
                                                         uint8_t* __restrict__ d_out, u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
 {
-	__shared__ uint32_t s_facc[4];
-	__shared__ uint32_t s_fpos[4];
 	const uint32_t lane = threadIdx.x;
 	const uint32_t u = blockIdx.x;
 	const u64 n = bt.in_len[u];
@@ -72,11 +104,9 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 	const u64 mbase = (u64)bt.chunk_prefix[u] * 65536u;           // this unit's slice of the per-position match arrays
 	const u64 end2 = n >= 2u ? n - 2u : 0u;
 
-	if (lane < 4) { s_facc[lane] = 0; s_fpos[lane] = 0; }
-	__syncthreads();
-
 	u64 cur = 0, F = 0, S = 0, N = 0, R = 0;                      // next token start, filled, sum sizes, tokens, long matches
 	bool pend = false; u64 pend_pos = 0; uint32_t pend_low = 0;   // length nibble byte waiting for its high half
+	uint32_t facc = 0; u64 fposc = 0;                             // flag word in progress (first token = bit 0) and its slot
 
 	// Inputs are burst-loaded 8 windows (512 positions) at a time into a double-buffered LDS stage: one wait on global
 	// memory per 512 positions instead of one per window (loads are unconditional with a clamped index).
@@ -205,73 +235,68 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 		const u64 tokmask = __ballot(is_tok);
 
 		// ---- emit ----------------------------------------------------------------------------------------------
+		const uint32_t nt = (uint32_t)__popcll(tokmask);
 		const bool lng = is_m && L >= 7u;
 		const u64 longmask = __ballot(lng);
-		const u64 r = R + popc_below(longmask);
-		const bool even = !(r & 1u);
+		const bool even = !(((uint32_t)R + popc_below(longmask)) & 1u);
 		uint32_t sz = 0;
 		if (is_tok) { sz = !is_m ? 1u : 2u + (uint32_t)(lng && even) + (uint32_t)(L >= 22u) + (L >= 277u ? (L <= 0xFFFFu ? 2u : 6u) : 0u); }
 		const uint32_t incl = wave_incl_scan_add(sz);
+		const uint32_t wsum = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 		const uint32_t tb = popc_below(tokmask);
-		const u64 t = N + tb;
-		const u64 pos = 4u * (t / 32u + 1u) + S + (incl - sz);
+		const uint32_t sh = (uint32_t)(N & 31u);                   // tokens already in the flag word in progress
+		const uint32_t tq = sh + tb;                               // my token's index counted from that word's first token
+		// every position of this window is base + a 32-bit offset: pos(t) = 4*(t div 32 + 1) + sum size(u<t)
+		const u64 base = 4u * (N / 32u + 1u) + S;
+		const uint32_t posrel = 4u * (tq >> 5) + (incl - sz);
+		const uint32_t kdone = (sh + nt) >> 5;                     // flag words completed by this window (0..2)
+		const bool fits = base + 4u * kdone + wsum <= cap;         // uniform: no store of this window can pass the capacity
 		// the nibble of the NEXT long match in this window (it shares my byte when my rank is even)
 		const u64 above = (longmask >> lane) >> 1;
 		const uint32_t nib = L >= 7u ? (L - 7u < 15u ? L - 7u : 15u) : 0u;
 		const uint32_t partner = above ? lane + 1u + ctz64(above) : lane;
 		const uint32_t pnib = (uint32_t)__shfl((int)nib, (int)partner, 64);
-		if (is_tok) {
-			if (!is_m) { put8(out, cap, pos, byte); }
-			else {
-				const uint32_t sym = ((off - 1u) << 3) | (L < 7u ? L : 7u);
-				put8(out, cap, pos, sym); put8(out, cap, pos + 1u, sym >> 8);
-				u64 q = pos + 2u;
-				if (lng) {
-					if (even) { put8(out, cap, q, nib | (above ? pnib << 4 : 0u)); ++q; }
-					else if (pend && (longmask & ((((u64)1) << lane) - 1u)) == 0) { put8(out, cap, pend_pos, pend_low | (nib << 4)); }
-					if (L >= 22u) {
-						put8(out, cap, q, L - 22u < 255u ? L - 22u : 255u); ++q;
-						if (L >= 277u) {
-							if (L <= 0xFFFFu) { put8(out, cap, q, L); put8(out, cap, q + 1u, L >> 8); }
-							else {
-								put8(out, cap, q, 0); put8(out, cap, q + 1u, 0);
-								put8(out, cap, q + 2u, L); put8(out, cap, q + 3u, L >> 8); put8(out, cap, q + 4u, L >> 16); put8(out, cap, q + 5u, L >> 24);
-							}
-						}
-					}
+		if (fits) { xe_emit_tokens<false>(out, cap, base, posrel, is_tok, is_m, byte, off, L, lng, even, above != 0, nib, pnib, pend, pend_pos, pend_low, longmask, lane); }
+		else      { xe_emit_tokens<true >(out, cap, base, posrel, is_tok, is_m, byte, off, L, lng, even, above != 0, nib, pnib, pend, pend_pos, pend_low, longmask, lane); }
+		XE_T(2)
+		// ---- flag words: the match bits in TOKEN order are a ballot after moving every token's bit to lane = its rank
+		// (tokens to [0,nt), the other lanes behind them: a permutation). The word in progress lives in scalars, first
+		// token in bit 0; a completed word is bit-reversed into its slot (the first token is the MSB, :317-324). ----------
+		{
+			const uint32_t dst = is_tok ? tb : nt + (lane - tb);
+			const uint32_t fm = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (is_tok && is_m) ? 1 : 0);
+			const u64 M = __ballot(fm != 0);
+			u64 sm = __ballot(is_tok && (tq & 31u) == 0);             // tokens that open a flag word: its slot is the 4 bytes before them
+			const u64 lo = (u64)facc | (M << sh);
+			const uint32_t hi = sh ? (uint32_t)(M >> (64u - sh)) : 0u;
+			u64 fp = fposc;
+			uint32_t w = (uint32_t)lo;
+			if (sh == 0) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; sm &= sm - 1u; }
+			if (kdone >= 1u) {
+				if (lane == 0) { xe_store32(out, cap, fp, __builtin_bitreverse32(w), !fits); }
+				w = (uint32_t)(lo >> 32);
+				if (sm) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; sm &= sm - 1u; }
+				if (kdone >= 2u) {
+					if (lane == 0) { xe_store32(out, cap, fp, __builtin_bitreverse32(w), !fits); }
+					w = hi;
+					if (sm) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; }
 				}
 			}
-			if ((t & 31u) == 0) { __hip_atomic_store(&s_fpos[(t >> 5) & 3u], (uint32_t)(pos - 4u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+			facc = w; fposc = fp;
 		}
-		XE_T(2)
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
-		if (is_m) { atomicOr(&s_facc[(t >> 5) & 3u], 1u << (31u - (uint32_t)(t & 31u))); }
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
-		const u64 N2 = N + (uint32_t)__popcll(tokmask);
-		for (u64 g = N / 32u; g < N2 / 32u; ++g) {                // flag words completed in this window
-			if (lane == 0) {
-				const uint32_t wv = __hip_atomic_load(&s_facc[g & 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-				const u64 fp = __hip_atomic_load(&s_fpos[g & 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-				put8(out, cap, fp, wv); put8(out, cap, fp + 1u, wv >> 8); put8(out, cap, fp + 2u, wv >> 16); put8(out, cap, fp + 3u, wv >> 24);
-				__hip_atomic_store(&s_facc[g & 3u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-			}
-		}
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
 		// carry
 		if (longmask) {
 			const uint32_t ll = 63u - (uint32_t)__builtin_clzll(longmask);        // last long match of the window
 			const u64 rl = R + (uint32_t)__popcll(longmask) - 1u;
 			pend = !(rl & 1u);
 			if (pend) {
-				const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pos, (int)ll);
-				const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pos >> 32), (int)ll);
-				pend_pos = (((u64)hi << 32) | lo) + 2u;
+				pend_pos = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)ll) + 2u;
 				pend_low = (uint32_t)__builtin_amdgcn_readlane((int)nib, (int)ll);
 			}
 			R += (uint32_t)__popcll(longmask);
 		}
-		N = N2;
-		S += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		N += nt;
+		S += wsum;
 		XE_T(3)
 	}
 #ifdef XE_PROFILE
@@ -284,7 +309,7 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 	const u64 total = 4u * (gf + 1u) + S;
 	if (lane == 0) {
 		uint32_t wv; u64 fp;
-		if (cnt) { wv = s_facc[gf & 3u] | ((1u << (32u - cnt)) - 1u); fp = s_fpos[gf & 3u]; }
+		if (cnt) { wv = __builtin_bitreverse32(facc) | ((1u << (32u - cnt)) - 1u); fp = fposc; }
 		else { wv = 0xFFFFFFFFu; fp = total - 4u; }
 		put8(out, cap, fp, wv); put8(out, cap, fp + 1u, wv >> 8); put8(out, cap, fp + 2u, wv >> 16); put8(out, cap, fp + 3u, wv >> 24);
 		const bool ok = total <= cap;
