@@ -40,22 +40,14 @@ __device__ __forceinline__ uint32_t ldg32_safe(const uint8_t* __restrict__ d, u6
 #ifdef XL_PROFILE
 __device__ unsigned long long g_xl_prof[8];
 extern "C" void mscomp_amd_debug_xl_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xl_prof), 64); unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xl_prof), z, 64); }
-#define XL_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); xl_acc[i] += t_ - xl_prev; xl_prev = t_; }
-#else
-#define XL_T(i)
 #endif
-// LDS of xp_links_kernel: heads | per-position info (2 tiles) | staged tile bytes | 14 conflict detectors
-#define XL_INFO_OFF   65536u
-#define XL_STAGE_OFF  (XL_INFO_OFF + 2u * 4096u * 4u)
-#define XL_TMP_OFF    (XL_STAGE_OFF + 4096u + 16u)
-#define XL_LDS_BYTES  (XL_TMP_OFF + 14u * 2048u)
+#define XL_NC 1u                                   // consumer waves (hash classes); the other 16-XL_NC waves produce hashes
+#define XL_NP (16u - XL_NC)
+#define XL_NQ ((64u + XL_NP - 1u) / XL_NP)         // batches of 64 positions per producer wave and tile
+// LDS of xp_links_kernel: 32768 heads (u32) | hashes of two tiles (u16)
+#define XL_HASH_OFF   131072u
+#define XL_LDS_BYTES  (XL_HASH_OFF + 2u * 4096u * 2u)
 
-// One 256-thread block per 64 KiB link chunk, software-pipelined over 4096-position tiles:
-//   waves 2-15 (producers): hash of every position of tile t and the intra-batch (64 positions) conflict resolution -- which
-//       earlier lane of the batch has the same hash, which lane is the last one with it -- none of which depends on the
-//       serial head table; result = one info word per position;
-//   waves 0-1 (consumers, one per hash parity): the serial pass over tile t-1: per 64 positions ONE LDS gather of the heads (lanes without an
-//       in-batch predecessor), one coalesced store of the links, ONE LDS scatter (last lane of every hash).
 // 16 bytes at ANY byte address of an LDS array whose base is 4-byte aligned. A byte-misaligned ds_read_b128 is replayed
 // (SQ_LDS_UNALIGNED_STALL was 77 % of this kernel's LDS cycles), so read 5 ALIGNED dwords and funnel-shift (v_alignbyte).
 __device__ __forceinline__ uint4 ld128(const uint8_t* base, uint32_t off)
@@ -69,13 +61,21 @@ __device__ __forceinline__ uint4 ld128(const uint8_t* base, uint32_t off)
 // index of the first differing byte of two 16-byte blocks given their XOR (16 if equal)
 __device__ __forceinline__ uint32_t first_diff16(const uint4 x) { return first_nz_byte16(x.x, x.y, x.z, x.w); }
 
+// One 1024-thread block per 64 KiB link chunk (its 128 KiB head table fills the CU's LDS), software-pipelined over
+// 4096-position tiles:
+//   waves XL_NC..15 (producers): the hash of every position of tile t, straight from global memory, into LDS;
+//   waves 0..XL_NC-1 (consumers, one per hash class h mod XL_NC so they never touch the same head): the serial pass
+//       over tile t-1 -- per 64 positions ONE returning LDS exchange  link[p] = exchange(head[hash(p)], p).
+// Batches are issued in ascending position order and, within one DS instruction, same-address atomics are served in
+// lane order (gfx950 behaviour, tools/dev/lds_order_test.hip; every parity test depends on it), so each position
+// receives exactly the most recent earlier position with its hash: the chain link of XpressDictionary.h:120-135.
+// No conflict detection, no head gather/scatter pairs: 8 exchanges in flight, links leave as coalesced u16 stores.
 __global__ __launch_bounds__(1024) void xp_links_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                       uint16_t* __restrict__ links, uint16_t* __restrict__ lasthead)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	uint16_t* const s_head = reinterpret_cast<uint16_t*>(smem);
-	uint32_t* const s_info = reinterpret_cast<uint32_t*>(smem + XL_INFO_OFF);
-	uint8_t* const s_stage = smem + XL_STAGE_OFF;
+	uint32_t* const s_head = reinterpret_cast<uint32_t*>(smem);
+	uint16_t* const s_hash = reinterpret_cast<uint16_t*>(smem + XL_HASH_OFF);
 
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
 	const uint32_t lc = blockIdx.x;
@@ -85,105 +85,88 @@ __global__ __launch_bounds__(1024) void xp_links_kernel(const uint8_t* __restric
 	const u64 cbase = (u64)k * 65536u;
 	const uint32_t cn = (n - cbase < 65536u) ? (uint32_t)(n - cbase) : 65536u;            // positions in this chunk
 	const uint32_t ins = (n >= cbase + 3u) ? ((n - 2u - cbase < cn) ? (uint32_t)(n - 2u - cbase) : cn) : 0u;   // p < n-2
-	const uint8_t* __restrict__ src = d_in + bt.in_off[u] + cbase;
-	const u64 avail = n - cbase;                                                          // readable bytes from src
+	const uint8_t* __restrict__ d = d_in + bt.in_off[u];
 	uint16_t* __restrict__ lk = links + (u64)lc * 65536u;
-	uint8_t* const s_tmp = smem + XL_TMP_OFF + (wv >= 2u ? wv - 2u : 0u) * 2048u;
 
-	for (uint32_t i = tid * 8u; i < 32768u; i += 8192u) { *reinterpret_cast<uint4*>(s_head + i) = make_uint4(~0u, ~0u, ~0u, ~0u); }
+	for (uint32_t i = tid * 4u; i < 32768u; i += 4096u) { *reinterpret_cast<uint4*>(s_head + i) = make_uint4(~0u, ~0u, ~0u, ~0u); }
+	// positions without a hash (the unit's last two) have no link
+	for (uint32_t o = ins + tid; o < cn; o += 1024u) { lk[o] = 0xFFFFu; }
 
-	if (wv < 2u) { __builtin_amdgcn_s_setprio(3); }            // the serial consumers are the critical path of the pipeline
-	const uint32_t ntiles = (ins + 4095u) >> 12;
 #ifdef XL_PROFILE
-	unsigned long long xl_acc[4] = {0, 0, 0, 0}, xl_prev = __builtin_readcyclecounter();
+	unsigned long long xl_c = 0, xl_p = 0; const unsigned long long xl_t0 = __builtin_readcyclecounter();
 #endif
+	if (wv < XL_NC) { __builtin_amdgcn_s_setprio(3); }          // the serial consumers are the critical path of the pipeline
+	const uint32_t ntiles = (ins + 4095u) >> 12;
+	// producers keep the NEXT tile's bytes in flight (registers) while they hash the current one: 15 waves x 5 batches
+	// (4800 >= 4096 positions per tile)
+	uint32_t v[XL_NQ];
+#define XL_LOAD_TILE(tb_) { const uint32_t tn_ = (ins - (tb_) < 4096u) ? ins - (tb_) : 4096u; _Pragma("unroll") for (uint32_t q = 0; q < XL_NQ; ++q) { \
+		const uint32_t r_ = q * (XL_NP * 64u) + (wv - XL_NC) * 64u + lane; v[q] = r_ < tn_ ? ldg32_safe(d, cbase + (tb_) + r_, n) : 0u; } }
+	if (wv >= XL_NC && ntiles) { XL_LOAD_TILE(0u) }
 	for (uint32_t t = 0; t <= ntiles; ++t) {
 		const uint32_t tbase = t * 4096u;
-		XL_T(3)
-		if (t < ntiles) {                                         // stage 4096+16 bytes of tile t (zero beyond the unit end)
-			const bool vec = (((uintptr_t)(src + tbase) & 15u) == 0);
-			for (uint32_t i = tid * 16u; i < 4096u + 16u; i += 16384u) {
-				uint4 v = make_uint4(0, 0, 0, 0);
-				if (vec && (u64)tbase + i + 16u <= avail) { v = *reinterpret_cast<const uint4*>(src + tbase + i); }
-				else {
-					uint32_t w[4] = { 0, 0, 0, 0 };
-					for (uint32_t bb = 0; bb < 16u; ++bb) { if ((u64)tbase + i + bb < avail) { w[bb >> 2] |= (uint32_t)src[tbase + i + bb] << (8u * (bb & 3u)); } }
-					v = make_uint4(w[0], w[1], w[2], w[3]);
-				}
-				*reinterpret_cast<uint4*>(s_stage + i) = v;
-			}
-		}
-		__syncthreads();
-		XL_T(0)
-		if (wv >= 2u) {
-			if (t < ntiles) {                                     // ---- producers: info words of tile t
+#ifdef XL_PROFILE
+		const unsigned long long xl_a = __builtin_readcyclecounter();
+#endif
+		if (wv >= XL_NC) {
+			if (t < ntiles) {                                     // ---- producers: hashes of tile t
 				const uint32_t tn = (ins - tbase < 4096u) ? ins - tbase : 4096u;
-				uint32_t* const info = s_info + (t & 1u) * 4096u;
-				for (uint32_t b = wv - 2u; b * 64u < tn; b += 14u) {
-					const uint32_t r = b * 64u + lane;
-					const bool valid = r < tn;
-					const uint32_t h = xp_hash3(ld32(s_stage + r));
-					if (valid) { __hip_atomic_store(&s_tmp[h & 2047u], (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
-					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
-					const bool loser = valid && __hip_atomic_load(&s_tmp[h & 2047u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) != lane;
-					// one iteration per hash shared by >1 lane of the batch: only capture the group's lane mask here
-					u64 mygrp = 0;
-					u64 lm = __ballot(loser);
-					while (lm) {
-						const uint32_t hh = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)ctz64(lm));
-						const u64 g = __ballot(valid && h == hh);
-						if (h == hh) { mygrp = g; }
-						lm &= ~g;
-					}
-					uint32_t prevlane = 0xFFu;
-					bool writer = valid;
-					if (mygrp) {
-						const u64 below = mygrp & ((((u64)1) << lane) - 1u);
-						if (below) { prevlane = 63u - (uint32_t)__builtin_clzll(below); }           // nearest earlier lane
-						writer = (lane == 63u - (uint32_t)__builtin_clzll(mygrp));                  // head = latest position
-					}
-					info[r] = h | ((uint32_t)writer << 15) | (prevlane << 16) | ((uint32_t)valid << 24);
-					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+				uint16_t* const hs = s_hash + (t & 1u) * 4096u;
+				#pragma unroll
+				for (uint32_t q = 0; q < XL_NQ; ++q) {
+					const uint32_t r = q * (XL_NP * 64u) + (wv - XL_NC) * 64u + lane;
+					if (r < tn) { hs[r] = (uint16_t)xp_hash3(v[q]); }
 				}
+				if (t + 1u < ntiles) { XL_LOAD_TILE(tbase + 4096u) }
 			}
-		} else if (t > 0) {                                       // ---- consumer: serial head pass over tile t-1
-			// 4 batches per round: all info words first, then gather/scatter of the heads ISSUED in order without waiting
-			// (DS operations of a wave execute in order, so batch b+1's gather sees batch b's scatter); links stored last.
+		} else if (t > 0) {                                       // ---- consumers: serial exchange pass over tile t-1 (my hash class)
 			const uint32_t pbase = tbase - 4096u;
 			const uint32_t tn = (ins - pbase < 4096u) ? ins - pbase : 4096u;
-			const uint32_t* const info = s_info + ((t - 1u) & 1u) * 4096u;
+			const uint16_t* const hs = s_hash + ((t - 1u) & 1u) * 4096u;
+			if (XL_NC == 1u && tn == 4096u) {
+				// full tile, single consumer: nothing to mask -- per batch one hash read, one exchange, one link store
+				for (uint32_t b0 = 0; b0 < 64u; b0 += 8u) {
+					uint32_t h[8], old[8];
+					#pragma unroll
+					for (int j = 0; j < 8; ++j) { h[j] = hs[(b0 + j) * 64u + lane]; }
+					#pragma unroll
+					for (int j = 0; j < 8; ++j) { old[j] = __hip_atomic_exchange(&s_head[h[j]], pbase + (b0 + j) * 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+					#pragma unroll
+					for (int j = 0; j < 8; ++j) { lk[pbase + (b0 + j) * 64u + lane] = (uint16_t)old[j]; }
+				}
+			} else
 			for (uint32_t b0 = 0; b0 * 64u < tn; b0 += 8u) {
-				uint32_t w[8], pred[8];
+				uint32_t h[8], old[8];
 				#pragma unroll
-				for (int j = 0; j < 8; ++j) { w[j] = info[((b0 + j) * 64u + lane) & 4095u]; }          // unconditional: waits once
+				for (int j = 0; j < 8; ++j) { h[j] = hs[((b0 + j) * 64u + lane) & 4095u]; }              // unconditional: waits once
 				#pragma unroll
 				for (int j = 0; j < 8; ++j) {
-					if (((w[j] >> 24) == 0) || ((w[j] & 1u) != wv) || (b0 + j) * 64u + lane >= tn) { w[j] = 0; }   // stale / other consumer's class
-					const uint32_t h = w[j] & 0x7FFFu;
-					const uint32_t o = pbase + (b0 + j) * 64u + lane;
-					// unconditional gather (idle lanes read head[0] and ignore it): no wait between the 8 gather/scatter pairs
-					pred[j] = __hip_atomic_load(&s_head[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-					if (w[j] & 0x8000u) { __hip_atomic_store(&s_head[h], (uint16_t)o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+					const uint32_t r = (b0 + j) * 64u + lane;
+					old[j] = 0xFFFFu;
+					if (r < tn && (h[j] & (XL_NC - 1u)) == wv) { old[j] = __hip_atomic_exchange(&s_head[h[j]], pbase + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 				}
 				#pragma unroll
 				for (int j = 0; j < 8; ++j) {
-					const uint32_t pl = (w[j] >> 16) & 0xFFu;
-					if (pl != 0xFFu) { pred[j] = pbase + (b0 + j) * 64u + pl; }
+					const uint32_t r = (b0 + j) * 64u + lane;
+					if (r < tn && (h[j] & (XL_NC - 1u)) == wv) { lk[pbase + r] = (uint16_t)old[j]; }
 				}
-				#pragma unroll
-				for (int j = 0; j < 8; ++j) { if (w[j]) { lk[pbase + (b0 + j) * 64u + lane] = (uint16_t)pred[j]; } }
 			}
 		}
-		XL_T(1)
+#ifdef XL_PROFILE
+		if (wv == 0) { xl_c += __builtin_readcyclecounter() - xl_a; } else { xl_p += __builtin_readcyclecounter() - xl_a; }
+#endif
 		__syncthreads();
-		XL_T(2)
 	}
 #ifdef XL_PROFILE
-	if (lane == 0 && (wv == 0 || wv == 2)) { for (int i_ = 0; i_ < 4; ++i_) { atomicAdd(&g_xl_prof[(wv >> 1) * 4 + i_], xl_acc[i_]); } }
+	if (lane == 0 && wv == 0) { atomicAdd(&g_xl_prof[0], xl_c); atomicAdd(&g_xl_prof[2], __builtin_readcyclecounter() - xl_t0); atomicAdd(&g_xl_prof[3], 1ull); }
+	if (lane == 0 && wv == XL_NC) { atomicAdd(&g_xl_prof[1], xl_p); }
 #endif
 	if (lc + 1u < bt.chunk_prefix[u + 1]) {                     // a later chunk of this unit continues chains into this one
 		uint16_t* __restrict__ lh = lasthead + (u64)lc * 32768u;
-		for (uint32_t i = tid * 8u; i < 32768u; i += 8192u) { *reinterpret_cast<uint4*>(lh + i) = *reinterpret_cast<const uint4*>(s_head + i); }
+		for (uint32_t i = tid * 2u; i < 32768u; i += 2048u) {
+			const uint32_t a0 = s_head[i], a1 = s_head[i + 1u];
+			*reinterpret_cast<uint32_t*>(lh + i) = (a0 & 0xFFFFu) | (a1 << 16);
+		}
 	}
 }
 
