@@ -464,20 +464,40 @@ __global__ __launch_bounds__(64) void xh_encode_kernel(const uint8_t* __restrict
 		else { atomicOr(&s_bits[(w0_ & 255u) >> 1], (((val) >> (b_ + (len) - 16u)) & 0xFFFFu) << ((w0_ & 1u) * 16u)); \
 		       atomicOr(&s_bits[((w0_ + 1u) & 255u) >> 1], (((val) << (32u - b_ - (len))) & 0xFFFFu) << (((w0_ + 1u) & 1u) * 16u)); } }
 	const uint32_t nwin = (g.cn + 63u) >> 6;
+	// Inputs are burst-loaded 8 windows (512 positions) at a time into a double-buffered LDS stage, like the parse kernel:
+	// one wait on global memory per 512 positions instead of two dependent round trips per window.
+	__shared__ uint16_t s_in_off[2][512];
+	__shared__ uint16_t s_in_len[2][512];
+	__shared__ uint8_t  s_in_byte[2][512];
+	__shared__ u64      s_in_tok[2][8];
+	uint32_t g_off[8], g_len[8], g_byte[8]; u64 g_tok = 0;
+#define XE_BURST_LOAD(gb) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { \
+		const uint32_t q_ = (gb) + (uint32_t)k_ * 64u + lane; const uint32_t c_ = q_ < g.cn ? q_ : g.cn - 1u; \
+		g_off[k_] = moff[gbase + c_]; g_len[k_] = mlen3[gbase + c_]; g_byte[k_] = d[c_]; } \
+		g_tok = (lane < 8u && ((gb) >> 6) + lane < nwin) ? tokbits[(u64)lc * 1024u + ((gb) >> 6) + lane] : (u64)0; }
+#define XE_BURST_STORE(buf) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { \
+		s_in_off[buf][k_ * 64 + lane] = (uint16_t)g_off[k_]; s_in_len[buf][k_ * 64 + lane] = (uint16_t)g_len[k_]; s_in_byte[buf][k_ * 64 + lane] = (uint8_t)g_byte[k_]; } \
+		if (lane < 8u) { s_in_tok[buf][lane] = g_tok; } }
+	if (nwin) { XE_BURST_LOAD(0u) }
 	for (uint32_t w = 0; w <= nwin; ++w) {
 		// window w < nwin: the tokens starting in it; w == nwin: the EOS token of the unit's last chunk (lane 0)
 		uint32_t clen = 0, code = 0, ob = 0, offlow = 0, rawn = 0, L = 0;
 		bool is_tok = false;
 		if (w < nwin) {
-			const u64 tm = tokbits[(u64)lc * 1024u + w];
+			const uint32_t wi = w & 7u, buf = (w >> 3) & 1u;
+			if (wi == 0) {                                          // group start: publish this group's inputs, start loading the next
+				XE_BURST_STORE(buf)
+				if ((w + 8u) < nwin) { XE_BURST_LOAD((w + 8u) * 64u) }
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+			}
+			const u64 tm = __hip_atomic_load(&s_in_tok[buf][wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 			if (tm == 0) { continue; }
 			is_tok = (tm >> lane) & (u64)1;
 			if (is_tok) {
-				const uint32_t o = w * 64u + lane;
-				const uint32_t off = moff[gbase + o];
-				uint32_t sym = d[o];
+				const uint32_t off = s_in_off[buf][wi * 64u + lane];
+				uint32_t sym = s_in_byte[buf][wi * 64u + lane];
 				if (off != 0 && !fallback) {
-					L = mlen3[gbase + o];
+					L = s_in_len[buf][wi * 64u + lane];
 					ob = 31u - (uint32_t)__builtin_clz(off);
 					sym = 0x100u | (ob << 4) | (L < 15u ? L : 15u);
 					offlow = off ^ (1u << ob);
@@ -532,6 +552,8 @@ __global__ __launch_bounds__(64) void xh_encode_kernel(const uint8_t* __restrict
 	}
 #undef XH_F
 #undef XH_ORBITS
+#undef XE_BURST_LOAD
+#undef XE_BURST_STORE
 }
 
 // ===================================================================================================================
