@@ -6,18 +6,20 @@
 //
 // The reference keeps one head table (32768 pointers) + a predecessor ring for the whole buffer and inserts
 // positions serially. Here every 64 KiB slice ("link chunk") of a unit is independent:
-//   xp_links_kernel : one 256-thread block per link chunk, head table (32768 x u16 = 64 KiB) in LDS. Positions are
-//                     inserted 64 at a time: ballot-resolved intra-batch hash conflicts (3 producer waves, no serial
-//                     dependency), then one LDS gather + scatter of the heads per 64 positions (1 consumer wave); the
-//                     predecessor links leave as coalesced u16 stores. pred(p) restricted to the chunk;
-//                     the chunk's final head table is exported so the NEXT chunk can continue a chain into it
-//                     (a chain never needs to reach further back than one chunk: 65535 / 8192 byte windows).
-//   xp_find_kernel  : 4096-position tiles, the tile's window staged in LDS; per position: walks <= 11 links (MaxChain, Level 3) while inside the window,
-//                     candidates must share the first 2 bytes, length by 4-byte XOR compares, strictly-longer wins
-//                     (nearest on ties), stop at >= 48 (NiceLength). Lengths are CAPPED at 48 here: the candidate
-//                     choice never depends on more (48 ends the walk); the parse kernels extend the chosen match.
-//                     The reference's "never count the buffer's final byte" rule (XpressDictionary.h:88-93) is the
-//                     limit n-p-1.
+//   xp_links_kernel : one 1024-thread block per link chunk, head table (32768 x u32 = 128 KiB) in LDS. 15 producer
+//                     waves hash the positions of a tile; one consumer wave inserts them 64 at a time with ONE
+//                     returning LDS exchange per batch, link[p] = exchange(head[hash(p)], p) (same-address atomics
+//                     of one DS instruction are served in lane order, so the serial insertion order is kept); the
+//                     links leave as coalesced u16 stores. pred(p) is restricted to the chunk; the chunk's final
+//                     head table is exported so the NEXT chunk can continue a chain into it (a chain never needs to
+//                     reach further back than one chunk: 65535 / 8192 byte windows).
+//   xp_find_kernel  : 4096-position tiles, the tile's window staged in LDS; per position: walks <= 11 links
+//                     (MaxChain, Level 3) while inside the window; every candidate is compared 16 bytes at a time
+//                     against the position's own 48 bytes held in registers (branch-free first-difference),
+//                     strictly-longer wins (nearest on ties), stop at >= 48 (NiceLength). Lengths are CAPPED at 48
+//                     here: the candidate choice never depends on more (48 ends the walk); the parse kernels extend
+//                     the chosen match. The reference's "never count the buffer's final byte" rule
+//                     (XpressDictionary.h:88-93) is the limit n-p-1.
 #include "common.h"
 #include "kernels.h"
 
