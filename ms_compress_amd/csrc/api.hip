@@ -30,7 +30,7 @@ struct DevBuf {
 };
 
 struct ProfRec { const char* name; hipEvent_t a, b; };
-const uint32_t XH_FB_BLOCKS = 256;                     // resident blocks (and HBM scratch slots) of the fallback kernel
+const uint32_t XH_FB_BLOCKS = 256;                     // persistent blocks of the fallback kernel (one per CU: its package pool fills the LDS)
 
 } // namespace
 
@@ -39,7 +39,7 @@ struct mscomp_amd_ctx {
 	hipStream_t stream = nullptr;
 	DevBuf slots, slot_size, prefix, tile_sums;        // chunk scratch (grow-only, shared by all plans of the ctx)
 	DevBuf links, lasthead, mlen3, moff;               // Xpress-family match finder scratch (per 64 KiB link chunk)
-	DevBuf tokbits, counts, extra, lens, codes, fb_list, fbflag, fb_pool;   // Xpress+Huffman per-chunk scratch
+	DevBuf tokbits, counts, extra, lens, codes, fb_list, fbflag;   // Xpress+Huffman per-chunk scratch
 	DevBuf one_in, one_out, one_meta;                  // staging of the host-pointer one-shot path
 	bool profiling = false;
 	std::vector<ProfRec> recs;
@@ -130,7 +130,7 @@ void mscomp_amd_ctx_destroy(mscomp_amd_ctx* c)
 	c->one_in.release(); c->one_out.release(); c->one_meta.release();
 	c->links.release(); c->lasthead.release(); c->mlen3.release(); c->moff.release();
 	c->tokbits.release(); c->counts.release(); c->extra.release(); c->lens.release(); c->codes.release();
-	c->fb_list.release(); c->fbflag.release(); c->fb_pool.release();
+	c->fb_list.release(); c->fbflag.release();
 	delete c;
 }
 
@@ -203,8 +203,7 @@ MSCompStatus mscomp_amd_plan_create(mscomp_amd_ctx* c, MSCompFormat format, size
 	if (ok && format == MSCOMP_XPRESS_HUFF) {
 		const size_t nc = (size_t)p->n_chunks + 1;
 		ok = c->tokbits.reserve(nc * 1024 * 8) && c->counts.reserve(nc * 512 * 4) && c->extra.reserve(nc * 4) &&
-		     c->lens.reserve(nc * 512) && c->codes.reserve(nc * 1024) && c->fb_list.reserve(nc * 4 + 64) && c->fbflag.reserve(nc * 4) &&
-		     c->fb_pool.reserve((size_t)XH_FB_BLOCKS * xh_fallback_pool_bytes_per_block());
+		     c->lens.reserve(nc * 512) && c->codes.reserve(nc * 1024) && c->fb_list.reserve(nc * 4 + 64) && c->fbflag.reserve(nc * 4);
 	}
 	if (!ok) { p->tables.release(); delete p; return MSCOMP_MEM_ERROR; }
 	*out = p;
@@ -258,7 +257,7 @@ MSCompStatus mscomp_amd_plan_execute(mscomp_amd_plan* p, const uint8_t* d_in, ui
 		{ KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0xFFFFu, 1); }
 		{ KernelTimer t(c, "xh_parse_kernel"); launch_xh_parse(st, d_in, p->bt, mlen3, moff, tokbits, counts, extra); }
 		{ KernelTimer t(c, "xh_huff_kernel"); launch_xh_huff(st, p->bt, counts, extra, lens, codes, slot_size, fb_list, fb_count, fbflag); }
-		{ KernelTimer t(c, "xh_fallback_kernel"); launch_xh_fallback(st, d_in, p->bt, fb_list, fb_count, static_cast<uint8_t*>(c->fb_pool.p), XH_FB_BLOCKS, tokbits, lens, codes, slot_size); }
+		{ KernelTimer t(c, "xh_fallback_kernel"); launch_xh_fallback(st, d_in, p->bt, fb_list, fb_count, XH_FB_BLOCKS, tokbits, lens, codes, slot_size); }
 		{ KernelTimer t(c, "scan_sizes"); launch_scan_sizes(st, slot_size, prefix, p->n_chunks, tile_sums); }
 		{ KernelTimer t(c, "xh_encode_kernel"); launch_xh_encode(st, d_in, p->bt, mlen3, moff, tokbits, lens, codes, fbflag, prefix, d_out); }
 		{ KernelTimer t(c, "finalize_units_kernel"); launch_finalize_units(st, prefix, p->bt, d_out, d_out_len, d_status, 0); }

@@ -25,10 +25,9 @@ void launch_xh_parse(hipStream_t st, const uint8_t* d_in, const BatchTables& bt,
 void launch_xh_huff(hipStream_t st, const BatchTables& bt, const uint32_t* counts, const uint32_t* extra, uint8_t* lens, uint16_t* codes,
                     uint32_t* chunk_size, uint32_t* fb_list, uint32_t* fb_count, uint32_t* fbflag);
 void launch_xh_fallback(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint32_t* fb_list, const uint32_t* fb_count,
-                        uint8_t* pool, uint32_t pool_blocks, u64* tokbits, uint8_t* lens, uint16_t* codes, uint32_t* chunk_size);
+                        uint32_t blocks, u64* tokbits, uint8_t* lens, uint16_t* codes, uint32_t* chunk_size);
 void launch_xh_encode(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* mlen3, const uint16_t* moff,
                       const u64* tokbits, const uint8_t* lens, const uint16_t* codes, const uint32_t* fbflag, const u64* prefix, uint8_t* d_out);
-uint32_t xh_fallback_pool_bytes_per_block();
 
 // ---- utilities (util.hip) ----
 // prefix[0..n] = exclusive scan of sizes[0..n) as u64 (prefix[n] = total). block_sums: scratch of ceil(n/1024)+1 u64.

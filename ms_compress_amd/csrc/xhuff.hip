@@ -11,7 +11,7 @@
 //                      one lane in LDS, depths / size test (xh_calc_compressed_len :181-188) / canonical codes (:109-123)
 //                      by the whole wave; flags chunks that need the fallback (:274, :310).
 //   xh_fallback_kernel xh_compress_no_matching + CreateCodesSlow (:155-180, HuffmanEncoder.h:129-226): literals only,
-//                      package-merge lengths (packages = per-symbol multiplicity vectors in an HBM scratch pool).
+//                      package-merge lengths (packages = per-symbol multiplicity vectors in an LDS pool).
 //   xh_encode_kernel   xh_compress_encode + OutputBitstream (:195-245, Bitstream.h:111-148): every bit/byte position is
 //                      a prefix sum: a WriteBits call that raises flushes(T)=ceil(T/16)-1 to f allocates
 //                      the slot of word f+1 at 4+2(f-1)+R; raw length bytes sit at 4+2*flushes+R. Bits are OR-ed into a
@@ -22,6 +22,7 @@
 namespace msc {
 
 __device__ __forceinline__ uint32_t xh_incl_scan_add(uint32_t v) { return wave_incl_scan_add_u32(v); }
+__device__ __forceinline__ uint32_t xh_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t xh_wave_sum(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)xh_incl_scan_add(v), 63); }
 
 __device__ __forceinline__ uint32_t xh_ldg32(const uint8_t* __restrict__ d, u64 pos, u64 n)
@@ -337,29 +338,51 @@ __global__ __launch_bounds__(64) void xh_huff_kernel(BatchTables bt, const uint3
 // ===================================================================================================================
 // fallback: literals only + package-merge (CreateCodesSlow)
 // ===================================================================================================================
-// scratch per resident block: two generations of <=512 packages, each a 512-byte multiplicity vector -> 512 KiB
-#define XH_FB_POOL_BYTES (2u * 512u * 512u)
+// package pool in (dynamic) LDS: two generations of <= 256 packages, each a multiplicity vector over the 257
+// literal/EOS symbols (stride 264) -> 132 KiB beside the 24 KiB of static LDS
+#define XH_FB_STRIDE 264u
+#define XH_FB_GEN_BYTES (256u * XH_FB_STRIDE)
+#define XH_FB_POOL_BYTES (2u * XH_FB_GEN_BYTES)
 
+#ifdef XF_PROFILE
+__device__ unsigned long long g_fb_prof[8];
+extern "C" void mscomp_amd_debug_fb_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fb_prof), 64); unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fb_prof), z, 64); }
+#define FB_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); if (tid == 0) { atomicAdd(&g_fb_prof[i], t_ - fb_prev); } fb_prev = t_; }
+#else
+#define FB_T(i)
+#endif
 __global__ __launch_bounds__(512) void xh_fallback_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                          const uint32_t* __restrict__ fb_list, const uint32_t* __restrict__ fb_count,
-                                                         uint8_t* __restrict__ pool, u64* __restrict__ tokbits,
+                                                         u64* __restrict__ tokbits,
                                                          uint8_t* __restrict__ lens_out, uint16_t* __restrict__ codes_out, uint32_t* __restrict__ chunk_size)
 {
 	__shared__ HuffLds h;
 	__shared__ uint16_t s_leaf[512];
+	__shared__ uint32_t s_lcnt[512];                               // counts of the sorted leaves
+	__shared__ uint16_t s_item[1024];                              // merged sequence of a round: package index, or 0x8000 | leaf symbol
 	__shared__ u64 s_pc[2][512];                                   // package counts, two generations
 	__shared__ uint32_t s_n[4];
 	const uint32_t tid = threadIdx.x;
-	uint8_t* gen[2] = { pool + (u64)blockIdx.x * XH_FB_POOL_BYTES, pool + (u64)blockIdx.x * XH_FB_POOL_BYTES + 512u * 512u };
+	extern __shared__ __attribute__((aligned(16))) uint8_t fb_pool_lds[];
+	uint8_t* const gen0 = fb_pool_lds;                             // two generations
 	const uint32_t nfb = *fb_count;
 	for (uint32_t it = blockIdx.x; it < nfb; it += gridDim.x) {
 		const uint32_t lc = fb_list[it];
 		const ChunkGeom g = chunk_geom(bt, lc);
 		const uint8_t* __restrict__ d = d_in + bt.in_off[g.u] + g.cbase;
+#ifdef XF_PROFILE
+		unsigned long long fb_prev = __builtin_readcyclecounter(); if (tid == 0) { atomicAdd(&g_fb_prof[7], 1ull); }
+#endif
 		__syncthreads();
 		h.cnt[tid] = 0;
 		__syncthreads();
-		for (uint32_t i = tid; i < g.cn; i += 512u) { atomicAdd(&h.cnt[d[i]], 1u); }     // xh_compress_no_matching (:155-180)
+		for (uint32_t i0 = tid; i0 < g.cn; i0 += 512u * 16u) {                            // xh_compress_no_matching (:155-180)
+			uint32_t by[16];                                                              // 16 loads in flight per thread
+			#pragma unroll
+			for (int j = 0; j < 16; ++j) { const uint32_t i = i0 + (uint32_t)j * 512u; by[j] = d[i < g.cn ? i : g.cn - 1u]; }
+			#pragma unroll
+			for (int j = 0; j < 16; ++j) { if (i0 + (uint32_t)j * 512u < g.cn) { atomicAdd(&h.cnt[by[j]], 1u); } }
+		}
 		for (uint32_t w = tid; w < 1024u; w += 512u) {                                   // every position is a literal token
 			const uint32_t lo = w * 64u;
 			tokbits[(u64)lc * 1024u + w] = lo >= g.cn ? 0 : (g.cn - lo >= 64u ? ~(u64)0 : ((((u64)1) << (g.cn - lo)) - 1u));
@@ -367,6 +390,7 @@ __global__ __launch_bounds__(512) void xh_fallback_kernel(const uint8_t* __restr
 		__syncthreads();
 		if (tid == 0 && g.last) { h.cnt[0x100] += 1u; }
 		__syncthreads();
+		FB_T(0)
 		// present symbols, stable-sorted by count (ties: symbol order)  -- rank = #{(count, sym) smaller}
 		const uint32_t myc = h.cnt[tid];
 		h.lens[tid] = myc ? 15 : 0;
@@ -374,32 +398,67 @@ __global__ __launch_bounds__(512) void xh_fallback_kernel(const uint8_t* __restr
 		if (myc) { for (uint32_t s = 0; s < 512u; ++s) { const uint32_t c = h.cnt[s]; rank += (c != 0) && (c < myc || (c == myc && s < tid)); } }
 		if (tid == 0) { s_n[0] = 0; }
 		__syncthreads();
-		if (myc) { s_leaf[rank] = (uint16_t)tid; atomicAdd(&s_n[0], 1u); }
+		if (myc) { s_leaf[rank] = (uint16_t)tid; s_lcnt[rank] = myc; atomicAdd(&s_n[0], 1u); }
 		__syncthreads();
 		const uint32_t nleaf = s_n[0];
+		FB_T(1)
 		if (nleaf == 1) { if (myc) { h.lens[tid] = 1; } }
 		else {
+			// Package-merge, 15 rounds. A round merges the sorted leaves with the sorted packages of the previous round
+			// (a leaf goes first on equal counts) and pairs consecutive items. The merge is rank arithmetic -- every
+			// leaf and every package finds its place with one binary search, in parallel -- and the per-symbol
+			// multiplicity vectors of the new packages are then summed column-wise (thread s = symbol s) with
+			// independent, coalesced loads. (The serial two-finger merge this replaces was one dependent L2 round trip
+			// per item: 1.2 ms for a single chunk.)
 			uint32_t ncur = 0;
 			int mylen = myc ? 15 : 0;
 			for (uint32_t round = 0; round < 15u; ++round) {
-				uint8_t* cur = gen[round & 1u]; uint8_t* nxt = gen[(round & 1u) ^ 1u];
+				const uint8_t* cur = gen0 + (round & 1u) * XH_FB_GEN_BYTES;
+				uint8_t* nxt = gen0 + ((round & 1u) ^ 1u) * XH_FB_GEN_BYTES;
 				const u64* pc = s_pc[round & 1u]; u64* pn = s_pc[(round & 1u) ^ 1u];
-				uint32_t ci = 0, li = 0, nn = 0;
-				while ((ncur - ci) + (nleaf - li) > 1u) {             // every thread runs the same (uniform) merge decisions
-					u64 cnt = 0; uint32_t m = 0;
-					for (int e = 0; e < 2; ++e) {
-						if (li >= nleaf || (ci < ncur && pc[ci] < (u64)h.cnt[s_leaf[li]])) {     // strict: the leaf wins ties
-							cnt += pc[ci]; m += cur[(u64)ci * 512u + tid]; ++ci;
-						} else { const uint32_t lf = s_leaf[li]; cnt += h.cnt[lf]; m += (lf == tid); ++li; }
-					}
-					nxt[(u64)nn * 512u + tid] = (uint8_t)m;
-					if (tid == 0) { pn[nn] = cnt; }
-					++nn;
+				const uint32_t M = ncur + nleaf, nn = M >> 1;
+				if (tid < nleaf) {                                   // my leaf: after the packages that are strictly lighter
+					const u64 x = s_lcnt[tid];
+					uint32_t lo = 0, hi = ncur;
+					while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pc[mid] < x) { lo = mid + 1u; } else { hi = mid; } }
+					s_item[tid + lo] = (uint16_t)(0x8000u | s_leaf[tid]);
 				}
-				if (ci < ncur) { mylen -= cur[(u64)ci * 512u + tid]; }                    // the leftover item is dropped
-				else if (li < nleaf) { mylen -= (s_leaf[li] == tid); }
+				if (tid < ncur) {                                    // my package: after the leaves that are not heavier
+					const u64 x = pc[tid];
+					uint32_t lo = 0, hi = nleaf;
+					while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((u64)s_lcnt[mid] <= x) { lo = mid + 1u; } else { hi = mid; } }
+					s_item[tid + lo] = (uint16_t)tid;
+				}
+				__syncthreads();
+				FB_T(2)
+				if (tid < nn) {
+					const uint32_t a = s_item[2u * tid], b2 = s_item[2u * tid + 1u];
+					pn[tid] = ((a & 0x8000u) ? (u64)h.cnt[a & 0x7FFFu] : pc[a]) + ((b2 & 0x8000u) ? (u64)h.cnt[b2 & 0x7FFFu] : pc[b2]);
+				}
+				// multiplicity vectors of the new packages: wave w sums the packages k = w, w+8, ...; lane l owns the dword
+				// of symbols 4l..4l+3 (byte-wise sums, no carries: a multiplicity stays below 256) and lane 0 the EOS byte
+				{
+					const uint32_t wv = tid >> 6, lane = tid & 63u;
+					const uint32_t* cur32 = reinterpret_cast<const uint32_t*>(cur);
+					uint32_t* nxt32 = reinterpret_cast<uint32_t*>(nxt);
+					for (uint32_t k = wv; k < nn; k += 8u) {
+						const uint32_t a = xh_uniform(s_item[2u * k]), b2 = xh_uniform(s_item[2u * k + 1u]);
+						uint32_t va, vb, ea, eb;
+						if (a & 0x8000u) { const uint32_t sy = a & 0x7FFFu; va = (sy < 256u && lane == (sy >> 2)) ? 1u << ((sy & 3u) * 8u) : 0u; ea = (sy == 256u); }
+						else { va = cur32[a * (XH_FB_STRIDE / 4u) + lane]; ea = cur[a * XH_FB_STRIDE + 256u]; }
+						if (b2 & 0x8000u) { const uint32_t sy = b2 & 0x7FFFu; vb = (sy < 256u && lane == (sy >> 2)) ? 1u << ((sy & 3u) * 8u) : 0u; eb = (sy == 256u); }
+						else { vb = cur32[b2 * (XH_FB_STRIDE / 4u) + lane]; eb = cur[b2 * XH_FB_STRIDE + 256u]; }
+						nxt32[k * (XH_FB_STRIDE / 4u) + lane] = va + vb;
+						if (lane == 0) { nxt[k * XH_FB_STRIDE + 256u] = (uint8_t)(ea + eb); }
+					}
+				}
+				if ((M & 1u) && tid <= 0x100u) {                     // the leftover item is dropped
+					const uint32_t a = s_item[M - 1u];
+					mylen -= (a & 0x8000u) ? (int)((a & 0x7FFFu) == tid) : (int)cur[a * XH_FB_STRIDE + tid];
+				}
 				ncur = nn;
 				__syncthreads();
+				FB_T(3)
 			}
 			h.lens[tid] = (uint8_t)mylen;
 		}
@@ -415,6 +474,7 @@ __global__ __launch_bounds__(512) void xh_fallback_kernel(const uint8_t* __restr
 		if (tid < 64u) { huff_canonical(h, tid); }
 		__syncthreads();
 		if (tid < 64u) { huff_store(h, tid, lens_out + (u64)lc * 512u, codes_out + (u64)lc * 512u); }
+		FB_T(4)
 	}
 }
 
@@ -573,11 +633,13 @@ void launch_xh_huff(hipStream_t st, const BatchTables& bt, const uint32_t* count
 	hipLaunchKernelGGL(xh_huff_kernel, dim3(bt.n_chunks), dim3(64), 0, st, bt, counts, extra, lens, codes, chunk_size, fb_list, fb_count, fbflag);
 }
 void launch_xh_fallback(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint32_t* fb_list, const uint32_t* fb_count,
-                        uint8_t* pool, uint32_t pool_blocks, u64* tokbits, uint8_t* lens, uint16_t* codes, uint32_t* chunk_size)
+                        uint32_t blocks, u64* tokbits, uint8_t* lens, uint16_t* codes, uint32_t* chunk_size)
 {
 	if (bt.n_chunks == 0) { return; }
-	const uint32_t grid = bt.n_chunks < pool_blocks ? bt.n_chunks : pool_blocks;
-	hipLaunchKernelGGL(xh_fallback_kernel, dim3(grid), dim3(512), 0, st, d_in, bt, fb_list, fb_count, pool, tokbits, lens, codes, chunk_size);
+	const uint32_t grid = bt.n_chunks < blocks ? bt.n_chunks : blocks;
+	static bool attr_set = false;
+	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xh_fallback_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XH_FB_POOL_BYTES); attr_set = true; }
+	hipLaunchKernelGGL(xh_fallback_kernel, dim3(grid), dim3(512), XH_FB_POOL_BYTES, st, d_in, bt, fb_list, fb_count, tokbits, lens, codes, chunk_size);
 }
 void launch_xh_encode(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* mlen3, const uint16_t* moff,
                       const u64* tokbits, const uint8_t* lens, const uint16_t* codes, const uint32_t* fbflag, const u64* prefix, uint8_t* d_out)
@@ -585,6 +647,5 @@ void launch_xh_encode(hipStream_t st, const uint8_t* d_in, const BatchTables& bt
 	if (bt.n_chunks == 0) { return; }
 	hipLaunchKernelGGL(xh_encode_kernel, dim3(bt.n_chunks), dim3(64), 0, st, d_in, bt, mlen3, moff, tokbits, lens, codes, fbflag, prefix, d_out);
 }
-uint32_t xh_fallback_pool_bytes_per_block() { return XH_FB_POOL_BYTES; }
 
 } // namespace msc
