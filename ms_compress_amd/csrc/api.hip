@@ -306,6 +306,16 @@ MSCompStatus mscomp_amd_debug_xpress_matches(mscomp_amd_ctx* c, const uint8_t* d
 	return ok ? MSCOMP_OK : MSCOMP_ERRNO;
 }
 
+// Hardware self-check (see util.hip): lanes whose returning LDS atomic was NOT served in lane order, summed over
+// blocks x rounds x 64 lanes x {add, exchange}; 0 on gfx950. 0xFFFFFFFF = the check could not run.
+uint32_t mscomp_amd_debug_lds_lane_order(mscomp_amd_ctx* c, uint32_t seed, uint32_t blocks, uint32_t rounds, uint32_t nkeys)
+{
+	if (!c || nkeys == 0 || nkeys > 2048u) { return 0xFFFFFFFFu; }
+	DeviceGuard g(c->device);
+	if (!c->slot_size.reserve(64)) { return 0xFFFFFFFFu; }
+	return run_lds_lane_order_check(c->stream, seed, blocks, rounds, nkeys, static_cast<uint32_t*>(c->slot_size.p));
+}
+
 // ---- drop-in one-shot path (host pointers): H2D, one-unit batch on the GPU, D2H. No CPU encoder exists here. ----
 static MSCompStatus one_shot(MSCompFormat format, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len)
 {

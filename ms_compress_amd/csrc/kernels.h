@@ -36,6 +36,7 @@ void launch_scan_sizes(hipStream_t st, const uint32_t* sizes, u64* prefix, uint3
 void launch_concat_slots(hipStream_t st, const uint8_t* slots, uint32_t slot_stride, const uint32_t* slot_size,
                          const u64* prefix, const BatchTables& bt, uint8_t* d_out);
 // Per unit: out_len, status (OK / BUF_ERROR); LZNT1 also appends the uncounted 00 00 End_of_buffer when room.
+uint32_t run_lds_lane_order_check(hipStream_t st, uint32_t seed, uint32_t blocks, uint32_t rounds, uint32_t nkeys, uint32_t* d_bad);
 void launch_finalize_units(hipStream_t st, const u64* prefix, const BatchTables& bt, uint8_t* d_out,
                            u64* d_out_len, int32_t* d_status, int lznt1_eob);
 

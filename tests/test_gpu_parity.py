@@ -162,3 +162,12 @@ def test_unaligned_unit_offsets(oracle, gpu_ctx, fmt):
         exp = oracle.oracle_compress(f, u)[1]
         got = bytes(h_out[int(out_off[i]): int(out_off[i]) + int(h_len[i])])
         assert h_st[i] == 0 and got == exp, (fmt, i, len(u))
+
+
+@pytest.mark.parametrize("nkeys", [1, 2, 3, 7, 33, 257, 2048])
+def test_lds_atomics_are_served_in_lane_order(gpu_ctx, nkeys):
+    """The LZNT1 bucket sort (rank = value returned by the histogram atomic) and the Xpress chain links
+    (link = exchange(head[hash], position)) rely on gfx950 serving the same-address LDS atomics of ONE wave
+    instruction in lane order; the parity tests would catch a violation only indirectly (a tie decided differently)."""
+    bad = gpu_ctx.lib.mscomp_amd_debug_lds_lane_order(gpu_ctx._h, 1234 + nkeys, 512, 64, nkeys)
+    assert bad == 0, "%d lanes were served out of lane order" % bad
