@@ -225,9 +225,11 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 		for (uint32_t i = wlen + tid; i < WINDOW + XP_TILE + 64u; i += NT) { s_data[i] = 0; }
 		if (LINKW == WINDOW) {
 			const uint32_t npos = (uint32_t)((P0 + XP_TILE < cbase + cn ? P0 + XP_TILE : cbase + cn) - lwstart);
-			for (uint32_t r = tid; r < npos; r += NT) {
-				const u64 pos = lwstart + r;
-				s_links[r] = links[(u64)(bt.chunk_prefix[u] + (uint32_t)(pos >> 16)) * 65536u + (uint32_t)(pos & 65535u)];
+			// the link arrays of a unit's chunks are contiguous, lwstart is a multiple of 4096 and s_links is 16-byte
+			// aligned: 8 links per load (entries beyond npos are never read)
+			const uint16_t* __restrict__ lsrc = links + (u64)bt.chunk_prefix[u] * 65536u + lwstart;
+			for (uint32_t r = tid * 8u; r < npos; r += NT * 8u) {
+				*reinterpret_cast<uint4*>(s_links + r) = *reinterpret_cast<const uint4*>(lsrc + r);
 			}
 		}
 	}
