@@ -68,135 +68,215 @@ __device__ __forceinline__ ChunkGeom chunk_geom(const BatchTables& bt, uint32_t 
 // ===================================================================================================================
 // parse: tokens + histogram
 // ===================================================================================================================
-__global__ __launch_bounds__(64) void xh_parse_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
-                                                     uint16_t* __restrict__ mlen3, const uint16_t* __restrict__ moff,
-                                                     u64* __restrict__ tokbits, uint32_t* __restrict__ counts, uint32_t* __restrict__ extra)
+// One window of the greedy parse (xh_compress_lz77, xpress_huff_compress.cpp:60-126): positions [wbase, wbase+64) of the
+// chunk, entered at `cur`; off / L are this lane's candidate (0 = none; L = len-3 as capped by the finder). Writes the
+// window's token mask and the final lengths of the taken matches; returns the parse position after the window.
+__device__ __forceinline__ uint32_t xh_parse_window(const ChunkGeom& g, const uint8_t* __restrict__ d, uint32_t lane, uint32_t wbase,
+                                                    uint32_t cur, uint32_t off, uint32_t L, uint16_t* __restrict__ mlen3c, u64* __restrict__ tokc,
+                                                    u64& tokmask_out, uint32_t& L_out)
+{
+	const uint32_t wend = (wbase + 64u < g.cn) ? wbase + 64u : g.cn;
+	if (cur >= wend) { if (lane == 0) { tokc[wbase >> 6] = 0; } tokmask_out = 0; L_out = L; return cur; }      // window wholly covered by a match
+	const uint32_t o = wbase + lane;
+	const bool inr = o < g.cn;
+	if (!inr) { off = 0; }
+	const u64 mm = __ballot(inr && off != 0 && o >= cur);
+	// the serial loop only decides which candidates are TAKEN; the token mask is derived in parallel afterwards
+	u64 matchmask = 0;
+	const uint32_t entry = cur;
+	const uint32_t wn = wend - wbase;
+	// Every candidate lane clips its length to the chunk end (:93) and precomputes where the walk goes after taking it:
+	// the first candidate at or after its end (relative to the window; >= wn leaves the window). The scalar loop is
+	// then one v_readlane per taken match; candidates the finder capped at 48 are extended on demand.
+	const uint32_t remL = g.cn - o;                              // bytes left in the chunk (>= 3 for a candidate)
+	const bool cappedL = (L == 45u) && remL > 48u;
+	{ const uint32_t lc_ = (L + 3u < remL) ? L + 3u : remL; if (inr && off != 0) { L = lc_ - 3u; } }
+	const uint32_t nx = lane + L + 3u;
+	const u64 restl = nx < 64u ? mm >> nx : (u64)0;
+	const uint32_t J = nx >= wn ? nx : (restl ? nx + ctz64(restl) : wn);
+	u64 capm = sgpr64(__ballot(cappedL) & mm);
+	uint32_t mp;
+	{
+		const uint32_t rel = cur - wbase;
+		const u64 rest = mm >> rel;
+		mp = rest ? rel + ctz64(rest) : wn;
+	}
+	mp = (uint32_t)__builtin_amdgcn_readfirstlane((int)mp);
+	const uint32_t wn_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wn);
+	while (mp < wn_s) {
+		uint32_t st;
+		matchmask = sgpr64(matchmask);
+		// v_readlane needs 4 wait states after the write of its lane select (mp): on the loop edge the five scalar
+		// instructions in between provide them, on entry the s_nop does.
+		asm volatile(
+			"s_nop 3\n\t"
+			"1:\n\t"
+			"s_bitcmp1_b64 %[cap], %[mp]\n\t"
+			"s_cbranch_scc1 3f\n\t"
+			"s_bitset1_b64 %[mk], %[mp]\n\t"
+			"v_readlane_b32 %[mp], %[J], %[mp]\n\t"
+			"s_cmp_lt_u32 %[mp], %[wn]\n\t"
+			"s_cbranch_scc1 1b\n\t"
+			"s_mov_b32 %[st], 0\n\t"
+			"s_branch 4f\n\t"
+			"3:\n\t"
+			"s_mov_b32 %[st], 1\n\t"
+			"4:\n\t"
+			: [mp] "+s"(mp), [mk] "+s"(matchmask), [st] "=&s"(st)
+			: [cap] "s"(capm), [wn] "s"(wn_s), [J] "v"(J)
+			: "scc");
+		if (st == 0) { break; }
+		// capped by the finder: extend, at most to the chunk end
+		matchmask |= ((u64)1) << mp;
+		capm &= ~(((u64)1) << mp);
+		const uint32_t rem = g.cn - (wbase + mp);
+		const u64 P = g.cbase + wbase + mp;
+		const u64 X = P - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
+		const u64 lim = g.n - P - 1u;                              // never count the buffer's final byte
+		const uint32_t maxadd = (uint32_t)((lim < rem ? lim : rem) - 48u);
+		uint32_t len = 48u + xh_extend(d, X + 48u, P + 48u, maxadd, g.n, lane);
+		if (len > rem) { len = rem; }                              // :93
+		if (lane == mp) { L = len - 3u; }
+		const uint32_t nxs = mp + len;
+		if (nxs >= wn_s) { mp = nxs; }
+		else { const u64 rest = mm >> nxs; mp = rest ? nxs + ctz64(rest) : wn_s; }
+	}
+	const bool is_m = (matchmask >> lane) & (u64)1;
+	const uint32_t mend = is_m ? lane + L + 3u : 0u;              // match end, relative to the window
+	const uint32_t reach = wave_incl_scan_max(mend);
+	const bool is_tok = o >= entry && inr && (is_m || reach <= lane);
+	const u64 tokmask = __ballot(is_tok);
+	if (is_m) { mlen3c[o] = (uint16_t)L; }
+	if (lane == 0) { tokc[wbase >> 6] = tokmask; }
+	tokmask_out = tokmask; L_out = L;
+	return wbase + mp;
+}
+
+// Adds (sign = +1) or removes (sign = -1) the tokens of one window from the symbol histogram and the raw-length-byte
+// count. off / L / byte: this lane's position (L = final length - 3 when the position is a match token).
+__device__ __forceinline__ int xh_count_window(u64 tokmask, uint32_t lane, uint32_t off, uint32_t L, uint32_t byte, uint32_t* s_cnt, uint32_t sign)
+{
+	int raw = 0;
+	if ((tokmask >> lane) & (u64)1) {
+		uint32_t sym = byte;
+		if (off != 0) {
+			const uint32_t ob = 31u - (uint32_t)__builtin_clz(off);
+			sym = 0x100u | (ob << 4) | (L < 15u ? L : 15u);
+			raw = L >= 270u ? 3 : (L >= 15u ? 1 : 0);
+		}
+		atomicAdd(&s_cnt[sym], sign);
+	}
+	return raw;
+}
+
+// Four waves per 64 KiB chunk. The parse is a serial walk whose only state is the position of the next token, so:
+//   1. wave j parses the windows [256 j, 256 j + 256) SPECULATIVELY, as if a token started exactly at the first position of
+//      its segment (wave 0's segment is exact), and records the parse position after every window;
+//   2. wave 0 repairs the seams in order: it re-parses segment j from the true entry position until the position after
+//      a window equals the recorded speculative one -- from there on both parses are identical (typically after one or
+//      two windows; a segment that never re-synchronises is simply parsed again, serially);
+//      The histogram and the raw-length-byte count are accumulated while parsing; a repaired window first takes its
+//      speculative tokens back.
+// A taken match's final length depends only on its position (chunk clipping, extension), so speculative writes of
+// mlen3 are consistent with the final parse.
+#define XH_SEGW 256u
+#ifdef XP_PROFILE
+__device__ unsigned long long g_xp_prof[8];
+extern "C" void mscomp_amd_debug_xp_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xp_prof), 64); unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xp_prof), z, 64); }
+#define XP_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); if (tid == 0) { atomicAdd(&g_xp_prof[i], t_ - xp_prev); atomicMax(&g_xp_prof[4 + (i)], t_ - xp_prev); } xp_prev = t_; }
+#else
+#define XP_T(i)
+#endif
+__global__ __launch_bounds__(256) void xh_parse_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
+                                                      uint16_t* __restrict__ mlen3, const uint16_t* __restrict__ moff,
+                                                      u64* __restrict__ tokbits, uint32_t* __restrict__ counts, uint32_t* __restrict__ extra)
 {
 	__shared__ uint32_t s_cnt[512];
-	const uint32_t lane = threadIdx.x;
+	__shared__ uint32_t s_end[1024];                               // parse position after every window
+	__shared__ uint32_t s_xtra[4];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = xh_uniform(tid >> 6);
 	const uint32_t lc = blockIdx.x;
 	const ChunkGeom g = chunk_geom(bt, lc);
 	const uint8_t* __restrict__ d = d_in + bt.in_off[g.u];
 	const u64 gbase = (u64)lc * 65536u;
-	for (uint32_t i = lane; i < 512u; i += 64u) { s_cnt[i] = 0; }
-	__syncthreads();
+	uint16_t* __restrict__ mlen3c = mlen3 + gbase;
+	const uint16_t* __restrict__ moffc = moff + gbase;
+	u64* __restrict__ tokc = tokbits + (u64)lc * 1024u;
+	for (uint32_t i = tid; i < 512u; i += 256u) { s_cnt[i] = 0; }
+	const uint32_t nwin = (g.cn + 63u) >> 6;
+#ifdef XP_PROFILE
+	unsigned long long xp_prev = __builtin_readcyclecounter();
+#endif
 
-	// Inputs are burst-loaded 8 windows (512 positions) at a time into a double-buffered LDS stage (one wait on global
-	// memory per 512 positions; unconditional loads with a clamped index).
-	__shared__ uint16_t s_in_off[2][512];
-	__shared__ uint16_t s_in_len[2][512];
-	__shared__ uint8_t  s_in_byte[2][512];
-	uint32_t g_off[8], g_len[8], g_byte[8];
-#define XP_BURST_LOAD(gb) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { \
+	// ---- 1. speculative parse of my segment. Inputs are burst-loaded 4 windows (256 positions) at a time into a
+	// double-buffered LDS stage (one wait on global memory per 256 positions; unconditional loads, clamped index).
+	__shared__ uint16_t s_in_off[4][2][256];
+	__shared__ uint16_t s_in_len[4][2][256];
+	__shared__ uint8_t  s_in_byte[4][2][256];
+	uint32_t g_off[4], g_len[4], g_byte[4];
+	int xtra = 0;                                                  // raw length bytes of my tokens (per lane, reduced at the end)
+#define XP_BURST_LOAD(gb) { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
 		const uint32_t q_ = (gb) + (uint32_t)k_ * 64u + lane; const uint32_t c_ = q_ < g.cn ? q_ : g.cn - 1u; \
-		g_off[k_] = moff[gbase + c_]; g_len[k_] = mlen3[gbase + c_]; g_byte[k_] = d[g.cbase + c_]; } }
-#define XP_BURST_STORE(buf) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { \
-		s_in_off[buf][k_ * 64 + lane] = (uint16_t)g_off[k_]; s_in_len[buf][k_ * 64 + lane] = (uint16_t)g_len[k_]; s_in_byte[buf][k_ * 64 + lane] = (uint8_t)g_byte[k_]; } }
-	XP_BURST_LOAD(0u)
-
-	uint32_t cur = 0, xtra = 0;                                  // next token start (offset in chunk), sum of raw length bytes
-	for (uint32_t wbase = 0; wbase < g.cn; wbase += 64u) {
-		const uint32_t wi = (wbase >> 6) & 7u, buf = (wbase >> 9) & 1u;
-		if (wi == 0) {
-			XP_BURST_STORE(buf)
-			if (wbase + 512u < g.cn) { XP_BURST_LOAD(wbase + 512u) }
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
-		}
-		const uint32_t wend = (wbase + 64u < g.cn) ? wbase + 64u : g.cn;
-		if (cur >= wend) { if (lane == 0) { tokbits[(u64)lc * 1024u + (wbase >> 6)] = 0; } continue; }
-		const uint32_t o = wbase + lane;
-		const bool inr = o < g.cn;
-		const uint32_t off = inr ? (uint32_t)s_in_off[buf][wi * 64u + lane] : 0u;
-		uint32_t L = s_in_len[buf][wi * 64u + lane];
-		const uint32_t byte = s_in_byte[buf][wi * 64u + lane];
-		const u64 mm = __ballot(inr && off != 0 && o >= cur);
-		// the serial loop only decides which candidates are TAKEN; the token mask is derived in parallel afterwards
-		u64 matchmask = 0;
-		const uint32_t entry = cur;
-		const uint32_t wn = wend - wbase;
-		// Every candidate lane clips its length to the chunk end (:93) and precomputes where the walk goes after taking it:
-		// the first candidate at or after its end (relative to the window; >= wn leaves the window). The scalar loop is
-		// then one v_readlane per taken match; candidates the finder capped at 48 are extended on demand.
-		const uint32_t remL = g.cn - o;                            // bytes left in the chunk (>= 3 for a candidate)
-		const bool cappedL = (L == 45u) && remL > 48u;
-		{ const uint32_t lc_ = (L + 3u < remL) ? L + 3u : remL; if (inr && off != 0) { L = lc_ - 3u; } }
-		const uint32_t nx = lane + L + 3u;
-		const u64 restl = nx < 64u ? mm >> nx : (u64)0;
-		const uint32_t J = nx >= wn ? nx : (restl ? nx + ctz64(restl) : wn);
-		u64 capm = sgpr64(__ballot(cappedL) & mm);
-		uint32_t mp;
-		{
-			const uint32_t rel = cur - wbase;
-			const u64 rest = mm >> rel;
-			mp = rest ? rel + ctz64(rest) : wn;
-		}
-		mp = (uint32_t)__builtin_amdgcn_readfirstlane((int)mp);
-		const uint32_t wn_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wn);
-		while (mp < wn_s) {
-			uint32_t st;
-			matchmask = sgpr64(matchmask);
-			// v_readlane needs 4 wait states after the write of its lane select (mp): on the loop edge the five scalar
-			// instructions in between provide them, on entry the s_nop does.
-			asm volatile(
-				"s_nop 3\n\t"
-				"1:\n\t"
-				"s_bitcmp1_b64 %[cap], %[mp]\n\t"
-				"s_cbranch_scc1 3f\n\t"
-				"s_bitset1_b64 %[mk], %[mp]\n\t"
-				"v_readlane_b32 %[mp], %[J], %[mp]\n\t"
-				"s_cmp_lt_u32 %[mp], %[wn]\n\t"
-				"s_cbranch_scc1 1b\n\t"
-				"s_mov_b32 %[st], 0\n\t"
-				"s_branch 4f\n\t"
-				"3:\n\t"
-				"s_mov_b32 %[st], 1\n\t"
-				"4:\n\t"
-				: [mp] "+s"(mp), [mk] "+s"(matchmask), [st] "=&s"(st)
-				: [cap] "s"(capm), [wn] "s"(wn_s), [J] "v"(J)
-				: "scc");
-			if (st == 0) { break; }
-			// capped by the finder: extend, at most to the chunk end
-			matchmask |= ((u64)1) << mp;
-			capm &= ~(((u64)1) << mp);
-			const uint32_t rem = g.cn - (wbase + mp);
-			const u64 P = g.cbase + wbase + mp;
-			const u64 X = P - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
-			const u64 lim = g.n - P - 1u;                          // never count the buffer's final byte
-			const uint32_t maxadd = (uint32_t)((lim < rem ? lim : rem) - 48u);
-			uint32_t len = 48u + xh_extend(d, X + 48u, P + 48u, maxadd, g.n, lane);
-			if (len > rem) { len = rem; }                          // :93
-			if (lane == mp) { L = len - 3u; }
-			const uint32_t nxs = mp + len;
-			if (nxs >= wn_s) { mp = nxs; }
-			else { const u64 rest = mm >> nxs; mp = rest ? nxs + ctz64(rest) : wn_s; }
-		}
-		cur = wbase + mp;
-		const bool is_m = (matchmask >> lane) & (u64)1;
-		const uint32_t mend = is_m ? lane + L + 3u : 0u;          // match end, relative to the window
-		const uint32_t reach = wave_incl_scan_max(mend);
-		const bool is_tok = o >= entry && inr && (is_m || reach <= lane);
-		const u64 tokmask = __ballot(is_tok);
-		if (is_m) { mlen3[gbase + o] = (uint16_t)L; }
-		if (lane == 0) { tokbits[(u64)lc * 1024u + (wbase >> 6)] = tokmask; }
-		uint32_t raw = 0;
-		if (is_tok) {
-			uint32_t sym = byte;
-			if (is_m) {
-				const uint32_t ob = 31u - (uint32_t)__builtin_clz(off);
-				sym = 0x100u | (ob << 4) | (L < 15u ? L : 15u);
-				raw = L >= 270u ? 3u : (L >= 15u ? 1u : 0u);
+		g_off[k_] = moffc[c_]; g_len[k_] = mlen3c[c_]; g_byte[k_] = d[g.cbase + c_]; } }
+#define XP_BURST_STORE(buf) { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
+		s_in_off[wv][buf][k_ * 64 + lane] = (uint16_t)g_off[k_]; s_in_len[wv][buf][k_ * 64 + lane] = (uint16_t)g_len[k_]; s_in_byte[wv][buf][k_ * 64 + lane] = (uint8_t)g_byte[k_]; } }
+	{
+		const uint32_t w0 = wv * XH_SEGW, w1 = (w0 + XH_SEGW < nwin) ? w0 + XH_SEGW : nwin;
+		uint32_t cur = w0 * 64u;
+		if (w0 < w1) { XP_BURST_LOAD(w0 * 64u) }
+		for (uint32_t w = w0; w < w1; ++w) {
+			const uint32_t wi = (w - w0) & 3u, buf = ((w - w0) >> 2) & 1u;
+			if (wi == 0) {
+				XP_BURST_STORE(buf)
+				if (w + 4u < w1) { XP_BURST_LOAD((w + 4u) * 64u) }
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
 			}
-			atomicAdd(&s_cnt[sym], 1u);
+			const uint32_t off = s_in_off[wv][buf][wi * 64u + lane];
+			u64 tm; uint32_t Lf;
+			cur = xh_parse_window(g, d, lane, w * 64u, cur, off, s_in_len[wv][buf][wi * 64u + lane], mlen3c, tokc, tm, Lf);
+			if (lane == 0) { s_end[w] = cur; }
+			xtra += xh_count_window(tm, lane, off, Lf, s_in_byte[wv][buf][wi * 64u + lane], s_cnt, 1u);
 		}
-		xtra += raw;                                              // per-lane partial sums, reduced once at the end
 	}
-	xtra = xh_wave_sum(xtra);
+#undef XP_BURST_LOAD
+#undef XP_BURST_STORE
 	__syncthreads();
-	if (g.last && lane == 0) { s_cnt[0x100] += 1u; }               // EOS (:127-144)
+	XP_T(0)
+	// ---- 2. repair the seams (wave 0) ------------------------------------------------------------------------------
+	if (wv == 0) {
+		for (uint32_t j = 1; j * XH_SEGW < nwin; ++j) {
+			const uint32_t w0 = j * XH_SEGW, w1 = (w0 + XH_SEGW < nwin) ? w0 + XH_SEGW : nwin;
+			uint32_t cur = xh_uniform(s_end[w0 - 1u]);                 // true entry of segment j
+			if (cur == w0 * 64u) { continue; }                         // the speculation was right
+			for (uint32_t w = w0; w < w1; ++w) {
+				const uint32_t q = w * 64u + lane, c = q < g.cn ? q : g.cn - 1u;
+				// (a length already finalised by the speculative pass is a fixed point of the clipping / extension)
+				// (written by another wave a moment ago: read past this CU's L1)
+				const u64 old_tm = __hip_atomic_load(&tokc[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const uint32_t off = moffc[c], Lold = __hip_atomic_load(&mlen3c[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), byte = d[g.cbase + c];
+				xtra -= xh_count_window(old_tm, lane, off, Lold, byte, s_cnt, 0xFFFFFFFFu);      // take the speculative tokens back
+				u64 tm; uint32_t Lf;
+				cur = xh_parse_window(g, d, lane, w * 64u, cur, off, Lold, mlen3c, tokc, tm, Lf);
+				xtra += xh_count_window(tm, lane, off, Lf, byte, s_cnt, 1u);
+				const uint32_t spec = xh_uniform(s_end[w]);
+				if (lane == 0) { s_end[w] = cur; }
+				if (cur == spec) { break; }                               // re-synchronised: the rest of the segment stands
+			}
+		}
+	}
 	__syncthreads();
-	for (uint32_t i = lane; i < 512u; i += 64u) { counts[(u64)lc * 512u + i] = s_cnt[i]; }
-	if (lane == 0) { extra[lc] = xtra; }
+	XP_T(1)
+	// ---- 3. reduce ------------------------------------------------------------------------------------------------
+	const uint32_t xsum = xh_wave_sum((uint32_t)xtra);              // (two's complement: the corrections of wave 0 may be negative)
+	if (lane == 0) { s_xtra[wv] = xsum; }
+	__syncthreads();
+	if (g.last && tid == 0) { s_cnt[0x100] += 1u; }                // EOS (:127-144)
+	__syncthreads();
+	for (uint32_t i = tid; i < 512u; i += 256u) { counts[(u64)lc * 512u + i] = s_cnt[i]; }
+	if (tid == 0) { extra[lc] = s_xtra[0] + s_xtra[1] + s_xtra[2] + s_xtra[3]; }
+	XP_T(2)
 }
+
 
 // ===================================================================================================================
 // Huffman lengths (heap), size, canonical codes
@@ -623,7 +703,7 @@ void launch_xh_parse(hipStream_t st, const uint8_t* d_in, const BatchTables& bt,
                      u64* tokbits, uint32_t* counts, uint32_t* extra)
 {
 	if (bt.n_chunks == 0) { return; }
-	hipLaunchKernelGGL(xh_parse_kernel, dim3(bt.n_chunks), dim3(64), 0, st, d_in, bt, mlen3, moff, tokbits, counts, extra);
+	hipLaunchKernelGGL(xh_parse_kernel, dim3(bt.n_chunks), dim3(256), 0, st, d_in, bt, mlen3, moff, tokbits, counts, extra);
 }
 void launch_xh_huff(hipStream_t st, const BatchTables& bt, const uint32_t* counts, const uint32_t* extra, uint8_t* lens, uint16_t* codes,
                     uint32_t* chunk_size, uint32_t* fb_list, uint32_t* fb_count, uint32_t* fbflag)
