@@ -39,6 +39,7 @@ struct mscomp_amd_ctx {
 	hipStream_t stream = nullptr;
 	DevBuf slots, slot_size, prefix, tile_sums;        // chunk scratch (grow-only, shared by all plans of the ctx)
 	DevBuf links, lasthead, mlen3, moff;               // Xpress-family match finder scratch (per 64 KiB link chunk)
+	DevBuf wtok, wmat, wfar;                           // Xpress parse records per 64-position window (token mask, match mask, far length)
 	DevBuf tokbits, counts, extra, lens, codes, fb_list, fbflag;   // Xpress+Huffman per-chunk scratch
 	DevBuf one_in, one_out, one_meta;                  // staging of the host-pointer one-shot path
 	bool profiling = false;
@@ -129,6 +130,7 @@ void mscomp_amd_ctx_destroy(mscomp_amd_ctx* c)
 	c->slots.release(); c->slot_size.release(); c->prefix.release(); c->tile_sums.release();
 	c->one_in.release(); c->one_out.release(); c->one_meta.release();
 	c->links.release(); c->lasthead.release(); c->mlen3.release(); c->moff.release();
+	c->wtok.release(); c->wmat.release(); c->wfar.release();
 	c->tokbits.release(); c->counts.release(); c->extra.release(); c->lens.release(); c->codes.release();
 	c->fb_list.release(); c->fbflag.release();
 	delete c;
@@ -199,6 +201,10 @@ MSCompStatus mscomp_amd_plan_create(mscomp_amd_ctx* c, MSCompFormat format, size
 	if (ok && format != MSCOMP_LZNT1) {
 		const size_t per = (size_t)p->n_chunks * 65536u * sizeof(uint16_t) + 64;
 		ok = c->links.reserve(per) && c->mlen3.reserve(per) && c->moff.reserve(per) && c->lasthead.reserve(per / 2 + 64);
+		if (ok && format == MSCOMP_XPRESS) {
+			const size_t nw = (size_t)p->n_chunks * 1024u + 64;
+			ok = c->wtok.reserve(nw * 8) && c->wmat.reserve(nw * 8) && c->wfar.reserve(nw * 4);
+		}
 	}
 	if (ok && format == MSCOMP_XPRESS_HUFF) {
 		const size_t nc = (size_t)p->n_chunks + 1;
@@ -243,7 +249,7 @@ MSCompStatus mscomp_amd_plan_execute(mscomp_amd_plan* p, const uint8_t* d_in, ui
 		uint16_t* mlen3 = static_cast<uint16_t*>(c->mlen3.p); uint16_t* moff = static_cast<uint16_t*>(c->moff.p);
 		{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
 		{ KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0x2000u, 0); }
-		{ KernelTimer t(c, "xpress_emit_kernel"); launch_xpress_emit(st, d_in, p->bt, mlen3, moff, d_out, d_out_len, d_status); }
+		{ KernelTimer t(c, "xpress_emit_kernel"); launch_xpress_emit(st, d_in, p->bt, mlen3, moff, static_cast<u64*>(c->wtok.p), static_cast<u64*>(c->wmat.p), static_cast<uint32_t*>(c->wfar.p), d_out, d_out_len, d_status); }
 		break;
 	}
 	case MSCOMP_XPRESS_HUFF: {
@@ -305,6 +311,9 @@ MSCompStatus mscomp_amd_debug_xpress_matches(mscomp_amd_ctx* c, const uint8_t* d
 	mscomp_amd_plan_destroy(p);
 	return ok ? MSCOMP_OK : MSCOMP_ERRNO;
 }
+
+// Test hook: which Xpress parse/emit kernel runs (0 = chosen by batch size, 1 = one wave per unit, 2 = four waves per unit).
+void mscomp_amd_debug_set_xpress_emit(int mode) { set_xpress_emit_mode(mode); }
 
 // Hardware self-check (see util.hip): lanes whose returning LDS atomic was NOT served in lane order, summed over
 // blocks x rounds x 64 lanes x {add, exchange}; 0 on gfx950. 0xFFFFFFFF = the check could not run.

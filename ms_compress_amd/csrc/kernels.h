@@ -16,8 +16,9 @@ void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, 
                     uint16_t* mlen3, uint16_t* moff, uint32_t max_off, int clip);
 
 // ---- Xpress stream emission (xpress_emit.hip): one wavefront per unit ----
-void launch_xpress_emit(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* mlen3, const uint16_t* moff,
-                        uint8_t* d_out, u64* d_out_len, int32_t* d_status);
+void set_xpress_emit_mode(int mode);
+void launch_xpress_emit(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* mlen3, const uint16_t* moff,
+                        u64* wtok, u64* wmat, uint32_t* wfar, uint8_t* d_out, u64* d_out_len, int32_t* d_status);
 
 // ---- Xpress+Huffman chunk pipeline (xhuff.hip) ----
 void launch_xh_parse(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* mlen3, const uint16_t* moff,

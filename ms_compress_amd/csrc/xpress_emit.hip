@@ -318,11 +318,428 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 	}
 }
 
-void launch_xpress_emit(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* mlen3, const uint16_t* moff,
-                        uint8_t* d_out, u64* d_out_len, int32_t* d_status)
+// ===================================================================================================================
+// NW = 4 or 16 waves per unit (version 2 of the kernel above; same bytes)
+// ===================================================================================================================
+// The greedy walk is serial, but its state is small -- the position of the next token and the lazy-Fill boundary -- and
+// it re-synchronises within a window or two wherever it is started. Per "super-block" of 1024 windows (64 KiB):
+//   1. wave j walks its segment of 1024 / NW windows SPECULATIVELY, as if a token started at the first position of its
+//      segment with the Fill boundary not lagging (wave 0 continues the true state); every window leaves its token mask,
+//      match mask, lengths, byte counts and the state after it;
+//   2. wave 0 repairs the seams in order: it re-walks a segment from the true entry state until the state after a
+//      window equals the recorded speculative one;
+//   3. wave 0 scans the windows: tokens, long matches (their rank parity decides who owns a length nibble) and bytes
+//      before every window;
+//   4. wave j EMITS its segment (every window knows its output position); what couples it to its neighbours -- the
+//      flag word in progress at its first token, the half-filled nibble byte of the previous long match -- is not
+//      written but recorded;
+//   5. wave 0 stitches the seams: the shared flag words and nibble bytes.
+// A unit longer than 64 KiB runs its super-blocks one after the other (the state is carried), each four waves wide.
+
+// One window of the walk (xpress_compress.cpp:262-345 without the emission). In: the state (cur, F), this lane's
+// candidate (off, L = len-3 as capped by the finder, or a length this function produced earlier: it is a fixed point).
+// Out: the new state, the final L of the lanes whose match is taken, the token and match masks.
+__device__ __forceinline__ void xe_walk_window(const uint8_t* __restrict__ d, u64 n, u64 end2, uint32_t lane, u64 wbase,
+                                               u64& cur, u64& F, uint32_t off, uint32_t& L, u64& tokmask, u64& matchmask)
+{
+	const u64 wend = (wbase + 64u < n) ? wbase + 64u : n;
+	tokmask = 0; matchmask = 0;
+	if (cur >= wend) { return; }                                  // window wholly covered by a match
+	const u64 p = wbase + lane;
+	const bool inr = p < n;
+	if (!inr) { off = 0; }
+	const u64 mm = __ballot(inr && off != 0 && p >= cur);
+	const u64 cur_entry = cur;
+	const uint32_t wn = (uint32_t)(wend - wbase);
+	if (F > wend || wbase >= end2) {
+		// fast path: the lazy-Fill rule cannot fire in this window. Jump table + scalar loop as in the kernel above.
+		const uint32_t nx = lane + L + 3u;
+		const u64 restl = nx < 64u ? mm >> nx : (u64)0;
+		const uint32_t J = nx >= wn ? nx : (restl ? nx + ctz64(restl) : wn);
+		u64 capm = sgpr64(__ballot(L == 45u) & mm);
+		uint32_t mp;
+		{
+			const uint32_t rel = (uint32_t)(cur - wbase);
+			const u64 rest = mm >> rel;
+			mp = rest ? rel + ctz64(rest) : wn;
+		}
+		mp = (uint32_t)__builtin_amdgcn_readfirstlane((int)mp);
+		const uint32_t wn_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wn);
+		bool far = false;
+		while (mp < wn_s) {
+			uint32_t st;
+			matchmask = sgpr64(matchmask); mp = (uint32_t)__builtin_amdgcn_readfirstlane((int)mp);   // (uniform; tell the compiler)
+			asm volatile(
+				"s_nop 3\n\t"
+				"1:\n\t"
+				"s_bitcmp1_b64 %[cap], %[mp]\n\t"
+				"s_cbranch_scc1 3f\n\t"
+				"s_bitset1_b64 %[mk], %[mp]\n\t"
+				"v_readlane_b32 %[mp], %[J], %[mp]\n\t"
+				"s_cmp_lt_u32 %[mp], %[wn]\n\t"
+				"s_cbranch_scc1 1b\n\t"
+				"s_mov_b32 %[st], 0\n\t"
+				"s_branch 4f\n\t"
+				"3:\n\t"
+				"s_mov_b32 %[st], 1\n\t"
+				"4:\n\t"
+				: [mp] "+s"(mp), [mk] "+s"(matchmask), [st] "=&s"(st)
+				: [cap] "s"(sgpr64(capm)), [wn] "s"(wn_s), [J] "v"(J)
+				: "scc");
+			if (st == 0) { break; }
+			matchmask |= ((u64)1) << mp;
+			capm &= ~(((u64)1) << mp);
+			const u64 pm = wbase + mp;
+			const u64 x = pm - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
+			const u64 ext = 45u + wave_extend(d, x + 48u, pm + 48u, n - pm - 1u - 48u, n, lane);
+			if (lane == mp) { L = (uint32_t)ext; }
+			if (ext > 0x10000u) { cur = pm + ext + 3u; far = true; break; }
+			const uint32_t nxs = mp + (uint32_t)ext + 3u;
+			if (nxs >= wn_s) { mp = nxs; }
+			else { const u64 rest = mm >> nxs; mp = rest ? nxs + ctz64(rest) : wn_s; }
+		}
+		if (!far) { cur = wbase + mp; }
+	} else
+	while (cur < wend) {                                          // exact loop with the ONE-lazy-Fill-per-token rule (:269)
+		if (cur < end2) {
+			if (F <= cur) { F = (F + 0x2000u < end2) ? F + 0x2000u : end2; }
+			if (cur >= F) { ++cur; continue; }                      // lagging fill => literal
+		}
+		const uint32_t rel = (uint32_t)(cur - wbase);
+		const u64 rest = (mm >> rel);
+		if (rest == 0) {
+			const u64 lastp = (wend - 1u < end2) ? wend - 1u : end2;
+			if (end2 && F <= lastp && lastp < end2) { F = (F + 0x2000u < end2) ? F + 0x2000u : end2; }
+			cur = wend;
+			break;
+		}
+		const uint32_t mp = rel + ctz64(rest);
+		const u64 pm = wbase + mp;
+		if (F <= pm) { F = (F + 0x2000u < end2) ? F + 0x2000u : end2; }
+		matchmask |= ((u64)1) << mp;
+		u64 Lm = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)mp);
+		if (Lm == 45u) {
+			const u64 x = pm - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
+			const u64 lim = n - pm - 1u;
+			Lm = 45u + wave_extend(d, x + 48u, pm + 48u, lim - 48u, n, lane);
+			if (lane == mp) { L = (uint32_t)Lm; }
+		}
+		cur = pm + Lm + 3u;
+	}
+	const bool is_m = (matchmask >> lane) & (u64)1;
+	const uint32_t mend = is_m ? (L < 0xFFFFFFu ? lane + L + 3u : 0xFFFFFFFFu) : 0u;
+	const uint32_t reach = wave_incl_scan_max_u32(mend);
+	const bool is_tok = p >= cur_entry && inr && (is_m || reach <= lane);
+	tokmask = __ballot(is_tok);
+}
+
+// state after a window, as stored for the seam repair: position relative to the window (saturating) and the index of
+// the Fill boundary (a multiple of 0x2000, or the end of the unit)
+__device__ __forceinline__ uint32_t xe_pack_cur(u64 cur, u64 wbase) { const u64 r = cur - wbase; return r < 0xFFFFFFFFull ? (uint32_t)r : 0xFFFFFFFFu; }
+__device__ __forceinline__ uint32_t xe_pack_F(u64 F, u64 end2) { return F == end2 ? 0xFFFFFFFFu : (uint32_t)(F >> 13); }
+
+// record a walked window: final lengths (u16, 0xFFFF = see the window's far length), masks, byte counts, state after it
+__device__ __forceinline__ void xe_store_window(uint32_t lane, u64 wbase, u64 n, u64 gw, uint32_t w, uint32_t off, uint32_t L, u64 tm, u64 mk,
+                                                u64 cur, u64 F, u64 end2, uint16_t* __restrict__ mlen3u, u64* __restrict__ wtoku, u64* __restrict__ wmatu,
+                                                uint32_t* __restrict__ wfaru, uint32_t* s_ecur, uint32_t* s_eF, uint32_t* s_sum)
+{
+	const bool is_m = (mk >> lane) & (u64)1;
+	if (is_m) { mlen3u[wbase + lane] = (uint16_t)(L < 0xFFFFu ? L : 0xFFFFu); if (L >= 0xFFFFu) { wfaru[gw] = L; } }
+	const uint32_t nm = (uint32_t)__popcll(mk), nt = (uint32_t)__popcll(tm);
+	const uint32_t nl = (uint32_t)__popcll(__ballot(is_m && L >= 7u));
+	const uint32_t n22 = (uint32_t)__popcll(__ballot(is_m && L >= 22u)), n277 = (uint32_t)__popcll(__ballot(is_m && L >= 277u));
+	const uint32_t nfar = (uint32_t)__popcll(__ballot(is_m && L > 0xFFFFu));
+	const uint32_t fsz = (nt - nm) + 2u * nm + n22 + 2u * n277 + 4u * nfar;
+	if (lane == 0) {
+		wtoku[gw] = tm; wmatu[gw] = mk;
+		s_ecur[w] = xe_pack_cur(cur, wbase); s_eF[w] = xe_pack_F(F, end2); s_sum[w] = nt | (nl << 8) | (fsz << 16);
+	}
+}
+
+#ifdef XE2_PROFILE
+__device__ unsigned long long g_xe2_prof[16];
+extern "C" void mscomp_amd_debug_xe2_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xe2_prof), 128); unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xe2_prof), z, 128); }
+#define XE2_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); if (tid == 0) { atomicAdd(&g_xe2_prof[i], t_ - x2_prev); atomicMax(&g_xe2_prof[8 + (i)], t_ - x2_prev); } x2_prev = t_; }
+#else
+#define XE2_T(i)
+#endif
+template <uint32_t NW>                                         // waves per unit: 4 or 16 (segments of 1024 / NW windows)
+__global__ __launch_bounds__(NW * 64u) void xpress_emit2_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
+                                                          uint16_t* __restrict__ mlen3, const uint16_t* __restrict__ moff,
+                                                          u64* __restrict__ wtok, u64* __restrict__ wmat, uint32_t* __restrict__ wfar,
+                                                          uint8_t* __restrict__ d_out, u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
+{
+	__shared__ uint32_t s_ecur[1024], s_eF[1024];                  // state after every window (phases 1-2); then: tokens | rank parity, bytes before it
+	__shared__ uint32_t s_sum[1024];                               // nt | nlong << 8 | fixed bytes << 16 of every window
+	__shared__ uint16_t s_in_off[NW][256];
+	__shared__ uint16_t s_in_len[NW][256];
+	__shared__ uint8_t  s_in_byte[NW][256];
+	__shared__ u64      s_in_mask[NW][8];                           // token masks [0..3] and match masks [4..7] of the staged windows
+	__shared__ u64      s_seam_pos[NW][2];                          // per segment: [0] slot of the flag word open at its end, [1] pending nibble byte
+	__shared__ uint32_t s_seam[NW][8];                              // per segment: lead bits, lead complete, tail bits, tail valid, lead nib, tail pend, tail low, tokens
+	__shared__ u64      s_state[4];                                // carried: cur, F (written by wave 0 after the repair)
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+	const uint32_t u = blockIdx.x;
+	const u64 n = bt.in_len[u];
+	const u64 cap = bt.out_cap[u];
+	const uint8_t* __restrict__ d = d_in + bt.in_off[u];
+	uint8_t* __restrict__ out = d_out + bt.out_off[u];
+	const u64 mbase = (u64)bt.chunk_prefix[u] * 65536u;           // this unit's slice of the per-position match arrays
+	uint16_t* __restrict__ mlen3u = mlen3 + mbase;
+	const uint16_t* __restrict__ moffu = moff + mbase;
+	u64* __restrict__ wtoku = wtok + (mbase >> 6); u64* __restrict__ wmatu = wmat + (mbase >> 6); uint32_t* __restrict__ wfaru = wfar + (mbase >> 6);
+	const u64 end2 = n >= 2u ? n - 2u : 0u;
+	const u64 nwin = (n + 63u) >> 6;
+
+	// carried over the super-blocks (wave 0 owns them; cur/F are broadcast through s_state)
+	u64 g_cur = 0, g_F = 0, g_N = 0, g_S = 0, g_R = 0;
+	uint32_t g_acc = 0; u64 g_fpos = 0; bool g_pend = false; u64 g_pend_pos = 0; uint32_t g_pend_low = 0;
+
+	uint32_t g_off[4], g_len[4], g_byte[4];
+#define XE2_LOAD(gb) { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
+		const u64 q_ = (gb) + (u64)k_ * 64u + lane; const u64 c_ = q_ < n ? q_ : n - 1u; \
+		g_off[k_] = moffu[c_]; g_len[k_] = mlen3u[c_]; g_byte[k_] = d[c_]; } }
+#define XE2_STORE() { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
+		s_in_off[wv][k_ * 64 + lane] = (uint16_t)g_off[k_]; s_in_len[wv][k_ * 64 + lane] = (uint16_t)g_len[k_]; s_in_byte[wv][k_ * 64 + lane] = (uint8_t)g_byte[k_]; } }
+
+#ifdef XE2_PROFILE
+	unsigned long long x2_prev = __builtin_readcyclecounter();
+#endif
+	for (u64 sb = 0; sb < nwin; sb += 1024u) {                     // super-block = windows [sb, sb + nsb)
+		const uint32_t nsb = (nwin - sb < 1024u) ? (uint32_t)(nwin - sb) : 1024u;
+		const uint32_t w0 = wv * (1024u / NW), w1 = (w0 + (1024u / NW) < nsb) ? w0 + (1024u / NW) : nsb;   // my segment (may be empty)
+		// ---- 1. speculative walk of my segment ---------------------------------------------------------------------
+		if (w0 < w1) {
+			u64 cur, F;
+			if (wv == 0) { cur = g_cur; F = g_F; }
+			else { cur = (sb + w0) * 64u; F = (cur < end2) ? cur : end2; }   // a token starts here, Fill not lagging
+			XE2_LOAD((sb + w0) * 64u)
+			for (uint32_t w = w0; w < w1; ++w) {
+				const uint32_t wi = (w - w0) & 3u;
+				if (wi == 0) {
+					XE2_STORE()
+					if (w + 4u < w1) { XE2_LOAD((sb + w + 4u) * 64u) }
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+				}
+				const u64 wbase = (sb + w) * 64u;
+				const uint32_t off = s_in_off[wv][wi * 64u + lane];
+				uint32_t L = s_in_len[wv][wi * 64u + lane];
+				u64 tm, mk;
+				xe_walk_window(d, n, end2, lane, wbase, cur, F, off, L, tm, mk);
+				xe_store_window(lane, wbase, n, sb + w, w, off, L, tm, mk, cur, F, end2, mlen3u, wtoku, wmatu, wfaru, s_ecur, s_eF, s_sum);
+			}
+		}
+		XE2_T(0)
+		__syncthreads();
+		XE2_T(1)
+		// ---- 2. repair the seams (wave 0) --------------------------------------------------------------------------
+		if (wv == 0) {
+			for (uint32_t j = 1; j * (1024u / NW) < nsb; ++j) {
+				const uint32_t a = j * (1024u / NW), b = (a + (1024u / NW) < nsb) ? a + (1024u / NW) : nsb;
+				const u64 wprev = (sb + a - 1u) * 64u;
+				const uint32_t pc = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ecur[a - 1u]), pf = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_eF[a - 1u]);
+				u64 cur = wprev + pc;                                  // true entry state of segment j
+				u64 F = (pf == 0xFFFFFFFFu) ? end2 : ((u64)pf << 13);
+				const u64 s0 = (sb + a) * 64u;
+				if (cur == s0 && F == ((s0 < end2) ? s0 : end2)) { continue; }   // the speculation was right
+				for (uint32_t w = a; w < b; ++w) {
+					const u64 wbase = (sb + w) * 64u;
+					const u64 q = wbase + lane, c = q < n ? q : n - 1u;
+					const uint32_t off = moffu[c];
+					uint32_t L = __hip_atomic_load(&mlen3u[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (written by another wave)
+					if (L == 0xFFFFu) { L = __hip_atomic_load(&wfaru[sb + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+					u64 tm, mk;
+					xe_walk_window(d, n, end2, lane, wbase, cur, F, off, L, tm, mk);
+					const uint32_t sc = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ecur[w]), sf = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_eF[w]);
+					xe_store_window(lane, wbase, n, sb + w, w, off, L, tm, mk, cur, F, end2, mlen3u, wtoku, wmatu, wfaru, s_ecur, s_eF, s_sum);
+					if (xe_pack_cur(cur, wbase) == sc && xe_pack_F(F, end2) == sf) { break; }   // re-synchronised
+				}
+			}
+			// the true state after the super-block
+			const u64 wl = (sb + nsb - 1u) * 64u;
+			const uint32_t pc = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ecur[nsb - 1u]), pf = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_eF[nsb - 1u]);
+			g_cur = wl + pc; g_F = (pf == 0xFFFFFFFFu) ? end2 : ((u64)pf << 13);
+			// ---- 3. scan: tokens / long-match rank parity / bytes before every window ---------------------------------
+			uint32_t nc = 0, sc = 0, rc = (uint32_t)g_R;
+			for (uint32_t b0 = 0; b0 < nsb; b0 += 64u) {
+				const uint32_t w = b0 + lane;
+				const uint32_t v = w < nsb ? s_sum[w] : 0u;
+				const uint32_t nt = v & 0xFFu, nl = (v >> 8) & 0xFFu, fsz = v >> 16;
+				const uint32_t ri = wave_incl_scan_add(nl);
+				const uint32_t rb = rc + ri - nl;                       // long matches before this window
+				const uint32_t sz = fsz + (((rb & 1u) == 0) ? (nl + 1u) >> 1 : nl >> 1);   // even ranks own a nibble byte
+				const uint32_t ni = wave_incl_scan_add(nt), si = wave_incl_scan_add(sz);
+				if (w < nsb) { s_ecur[w] = (nc + ni - nt) | ((rb & 1u) << 31); s_eF[w] = sc + si - sz; }
+				nc += (uint32_t)__builtin_amdgcn_readlane((int)ni, 63); sc += (uint32_t)__builtin_amdgcn_readlane((int)si, 63); rc += (uint32_t)__builtin_amdgcn_readlane((int)ri, 63);
+			}
+			if (lane == 0) { s_state[0] = g_N; s_state[1] = g_S; s_state[2] = nc; s_state[3] = sc; }
+			g_R += (u64)(rc - (uint32_t)g_R);
+		}
+		XE2_T(2)
+		__syncthreads();
+		XE2_T(3)
+		// ---- 4. emission of my segment -----------------------------------------------------------------------------
+		const u64 Nsb = s_state[0], Ssb = s_state[1];
+		if (w0 < w1) {
+			bool pend = false; u64 pend_pos = 0; uint32_t pend_low = 0;
+			uint32_t facc = 0; u64 fposc = 0;
+			bool lead_open = false, lead_done = false; uint32_t lead_bits = 0, lead_nib = 0xFFu; bool tail_started = false;
+			bool first = true; uint32_t ntok_seg = 0;
+			// (the masks of the 4 windows of a burst travel with it: lanes 0-3 / 4-7 fetch them)
+			u64 g_mask = 0;
+#define XE2_LOAD_MASKS(wq) { g_mask = 0; if (lane < 8u && (wq) + (lane & 3u) < w1) { \
+		g_mask = __hip_atomic_load((lane < 4u ? wtoku : wmatu) + sb + (wq) + (lane & 3u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } }
+			XE2_LOAD((sb + w0) * 64u) XE2_LOAD_MASKS(w0)
+			for (uint32_t w = w0; w < w1; ++w) {
+				const uint32_t wi = (w - w0) & 3u;
+				if (wi == 0) {
+					XE2_STORE()
+					if (lane < 8u) { s_in_mask[wv][lane] = g_mask; }
+					if (w + 4u < w1) { XE2_LOAD((sb + w + 4u) * 64u) XE2_LOAD_MASKS(w + 4u) }
+					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+				}
+				const u64 tokmask = s_in_mask[wv][wi];
+				if (tokmask == 0) { continue; }
+				const u64 matchmask = s_in_mask[wv][4u + wi];
+				const uint32_t off = s_in_off[wv][wi * 64u + lane], byte = s_in_byte[wv][wi * 64u + lane];
+				uint32_t L = s_in_len[wv][wi * 64u + lane];
+				if (L == 0xFFFFu) { L = __hip_atomic_load(&wfaru[sb + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+				const bool is_tok = (tokmask >> lane) & (u64)1, is_m = (matchmask >> lane) & (u64)1;
+				const u64 N = Nsb + (s_ecur[w] & 0x7FFFFFFFu), S = Ssb + s_eF[w];
+				const uint32_t Rpar = s_ecur[w] >> 31;
+				if (first) { first = false; lead_open = (N & 31u) != 0; }
+
+				const uint32_t nt = (uint32_t)__popcll(tokmask);
+				ntok_seg += nt;
+				const bool lng = is_m && L >= 7u;
+				const u64 longmask = __ballot(lng);
+				const bool even = !((Rpar + popc_below(longmask)) & 1u);
+				uint32_t sz = 0;
+				if (is_tok) { sz = !is_m ? 1u : 2u + (uint32_t)(lng && even) + (uint32_t)(L >= 22u) + (L >= 277u ? (L <= 0xFFFFu ? 2u : 6u) : 0u); }
+				const uint32_t incl = wave_incl_scan_add(sz);
+				const uint32_t wsum = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+				const uint32_t tb = popc_below(tokmask);
+				const uint32_t sh = (uint32_t)(N & 31u);
+				const uint32_t tq = sh + tb;
+				const u64 base = 4u * (N / 32u + 1u) + S;
+				const uint32_t posrel = 4u * (tq >> 5) + (incl - sz);
+				const uint32_t kdone = (sh + nt) >> 5;
+				const bool fits = base + 4u * kdone + wsum <= cap;
+				const u64 above = (longmask >> lane) >> 1;
+				const uint32_t nib = L >= 7u ? (L - 7u < 15u ? L - 7u : 15u) : 0u;
+				const uint32_t partner = above ? lane + 1u + ctz64(above) : lane;
+				const uint32_t pnib = (uint32_t)__shfl((int)nib, (int)partner, 64);
+				// the first long match of the segment with an odd rank completes a byte owned by an earlier segment: recorded
+				if (longmask && lead_nib == 0xFFu && !pend) {
+					const uint32_t fl = ctz64(longmask);
+					const uint32_t fn = (uint32_t)__builtin_amdgcn_readlane((int)nib, (int)fl);
+					if (Rpar & 1u) { lead_nib = fn | 0x100u; } else { lead_nib = 0x200u; }   // 0x1xx: odd first rank (nibble xx); 0x200: nothing to complete
+				}
+				if (fits) { xe_emit_tokens<false>(out, cap, base, posrel, is_tok, is_m, byte, off, L, lng, even, above != 0, nib, pnib, pend, pend_pos, pend_low, longmask, lane); }
+				else      { xe_emit_tokens<true >(out, cap, base, posrel, is_tok, is_m, byte, off, L, lng, even, above != 0, nib, pnib, pend, pend_pos, pend_low, longmask, lane); }
+				{
+					const uint32_t dst = is_tok ? tb : nt + (lane - tb);
+					const uint32_t fm = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (is_tok && is_m) ? 1 : 0);
+					const u64 M = __ballot(fm != 0);
+					u64 sm = __ballot(is_tok && (tq & 31u) == 0);
+					const u64 lo = (u64)facc | (M << sh);
+					const uint32_t hi = sh ? (uint32_t)(M >> (64u - sh)) : 0u;
+					u64 fp = fposc;
+					uint32_t wd = (uint32_t)lo;
+					bool started = tail_started;                            // does the word in `wd` start inside this segment?
+					if (sh == 0) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; sm &= sm - 1u; started = true; }
+					if (kdone >= 1u) {
+						if (started) { if (lane == 0) { xe_store32(out, cap, fp, __builtin_bitreverse32(wd), !fits); } }
+						else { lead_bits = wd; lead_done = true; }            // the word that was open at the segment's first token
+						wd = (uint32_t)(lo >> 32); started = false;
+						if (sm) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; sm &= sm - 1u; started = true; }
+						if (kdone >= 2u) {
+							if (lane == 0) { xe_store32(out, cap, fp, __builtin_bitreverse32(wd), !fits); }
+							wd = hi; started = false;
+							if (sm) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; started = true; }
+						}
+					}
+					facc = wd; fposc = fp; tail_started = started;
+				}
+				if (longmask) {
+					const uint32_t ll = 63u - (uint32_t)__builtin_clzll(longmask);
+					const uint32_t rl = Rpar + (uint32_t)__popcll(longmask) - 1u;
+					pend = !(rl & 1u);
+					if (pend) {
+						pend_pos = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)ll) + 2u;
+						pend_low = (uint32_t)__builtin_amdgcn_readlane((int)nib, (int)ll);
+					}
+				}
+			}
+			if (lane == 0) {
+				// lead: bits of the word that was open at my first token (complete or not); tail: the word open at my end
+				s_seam[wv][0] = lead_open ? (lead_done ? lead_bits : facc) : 0u;
+				s_seam[wv][1] = (lead_open && lead_done) ? 1u : 0u;
+				s_seam[wv][2] = (lead_open && !lead_done) ? 0u : facc;
+				s_seam[wv][3] = ((!lead_open || lead_done) && tail_started) ? 1u : 0u;
+				s_seam[wv][4] = lead_nib;
+				s_seam[wv][5] = pend ? 1u : 0u;
+				s_seam[wv][6] = pend_low;
+				s_seam[wv][7] = ntok_seg;
+				s_seam_pos[wv][0] = fposc; s_seam_pos[wv][1] = pend_pos;
+			}
+		} else if (lane == 0) { s_seam[wv][7] = 0; s_seam[wv][4] = 0xFFu; s_seam[wv][5] = 0; }
+		XE2_T(4)
+		__syncthreads();
+		XE2_T(5)
+		// ---- 5. stitch the seams (wave 0) --------------------------------------------------------------------------
+		if (wv == 0) {
+			for (uint32_t j = 0; j < NW; ++j) {
+				if (s_seam[j][7] == 0) { continue; }                     // no token starts in this segment
+				// flag word in progress
+				if (s_seam[j][1]) {                                      // the open word was completed inside segment j
+					const uint32_t wdv = g_acc | s_seam[j][0];
+					if (lane == 0) { xe_store32(out, cap, g_fpos, __builtin_bitreverse32(wdv), true); }
+					g_acc = 0;
+				} else { g_acc |= s_seam[j][0]; }
+				if (s_seam[j][3]) { g_acc = s_seam[j][2]; g_fpos = s_seam_pos[j][0]; }
+				// nibble byte in progress
+				const uint32_t ln = s_seam[j][4];
+				if (ln & 0x100u) { if (g_pend && lane == 0) { put8(out, cap, g_pend_pos, g_pend_low | ((ln & 0xFu) << 4)); } g_pend = false; }
+				if (ln != 0xFFu) { g_pend = s_seam[j][5] != 0; g_pend_pos = s_seam_pos[j][1]; g_pend_low = s_seam[j][6]; }
+			}
+			g_N += s_state[2]; g_S += s_state[3];
+			if (lane == 0) { s_state[0] = g_cur; s_state[1] = g_F; }
+		}
+		__syncthreads();
+	}
+	// ---- final flag word (:343-344), size, status ----------------------------------------------------------------
+	if (wv == 0) {
+		const u64 gf = g_N / 32u;
+		const uint32_t cnt = (uint32_t)(g_N & 31u);
+		const u64 total = 4u * (gf + 1u) + g_S;
+		if (lane == 0) {
+			uint32_t wvv; u64 fp;
+			if (cnt) { wvv = __builtin_bitreverse32(g_acc) | ((1u << (32u - cnt)) - 1u); fp = g_fpos; }
+			else { wvv = 0xFFFFFFFFu; fp = total - 4u; }
+			put8(out, cap, fp, wvv); put8(out, cap, fp + 1u, wvv >> 8); put8(out, cap, fp + 2u, wvv >> 16); put8(out, cap, fp + 3u, wvv >> 24);
+			const bool ok = total <= cap;
+			d_out_len[u] = ok ? total : 0;
+			d_status[u] = ok ? 0 : -5;
+		}
+	}
+#undef XE2_LOAD
+#undef XE2_STORE
+#undef XE2_LOAD_MASKS
+}
+
+static int g_xpress_emit_mode = 0;                               // 0 = by batch size, 1 = one wave per unit, 2 / 3 = four / sixteen waves per unit (tests)
+void launch_xpress_emit(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* mlen3, const uint16_t* moff,
+                        u64* wtok, u64* wmat, uint32_t* wfar, uint8_t* d_out, u64* d_out_len, int32_t* d_status)
 {
 	if (bt.n_units == 0) { return; }
-	hipLaunchKernelGGL(xpress_emit_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, mlen3, moff, d_out, d_out_len, d_status);
+	// One wave per unit is the better use of a full GPU (the multi-wave kernel spends twice the wave-cycles); with few
+	// units the 4- or 16-wave kernel cuts the latency of each.
+	const int mode = g_xpress_emit_mode ? g_xpress_emit_mode : (bt.n_units <= 64u ? 3 : (bt.n_units <= 1024u ? 2 : 1));
+	if (mode == 1) { hipLaunchKernelGGL(xpress_emit_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, mlen3, moff, d_out, d_out_len, d_status); }
+	else if (mode == 2) { hipLaunchKernelGGL(xpress_emit2_kernel<4u>, dim3(bt.n_units), dim3(256), 0, st, d_in, bt, mlen3, moff, wtok, wmat, wfar, d_out, d_out_len, d_status); }
+	else { hipLaunchKernelGGL(xpress_emit2_kernel<16u>, dim3(bt.n_units), dim3(1024), 0, st, d_in, bt, mlen3, moff, wtok, wmat, wfar, d_out, d_out_len, d_status); }
 }
+void set_xpress_emit_mode(int mode) { g_xpress_emit_mode = mode; }
 
 } // namespace msc

@@ -171,3 +171,29 @@ def test_lds_atomics_are_served_in_lane_order(gpu_ctx, nkeys):
     instruction in lane order; the parity tests would catch a violation only indirectly (a tie decided differently)."""
     bad = gpu_ctx.lib.mscomp_amd_debug_lds_lane_order(gpu_ctx._h, 1234 + nkeys, 512, 64, nkeys)
     assert bad == 0, "%d lanes were served out of lane order" % bad
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_xpress_emit_kernels_agree(oracle, gpu_ctx, mode):
+    """The Xpress parse/emit stage has two kernels (one wave per unit / four waves per unit with speculative segments and
+    seam repair, 4 or 16 waves); the library picks by batch size. Both must produce the reference's bytes: edge families, a multi-
+    super-block stream (> 64 KiB, incl. a run longer than 64 KiB and an incompressible stretch) and exact capacities."""
+    import ms_compress_amd as m
+    gpu_ctx.lib.mscomp_amd_debug_set_xpress_emit(mode)
+    try:
+        units = cases.edge_cases()
+        rng = np.random.default_rng(77)
+        big = np.concatenate([np.frombuffer(b"the quick brown fox jumps over the lazy dog. " * 3000, dtype=np.uint8),
+                              np.zeros(150000, dtype=np.uint8), rng.integers(0, 256, 90000, dtype=np.uint8),
+                              np.frombuffer(b"ab" * 50000, dtype=np.uint8), rng.integers(0, 4, 120000, dtype=np.uint8)])
+        units = list(units) + [big, big[:200001], big[131000:400000]]
+        _check_units(m, oracle, FMTS["xpress"], units, gpu_ctx)
+        # exact and one-short capacities go through the capacity-checked store path
+        sub = [u for u in units if 0 < len(u) <= 70000][:60]
+        exp = [oracle.oracle_compress(FMTS["xpress"], u)[1] for u in sub]
+        got, st = m.compress_units(FMTS["xpress"], sub, ctx=gpu_ctx, capacities=[len(e) for e in exp])
+        assert all(s == 0 for s in st) and all(g == e for g, e in zip(got, exp))
+        got, st = m.compress_units(FMTS["xpress"], sub, ctx=gpu_ctx, capacities=[len(e) - 1 for e in exp])
+        assert all(s == -5 for s in st)
+    finally:
+        gpu_ctx.lib.mscomp_amd_debug_set_xpress_emit(0)
