@@ -236,8 +236,9 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 	__syncthreads();
 
 	// links of this chunk; the previous chunk's array directly precedes it, so a window-relative position xr is entry
-	// lkg[xr - crel] for both (negative index = previous chunk)
+	// lkw[xr] of an array that starts where the window starts (unsigned 32-bit index: scalar base + lane offset)
 	const uint16_t* __restrict__ lkg = links + (u64)lc * 65536u;
+	const uint16_t* __restrict__ lkw = lkg - (ptrdiff_t)(cbase - wstart);
 	const uint16_t* __restrict__ lh_prev = lasthead + (u64)(lc - (k ? 1u : 0u)) * 32768u;
 	const uint32_t tn = (cn - tstart < XP_TILE) ? cn - tstart : XP_TILE;
 	// 65535 as the previous chunk's head is indistinguishable from "none" (0xFFFF): decide by that position's hash
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 				if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(__ballot(1))) { XF_CNT(2, 64) }
 				const uint32_t dist = (uint32_t)((int32_t)pr - xr);
 				// the link of xr is fetched first (L2 latency for Xpress+Huffman) and consumed after the compare
-				uint32_t x = (LINKW == WINDOW) ? (uint32_t)s_links[(uint32_t)xr - lrel] : (uint32_t)lkg[xr - crel];
+				uint32_t x = (LINKW == WINDOW) ? (uint32_t)s_links[(uint32_t)xr - lrel] : (uint32_t)lkw[(uint32_t)xr];
 				// 16 bytes per step against my own 48 bytes held in registers (lengths are capped at 48 here)
 				uint4 c = ld128(s_data, (uint32_t)xr);
 				uint32_t l = first_diff16(make_uint4(c.x ^ oa.x, c.y ^ oa.y, c.z ^ oa.z, c.w ^ oa.w));
