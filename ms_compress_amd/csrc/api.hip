@@ -40,6 +40,7 @@ struct mscomp_amd_ctx {
 	DevBuf slots, slot_size, prefix, tile_sums;        // chunk scratch (grow-only, shared by all plans of the ctx)
 	DevBuf links, lasthead, mlen3, moff;               // Xpress-family match finder scratch (per 64 KiB link chunk)
 	DevBuf wtok, wmat, wfar;                           // Xpress parse records per 64-position window (token mask, match mask, far length)
+	DevBuf wrec, sbrec;                                // ... state / counts / prefixes per window (6 x u32), per super-block (tot 4 x u32, pre 3 x u64, seams)
 	DevBuf tokbits, counts, extra, lens, codes, fb_list, fbflag;   // Xpress+Huffman per-chunk scratch
 	DevBuf one_in, one_out, one_meta;                  // staging of the host-pointer one-shot path
 	bool profiling = false;
@@ -130,7 +131,7 @@ void mscomp_amd_ctx_destroy(mscomp_amd_ctx* c)
 	c->slots.release(); c->slot_size.release(); c->prefix.release(); c->tile_sums.release();
 	c->one_in.release(); c->one_out.release(); c->one_meta.release();
 	c->links.release(); c->lasthead.release(); c->mlen3.release(); c->moff.release();
-	c->wtok.release(); c->wmat.release(); c->wfar.release();
+	c->wtok.release(); c->wmat.release(); c->wfar.release(); c->wrec.release(); c->sbrec.release();
 	c->tokbits.release(); c->counts.release(); c->extra.release(); c->lens.release(); c->codes.release();
 	c->fb_list.release(); c->fbflag.release();
 	delete c;
@@ -204,6 +205,10 @@ MSCompStatus mscomp_amd_plan_create(mscomp_amd_ctx* c, MSCompFormat format, size
 		if (ok && format == MSCOMP_XPRESS) {
 			const size_t nw = (size_t)p->n_chunks * 1024u + 64;
 			ok = c->wtok.reserve(nw * 8) && c->wmat.reserve(nw * 8) && c->wfar.reserve(nw * 4);
+			if (ok && (p->n_units <= 64u || get_xpress_emit_mode() == 4)) {    // the block-per-super-block kernels (few units)
+				const size_t ns = (size_t)p->n_chunks + 1;
+				ok = c->wrec.reserve(nw * 6 * 4) && c->sbrec.reserve(ns * (16 + 24 + 16 * 8 * 4 + 16 * 2 * 8));
+			}
 		}
 	}
 	if (ok && format == MSCOMP_XPRESS_HUFF) {
@@ -223,6 +228,23 @@ void mscomp_amd_plan_destroy(mscomp_amd_plan* p)
 	(void)hipStreamSynchronize(p->ctx->stream);
 	p->tables.release();
 	delete p;
+}
+
+static XpressWinBufs xpress_win_bufs(mscomp_amd_ctx* c, uint32_t n_chunks)
+{
+	XpressWinBufs b = {};
+	b.wtok = static_cast<u64*>(c->wtok.p); b.wmat = static_cast<u64*>(c->wmat.p); b.wfar = static_cast<uint32_t*>(c->wfar.p);
+	const size_t nw = (size_t)n_chunks * 1024u + 64, ns = (size_t)n_chunks + 1;
+	if (c->wrec.p && c->sbrec.p) {
+		uint32_t* w = static_cast<uint32_t*>(c->wrec.p);
+		b.wecur = w; b.weF = w + nw; b.wsum = w + 2 * nw; b.wnr = w + 3 * nw; b.ws0 = w + 4 * nw; b.ws1 = w + 5 * nw;
+		uint8_t* q = static_cast<uint8_t*>(c->sbrec.p);
+		b.sbpre = reinterpret_cast<u64*>(q); q += ns * 24;
+		b.seampos = reinterpret_cast<u64*>(q); q += ns * 16 * 2 * 8;
+		b.sbtot = reinterpret_cast<uint32_t*>(q); q += ns * 16;
+		b.seam = reinterpret_cast<uint32_t*>(q);
+	}
+	return b;
 }
 
 MSCompStatus mscomp_amd_plan_execute(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t* d_out, uint64_t* d_out_len, int32_t* d_status)
@@ -249,7 +271,7 @@ MSCompStatus mscomp_amd_plan_execute(mscomp_amd_plan* p, const uint8_t* d_in, ui
 		uint16_t* mlen3 = static_cast<uint16_t*>(c->mlen3.p); uint16_t* moff = static_cast<uint16_t*>(c->moff.p);
 		{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
 		{ KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0x2000u, 0); }
-		{ KernelTimer t(c, "xpress_emit_kernel"); launch_xpress_emit(st, d_in, p->bt, mlen3, moff, static_cast<u64*>(c->wtok.p), static_cast<u64*>(c->wmat.p), static_cast<uint32_t*>(c->wfar.p), d_out, d_out_len, d_status); }
+		{ KernelTimer t(c, "xpress_emit_kernel"); launch_xpress_emit(st, d_in, p->bt, mlen3, moff, xpress_win_bufs(c, p->n_chunks), d_out, d_out_len, d_status); }
 		break;
 	}
 	case MSCOMP_XPRESS_HUFF: {

@@ -456,6 +456,133 @@ __device__ __forceinline__ void xe_store_window(uint32_t lane, u64 wbase, u64 n,
 	}
 }
 
+// Emission of one segment (windows [w0, w1) of the super-block that starts at window sb of the unit) from the recorded
+// masks and lengths; s_nr[w] = tokens before window w of the super-block | long-match rank parity << 31, s_sr[w] = bytes
+// before it (both relative to Nsb / Ssb). What couples the segment to its neighbours is recorded in seam[] / seampos[]:
+// seam: lead bits, lead complete, tail bits, tail valid, lead nibble, tail pending, tail low nibble, tokens;
+// seampos: slot of the flag word open at the segment's end, position of its pending nibble byte.
+__device__ __forceinline__ void xe_emit_segment(uint32_t lane, u64 sb, uint32_t w0, uint32_t w1, u64 n, u64 cap, const uint8_t* __restrict__ d,
+                                                uint8_t* __restrict__ out, const uint16_t* __restrict__ mlen3u, const uint16_t* __restrict__ moffu,
+                                                const u64* wtoku, const u64* wmatu, const uint32_t* wfaru, const uint32_t* s_nr, const uint32_t* s_sr,
+                                                u64 Nsb, u64 Ssb, uint16_t* s_off, uint16_t* s_len, uint8_t* s_byte, u64* s_mask,
+                                                uint32_t* seam, u64* seampos)
+{
+	uint32_t g_off[4], g_len[4], g_byte[4];
+#define XE4_LOAD(gb) { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
+		const u64 q_ = (gb) + (u64)k_ * 64u + lane; const u64 c_ = q_ < n ? q_ : n - 1u; \
+		g_off[k_] = moffu[c_]; g_len[k_] = mlen3u[c_]; g_byte[k_] = d[c_]; } }
+#define XE4_STORE() { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
+		s_off[k_ * 64 + lane] = (uint16_t)g_off[k_]; s_len[k_ * 64 + lane] = (uint16_t)g_len[k_]; s_byte[k_ * 64 + lane] = (uint8_t)g_byte[k_]; } }
+	if (w0 >= w1) { if (lane == 0) { seam[7] = 0; seam[4] = 0xFFu; seam[5] = 0; } return; }
+	{
+	bool pend = false; u64 pend_pos = 0; uint32_t pend_low = 0;
+	uint32_t facc = 0; u64 fposc = 0;
+	bool lead_open = false, lead_done = false; uint32_t lead_bits = 0, lead_nib = 0xFFu; bool tail_started = false;
+	bool first = true; uint32_t ntok_seg = 0;
+	// (the masks of the 4 windows of a burst travel with it: lanes 0-3 / 4-7 fetch them)
+	u64 g_mask = 0;
+#define XE2_LOAD_MASKS(wq) { g_mask = 0; if (lane < 8u && (wq) + (lane & 3u) < w1) { \
+g_mask = __hip_atomic_load((lane < 4u ? wtoku : wmatu) + sb + (wq) + (lane & 3u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } }
+	XE4_LOAD((sb + w0) * 64u) XE2_LOAD_MASKS(w0)
+	for (uint32_t w = w0; w < w1; ++w) {
+		const uint32_t wi = (w - w0) & 3u;
+		if (wi == 0) {
+			XE4_STORE()
+			if (lane < 8u) { s_mask[lane] = g_mask; }
+			if (w + 4u < w1) { XE4_LOAD((sb + w + 4u) * 64u) XE2_LOAD_MASKS(w + 4u) }
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+		}
+		const u64 tokmask = s_mask[wi];
+		if (tokmask == 0) { continue; }
+		const u64 matchmask = s_mask[4u + wi];
+		const uint32_t off = s_off[wi * 64u + lane], byte = s_byte[wi * 64u + lane];
+		uint32_t L = s_len[wi * 64u + lane];
+		if (L == 0xFFFFu) { L = __hip_atomic_load(&wfaru[sb + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+		const bool is_tok = (tokmask >> lane) & (u64)1, is_m = (matchmask >> lane) & (u64)1;
+		const u64 N = Nsb + (s_nr[w] & 0x7FFFFFFFu), S = Ssb + s_sr[w];
+		const uint32_t Rpar = s_nr[w] >> 31;
+		if (first) { first = false; lead_open = (N & 31u) != 0; }
+
+		const uint32_t nt = (uint32_t)__popcll(tokmask);
+		ntok_seg += nt;
+		const bool lng = is_m && L >= 7u;
+		const u64 longmask = __ballot(lng);
+		const bool even = !((Rpar + popc_below(longmask)) & 1u);
+		uint32_t sz = 0;
+		if (is_tok) { sz = !is_m ? 1u : 2u + (uint32_t)(lng && even) + (uint32_t)(L >= 22u) + (L >= 277u ? (L <= 0xFFFFu ? 2u : 6u) : 0u); }
+		const uint32_t incl = wave_incl_scan_add(sz);
+		const uint32_t wsum = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		const uint32_t tb = popc_below(tokmask);
+		const uint32_t sh = (uint32_t)(N & 31u);
+		const uint32_t tq = sh + tb;
+		const u64 base = 4u * (N / 32u + 1u) + S;
+		const uint32_t posrel = 4u * (tq >> 5) + (incl - sz);
+		const uint32_t kdone = (sh + nt) >> 5;
+		const bool fits = base + 4u * kdone + wsum <= cap;
+		const u64 above = (longmask >> lane) >> 1;
+		const uint32_t nib = L >= 7u ? (L - 7u < 15u ? L - 7u : 15u) : 0u;
+		const uint32_t partner = above ? lane + 1u + ctz64(above) : lane;
+		const uint32_t pnib = (uint32_t)__shfl((int)nib, (int)partner, 64);
+		// the first long match of the segment with an odd rank completes a byte owned by an earlier segment: recorded
+		if (longmask && lead_nib == 0xFFu && !pend) {
+			const uint32_t fl = ctz64(longmask);
+			const uint32_t fn = (uint32_t)__builtin_amdgcn_readlane((int)nib, (int)fl);
+			if (Rpar & 1u) { lead_nib = fn | 0x100u; } else { lead_nib = 0x200u; }   // 0x1xx: odd first rank (nibble xx); 0x200: nothing to complete
+		}
+		if (fits) { xe_emit_tokens<false>(out, cap, base, posrel, is_tok, is_m, byte, off, L, lng, even, above != 0, nib, pnib, pend, pend_pos, pend_low, longmask, lane); }
+		else      { xe_emit_tokens<true >(out, cap, base, posrel, is_tok, is_m, byte, off, L, lng, even, above != 0, nib, pnib, pend, pend_pos, pend_low, longmask, lane); }
+		{
+			const uint32_t dst = is_tok ? tb : nt + (lane - tb);
+			const uint32_t fm = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (is_tok && is_m) ? 1 : 0);
+			const u64 M = __ballot(fm != 0);
+			u64 sm = __ballot(is_tok && (tq & 31u) == 0);
+			const u64 lo = (u64)facc | (M << sh);
+			const uint32_t hi = sh ? (uint32_t)(M >> (64u - sh)) : 0u;
+			u64 fp = fposc;
+			uint32_t wd = (uint32_t)lo;
+			bool started = tail_started;                            // does the word in `wd` start inside this segment?
+			if (sh == 0) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; sm &= sm - 1u; started = true; }
+			if (kdone >= 1u) {
+				if (started) { if (lane == 0) { xe_store32(out, cap, fp, __builtin_bitreverse32(wd), !fits); } }
+				else { lead_bits = wd; lead_done = true; }            // the word that was open at the segment's first token
+				wd = (uint32_t)(lo >> 32); started = false;
+				if (sm) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; sm &= sm - 1u; started = true; }
+				if (kdone >= 2u) {
+					if (lane == 0) { xe_store32(out, cap, fp, __builtin_bitreverse32(wd), !fits); }
+					wd = hi; started = false;
+					if (sm) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; started = true; }
+				}
+			}
+			facc = wd; fposc = fp; tail_started = started;
+		}
+		if (longmask) {
+			const uint32_t ll = 63u - (uint32_t)__builtin_clzll(longmask);
+			const uint32_t rl = Rpar + (uint32_t)__popcll(longmask) - 1u;
+			pend = !(rl & 1u);
+			if (pend) {
+				pend_pos = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)ll) + 2u;
+				pend_low = (uint32_t)__builtin_amdgcn_readlane((int)nib, (int)ll);
+			}
+		}
+	}
+	if (lane == 0) {
+		// lead: bits of the word that was open at my first token (complete or not); tail: the word open at my end
+		seam[0] = lead_open ? (lead_done ? lead_bits : facc) : 0u;
+		seam[1] = (lead_open && lead_done) ? 1u : 0u;
+		seam[2] = (lead_open && !lead_done) ? 0u : facc;
+		seam[3] = ((!lead_open || lead_done) && tail_started) ? 1u : 0u;
+		seam[4] = lead_nib;
+		seam[5] = pend ? 1u : 0u;
+		seam[6] = pend_low;
+		seam[7] = ntok_seg;
+		seampos[0] = fposc; seampos[1] = pend_pos;
+	}
+	}
+#undef XE4_LOAD
+#undef XE4_STORE
+#undef XE2_LOAD_MASKS
+}
+
 #ifdef XE2_PROFILE
 __device__ unsigned long long g_xe2_prof[16];
 extern "C" void mscomp_amd_debug_xe2_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xe2_prof), 128); unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xe2_prof), z, 128); }
@@ -579,111 +706,8 @@ __global__ __launch_bounds__(NW * 64u) void xpress_emit2_kernel(const uint8_t* _
 		__syncthreads();
 		XE2_T(3)
 		// ---- 4. emission of my segment -----------------------------------------------------------------------------
-		const u64 Nsb = s_state[0], Ssb = s_state[1];
-		if (w0 < w1) {
-			bool pend = false; u64 pend_pos = 0; uint32_t pend_low = 0;
-			uint32_t facc = 0; u64 fposc = 0;
-			bool lead_open = false, lead_done = false; uint32_t lead_bits = 0, lead_nib = 0xFFu; bool tail_started = false;
-			bool first = true; uint32_t ntok_seg = 0;
-			// (the masks of the 4 windows of a burst travel with it: lanes 0-3 / 4-7 fetch them)
-			u64 g_mask = 0;
-#define XE2_LOAD_MASKS(wq) { g_mask = 0; if (lane < 8u && (wq) + (lane & 3u) < w1) { \
-		g_mask = __hip_atomic_load((lane < 4u ? wtoku : wmatu) + sb + (wq) + (lane & 3u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } }
-			XE2_LOAD((sb + w0) * 64u) XE2_LOAD_MASKS(w0)
-			for (uint32_t w = w0; w < w1; ++w) {
-				const uint32_t wi = (w - w0) & 3u;
-				if (wi == 0) {
-					XE2_STORE()
-					if (lane < 8u) { s_in_mask[wv][lane] = g_mask; }
-					if (w + 4u < w1) { XE2_LOAD((sb + w + 4u) * 64u) XE2_LOAD_MASKS(w + 4u) }
-					__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
-				}
-				const u64 tokmask = s_in_mask[wv][wi];
-				if (tokmask == 0) { continue; }
-				const u64 matchmask = s_in_mask[wv][4u + wi];
-				const uint32_t off = s_in_off[wv][wi * 64u + lane], byte = s_in_byte[wv][wi * 64u + lane];
-				uint32_t L = s_in_len[wv][wi * 64u + lane];
-				if (L == 0xFFFFu) { L = __hip_atomic_load(&wfaru[sb + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-				const bool is_tok = (tokmask >> lane) & (u64)1, is_m = (matchmask >> lane) & (u64)1;
-				const u64 N = Nsb + (s_ecur[w] & 0x7FFFFFFFu), S = Ssb + s_eF[w];
-				const uint32_t Rpar = s_ecur[w] >> 31;
-				if (first) { first = false; lead_open = (N & 31u) != 0; }
-
-				const uint32_t nt = (uint32_t)__popcll(tokmask);
-				ntok_seg += nt;
-				const bool lng = is_m && L >= 7u;
-				const u64 longmask = __ballot(lng);
-				const bool even = !((Rpar + popc_below(longmask)) & 1u);
-				uint32_t sz = 0;
-				if (is_tok) { sz = !is_m ? 1u : 2u + (uint32_t)(lng && even) + (uint32_t)(L >= 22u) + (L >= 277u ? (L <= 0xFFFFu ? 2u : 6u) : 0u); }
-				const uint32_t incl = wave_incl_scan_add(sz);
-				const uint32_t wsum = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-				const uint32_t tb = popc_below(tokmask);
-				const uint32_t sh = (uint32_t)(N & 31u);
-				const uint32_t tq = sh + tb;
-				const u64 base = 4u * (N / 32u + 1u) + S;
-				const uint32_t posrel = 4u * (tq >> 5) + (incl - sz);
-				const uint32_t kdone = (sh + nt) >> 5;
-				const bool fits = base + 4u * kdone + wsum <= cap;
-				const u64 above = (longmask >> lane) >> 1;
-				const uint32_t nib = L >= 7u ? (L - 7u < 15u ? L - 7u : 15u) : 0u;
-				const uint32_t partner = above ? lane + 1u + ctz64(above) : lane;
-				const uint32_t pnib = (uint32_t)__shfl((int)nib, (int)partner, 64);
-				// the first long match of the segment with an odd rank completes a byte owned by an earlier segment: recorded
-				if (longmask && lead_nib == 0xFFu && !pend) {
-					const uint32_t fl = ctz64(longmask);
-					const uint32_t fn = (uint32_t)__builtin_amdgcn_readlane((int)nib, (int)fl);
-					if (Rpar & 1u) { lead_nib = fn | 0x100u; } else { lead_nib = 0x200u; }   // 0x1xx: odd first rank (nibble xx); 0x200: nothing to complete
-				}
-				if (fits) { xe_emit_tokens<false>(out, cap, base, posrel, is_tok, is_m, byte, off, L, lng, even, above != 0, nib, pnib, pend, pend_pos, pend_low, longmask, lane); }
-				else      { xe_emit_tokens<true >(out, cap, base, posrel, is_tok, is_m, byte, off, L, lng, even, above != 0, nib, pnib, pend, pend_pos, pend_low, longmask, lane); }
-				{
-					const uint32_t dst = is_tok ? tb : nt + (lane - tb);
-					const uint32_t fm = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (is_tok && is_m) ? 1 : 0);
-					const u64 M = __ballot(fm != 0);
-					u64 sm = __ballot(is_tok && (tq & 31u) == 0);
-					const u64 lo = (u64)facc | (M << sh);
-					const uint32_t hi = sh ? (uint32_t)(M >> (64u - sh)) : 0u;
-					u64 fp = fposc;
-					uint32_t wd = (uint32_t)lo;
-					bool started = tail_started;                            // does the word in `wd` start inside this segment?
-					if (sh == 0) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; sm &= sm - 1u; started = true; }
-					if (kdone >= 1u) {
-						if (started) { if (lane == 0) { xe_store32(out, cap, fp, __builtin_bitreverse32(wd), !fits); } }
-						else { lead_bits = wd; lead_done = true; }            // the word that was open at the segment's first token
-						wd = (uint32_t)(lo >> 32); started = false;
-						if (sm) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; sm &= sm - 1u; started = true; }
-						if (kdone >= 2u) {
-							if (lane == 0) { xe_store32(out, cap, fp, __builtin_bitreverse32(wd), !fits); }
-							wd = hi; started = false;
-							if (sm) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; started = true; }
-						}
-					}
-					facc = wd; fposc = fp; tail_started = started;
-				}
-				if (longmask) {
-					const uint32_t ll = 63u - (uint32_t)__builtin_clzll(longmask);
-					const uint32_t rl = Rpar + (uint32_t)__popcll(longmask) - 1u;
-					pend = !(rl & 1u);
-					if (pend) {
-						pend_pos = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)ll) + 2u;
-						pend_low = (uint32_t)__builtin_amdgcn_readlane((int)nib, (int)ll);
-					}
-				}
-			}
-			if (lane == 0) {
-				// lead: bits of the word that was open at my first token (complete or not); tail: the word open at my end
-				s_seam[wv][0] = lead_open ? (lead_done ? lead_bits : facc) : 0u;
-				s_seam[wv][1] = (lead_open && lead_done) ? 1u : 0u;
-				s_seam[wv][2] = (lead_open && !lead_done) ? 0u : facc;
-				s_seam[wv][3] = ((!lead_open || lead_done) && tail_started) ? 1u : 0u;
-				s_seam[wv][4] = lead_nib;
-				s_seam[wv][5] = pend ? 1u : 0u;
-				s_seam[wv][6] = pend_low;
-				s_seam[wv][7] = ntok_seg;
-				s_seam_pos[wv][0] = fposc; s_seam_pos[wv][1] = pend_pos;
-			}
-		} else if (lane == 0) { s_seam[wv][7] = 0; s_seam[wv][4] = 0xFFu; s_seam[wv][5] = 0; }
+		xe_emit_segment(lane, sb, w0, w1, n, cap, d, out, mlen3u, moffu, wtoku, wmatu, wfaru, s_ecur, s_eF, s_state[0], s_state[1],
+		                s_in_off[wv], s_in_len[wv], s_in_byte[wv], s_in_mask[wv], s_seam[wv], s_seam_pos[wv]);
 		XE2_T(4)
 		__syncthreads();
 		XE2_T(5)
@@ -725,21 +749,292 @@ __global__ __launch_bounds__(NW * 64u) void xpress_emit2_kernel(const uint8_t* _
 	}
 #undef XE2_LOAD
 #undef XE2_STORE
-#undef XE2_LOAD_MASKS
 }
 
-static int g_xpress_emit_mode = 0;                               // 0 = by batch size, 1 = one wave per unit, 2 / 3 = four / sixteen waves per unit (tests)
+// ===================================================================================================================
+// One block per 64 KiB super-block (mode 4): the same five phases, spread over four kernels, so that ONE long stream is
+// parsed and emitted by the whole GPU
+// ===================================================================================================================
+//   xe3_walk_kernel   (block per super-block, 16 waves): speculative walk of the 16 segments -- the super-block's own
+//                     entry is speculative too, except for the first one of a unit -- in-block seam repair, per-window
+//                     records to global memory, in-block scans for both parities of the long-match rank at its entry;
+//   xe3_fix_kernel    (wave per unit): repairs the seams BETWEEN super-blocks (re-walk until the recorded state is met,
+//                     then re-scan that super-block), prefix of tokens / long matches / bytes over the super-blocks;
+//   xe3_emit_kernel   (block per super-block): emission of its 16 segments, seam records to global memory;
+//   xe3_stitch_kernel (wave per unit): stitches every seam of the unit in order, final flag word, size, status.
+struct Xe3 {
+	u64* wtok; u64* wmat; uint32_t* wfar;                          // per window (exist for the in-block kernel too)
+	uint32_t* wecur; uint32_t* weF; uint32_t* wsum;               // per window: state after it, counts
+	uint32_t* wnr; uint32_t* ws0; uint32_t* ws1;                  // per window: tokens before | rank parity << 31 (relative to the super-block), bytes before (entry parity 0 / 1)
+	uint32_t* sbtot;                                              // per super-block: tokens, long matches, bytes (entry parity 0 / 1)
+	u64* sbpre;                                                   // per super-block: tokens, bytes, long matches before it
+	uint32_t* seam; u64* seampos;                                 // per super-block: 16 x 8, 16 x 2 (xe_emit_segment)
+};
+
+// scan of one super-block's windows (one wave): sum = nt | nlong << 8 | fixed bytes << 16 per window
+__device__ __forceinline__ void xe3_scan_sb(uint32_t lane, uint32_t nsb, const uint32_t* sum, uint32_t* wnr, uint32_t* ws0, uint32_t* ws1, uint32_t* tot)
+{
+	uint32_t nc = 0, rc = 0, sc0 = 0, sc1 = 0;
+	for (uint32_t b0 = 0; b0 < nsb; b0 += 64u) {
+		const uint32_t w = b0 + lane;
+		const uint32_t v = w < nsb ? sum[w] : 0u;
+		const uint32_t nt = v & 0xFFu, nl = (v >> 8) & 0xFFu, fsz = v >> 16;
+		const uint32_t ri = wave_incl_scan_add(nl);
+		const uint32_t rb = rc + ri - nl;                             // long matches before this window inside the super-block
+		const uint32_t z0 = fsz + (((rb & 1u) == 0) ? (nl + 1u) >> 1 : nl >> 1);   // entry parity 0: even relative ranks own a nibble byte
+		const uint32_t z1 = fsz + (((rb & 1u) != 0) ? (nl + 1u) >> 1 : nl >> 1);   // entry parity 1
+		const uint32_t ni = wave_incl_scan_add(nt), s0 = wave_incl_scan_add(z0), s1 = wave_incl_scan_add(z1);
+		if (w < nsb) { wnr[w] = (nc + ni - nt) | ((rb & 1u) << 31); ws0[w] = sc0 + s0 - z0; ws1[w] = sc1 + s1 - z1; }
+		nc += (uint32_t)__builtin_amdgcn_readlane((int)ni, 63); rc += (uint32_t)__builtin_amdgcn_readlane((int)ri, 63);
+		sc0 += (uint32_t)__builtin_amdgcn_readlane((int)s0, 63); sc1 += (uint32_t)__builtin_amdgcn_readlane((int)s1, 63);
+	}
+	if (lane == 0) { tot[0] = nc; tot[1] = rc; tot[2] = sc0; tot[3] = sc1; }
+}
+
+__global__ __launch_bounds__(1024) void xe3_walk_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, uint16_t* __restrict__ mlen3,
+                                                       const uint16_t* __restrict__ moff, Xe3 x)
+{
+	__shared__ uint32_t s_ecur[1024], s_eF[1024], s_sum[1024];
+	__shared__ uint16_t s_in_off[16][256];
+	__shared__ uint16_t s_in_len[16][256];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+	const uint32_t lc = blockIdx.x;
+	const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, lc);
+	const uint32_t k = lc - bt.chunk_prefix[u];
+	const u64 n = bt.in_len[u];
+	const uint8_t* __restrict__ d = d_in + bt.in_off[u];
+	const u64 mbase = (u64)bt.chunk_prefix[u] * 65536u;
+	uint16_t* __restrict__ mlen3u = mlen3 + mbase;
+	const uint16_t* __restrict__ moffu = moff + mbase;
+	const u64 gwu = mbase >> 6;                                    // first window record of the unit
+	const u64 end2 = n >= 2u ? n - 2u : 0u;
+	const u64 nwin = (n + 63u) >> 6;
+	const u64 sb = (u64)k * 1024u;
+	const uint32_t nsb = sb >= nwin ? 0u : ((nwin - sb < 1024u) ? (uint32_t)(nwin - sb) : 1024u);
+	const uint32_t w0 = wv * 64u, w1 = (w0 + 64u < nsb) ? w0 + 64u : nsb;
+	uint32_t g_off[4], g_len[4];
+#define XE3_LOAD(gb) { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
+		const u64 q_ = (gb) + (u64)k_ * 64u + lane; const u64 c_ = q_ < n ? q_ : n - 1u; g_off[k_] = moffu[c_]; g_len[k_] = mlen3u[c_]; } }
+#define XE3_STORE() { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
+		s_in_off[wv][k_ * 64 + lane] = (uint16_t)g_off[k_]; s_in_len[wv][k_ * 64 + lane] = (uint16_t)g_len[k_]; } }
+	if (w0 < w1) {                                                // ---- speculative walk of my segment
+		u64 cur = (sb + w0) * 64u, F = (cur < end2) ? cur : end2;   // a token starts here, Fill not lagging (exact for the unit's first position)
+		if (sb + w0 == 0) { F = 0; }
+		XE3_LOAD((sb + w0) * 64u)
+		for (uint32_t w = w0; w < w1; ++w) {
+			const uint32_t wi = (w - w0) & 3u;
+			if (wi == 0) {
+				XE3_STORE()
+				if (w + 4u < w1) { XE3_LOAD((sb + w + 4u) * 64u) }
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+			}
+			const u64 wbase = (sb + w) * 64u;
+			const uint32_t off = s_in_off[wv][wi * 64u + lane];
+			uint32_t L = s_in_len[wv][wi * 64u + lane];
+			u64 tm, mk;
+			xe_walk_window(d, n, end2, lane, wbase, cur, F, off, L, tm, mk);
+			xe_store_window(lane, wbase, n, sb + w, w, off, L, tm, mk, cur, F, end2, mlen3u, x.wtok + gwu, x.wmat + gwu, x.wfar + gwu, s_ecur, s_eF, s_sum);
+		}
+	}
+#undef XE3_LOAD
+#undef XE3_STORE
+	__syncthreads();
+	if (wv == 0) {                                                // ---- seams inside the super-block
+		for (uint32_t j = 1; j * 64u < nsb; ++j) {
+			const uint32_t a = j * 64u, b = (a + 64u < nsb) ? a + 64u : nsb;
+			const u64 wprev = (sb + a - 1u) * 64u;
+			const uint32_t pc = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ecur[a - 1u]), pf = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_eF[a - 1u]);
+			u64 cur = wprev + pc;
+			u64 F = (pf == 0xFFFFFFFFu) ? end2 : ((u64)pf << 13);
+			const u64 s0 = (sb + a) * 64u;
+			if (cur == s0 && F == ((s0 < end2) ? s0 : end2)) { continue; }
+			for (uint32_t w = a; w < b; ++w) {
+				const u64 wbase = (sb + w) * 64u;
+				const u64 q = wbase + lane, c = q < n ? q : n - 1u;
+				const uint32_t off = moffu[c];
+				uint32_t L = __hip_atomic_load(&mlen3u[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (L == 0xFFFFu) { L = __hip_atomic_load(&x.wfar[gwu + sb + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+				u64 tm, mk;
+				xe_walk_window(d, n, end2, lane, wbase, cur, F, off, L, tm, mk);
+				const uint32_t sc = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ecur[w]), sf = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_eF[w]);
+				xe_store_window(lane, wbase, n, sb + w, w, off, L, tm, mk, cur, F, end2, mlen3u, x.wtok + gwu, x.wmat + gwu, x.wfar + gwu, s_ecur, s_eF, s_sum);
+				if (xe_pack_cur(cur, wbase) == sc && xe_pack_F(F, end2) == sf) { break; }
+			}
+		}
+	}
+	__syncthreads();
+	for (uint32_t w = tid; w < nsb; w += 1024u) { x.wecur[gwu + sb + w] = s_ecur[w]; x.weF[gwu + sb + w] = s_eF[w]; x.wsum[gwu + sb + w] = s_sum[w]; }
+	if (wv == 0) { xe3_scan_sb(lane, nsb, s_sum, x.wnr + gwu + sb, x.ws0 + gwu + sb, x.ws1 + gwu + sb, x.sbtot + (u64)lc * 4u); }
+}
+
+__global__ __launch_bounds__(64) void xe3_fix_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, uint16_t* __restrict__ mlen3,
+                                                    const uint16_t* __restrict__ moff, Xe3 x, u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
+{
+	const uint32_t lane = threadIdx.x;
+	const uint32_t u = blockIdx.x;
+	const u64 n = bt.in_len[u];
+	const uint8_t* __restrict__ d = d_in + bt.in_off[u];
+	const u64 mbase = (u64)bt.chunk_prefix[u] * 65536u;
+	uint16_t* __restrict__ mlen3u = mlen3 + mbase;
+	const uint16_t* __restrict__ moffu = moff + mbase;
+	const u64 gwu = mbase >> 6;
+	const u64 end2 = n >= 2u ? n - 2u : 0u;
+	const u64 nwin = (n + 63u) >> 6;
+	const uint32_t nk = bt.chunk_prefix[u + 1] - bt.chunk_prefix[u];
+	u64 N = 0, S = 0, R = 0;
+	for (uint32_t k = 0; k < nk; ++k) {
+		const uint32_t lc = bt.chunk_prefix[u] + k;
+		const u64 sb = (u64)k * 1024u;
+		const uint32_t nsb = sb >= nwin ? 0u : ((nwin - sb < 1024u) ? (uint32_t)(nwin - sb) : 1024u);
+		if (k > 0 && nsb) {                                          // seam between super-blocks k-1 and k
+			const u64 wprev = (sb - 1u) * 64u;
+			const uint32_t pc = __hip_atomic_load(&x.wecur[gwu + sb - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t pf = __hip_atomic_load(&x.weF[gwu + sb - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			u64 cur = wprev + pc;
+			u64 F = (pf == 0xFFFFFFFFu) ? end2 : ((u64)pf << 13);
+			const u64 s0 = sb * 64u;
+			if (!(cur == s0 && F == ((s0 < end2) ? s0 : end2))) {
+				for (uint32_t w = 0; w < nsb; ++w) {
+					const u64 wbase = (sb + w) * 64u;
+					const u64 q = wbase + lane, c = q < n ? q : n - 1u;
+					const uint32_t off = moffu[c];
+					uint32_t L = __hip_atomic_load(&mlen3u[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (L == 0xFFFFu) { L = __hip_atomic_load(&x.wfar[gwu + sb + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+					u64 tm, mk;
+					xe_walk_window(d, n, end2, lane, wbase, cur, F, off, L, tm, mk);
+					const uint32_t sc = __hip_atomic_load(&x.wecur[gwu + sb + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					const uint32_t sf = __hip_atomic_load(&x.weF[gwu + sb + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					xe_store_window(lane, wbase, n, sb + w, w, off, L, tm, mk, cur, F, end2, mlen3u, x.wtok + gwu, x.wmat + gwu, x.wfar + gwu,
+					                x.wecur + gwu + sb, x.weF + gwu + sb, x.wsum + gwu + sb);
+					if (xe_pack_cur(cur, wbase) == sc && xe_pack_F(F, end2) == sf) { break; }
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+				xe3_scan_sb(lane, nsb, x.wsum + gwu + sb, x.wnr + gwu + sb, x.ws0 + gwu + sb, x.ws1 + gwu + sb, x.sbtot + (u64)lc * 4u);
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			}
+		}
+		if (lane == 0) { x.sbpre[(u64)lc * 3u] = N; x.sbpre[(u64)lc * 3u + 1u] = S; x.sbpre[(u64)lc * 3u + 2u] = R; }
+		const uint32_t t0 = __hip_atomic_load(&x.sbtot[(u64)lc * 4u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t t1 = __hip_atomic_load(&x.sbtot[(u64)lc * 4u + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t t2 = __hip_atomic_load(&x.sbtot[(u64)lc * 4u + 2u + (uint32_t)(R & 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (nsb) { N += t0; S += t2; R += t1; }
+	}
+	if (lane == 0) {
+		const u64 total = 4u * (N / 32u + 1u) + S;
+		const bool ok = total <= bt.out_cap[u];
+		d_out_len[u] = ok ? total : 0;
+		d_status[u] = ok ? 0 : -5;
+	}
+}
+
+__global__ __launch_bounds__(1024) void xe3_emit_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, const uint16_t* __restrict__ mlen3,
+                                                       const uint16_t* __restrict__ moff, Xe3 x, uint8_t* __restrict__ d_out)
+{
+	__shared__ uint32_t s_nr[1024], s_sr[1024];
+	__shared__ uint16_t s_in_off[16][256];
+	__shared__ uint16_t s_in_len[16][256];
+	__shared__ uint8_t  s_in_byte[16][256];
+	__shared__ u64      s_in_mask[16][8];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+	const uint32_t lc = blockIdx.x;
+	const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, lc);
+	const uint32_t k = lc - bt.chunk_prefix[u];
+	const u64 n = bt.in_len[u];
+	const u64 cap = bt.out_cap[u];
+	const uint8_t* __restrict__ d = d_in + bt.in_off[u];
+	uint8_t* __restrict__ out = d_out + bt.out_off[u];
+	const u64 mbase = (u64)bt.chunk_prefix[u] * 65536u;
+	const u64 gwu = mbase >> 6;
+	const u64 nwin = (n + 63u) >> 6;
+	const u64 sb = (u64)k * 1024u;
+	const uint32_t nsb = sb >= nwin ? 0u : ((nwin - sb < 1024u) ? (uint32_t)(nwin - sb) : 1024u);
+	const u64 Nsb = x.sbpre[(u64)lc * 3u], Ssb = x.sbpre[(u64)lc * 3u + 1u];
+	const uint32_t par = (uint32_t)(x.sbpre[(u64)lc * 3u + 2u] & 1u);     // rank parity of the long matches at the super-block's entry
+	for (uint32_t w = tid; w < nsb; w += 1024u) {
+		const uint32_t v = x.wnr[gwu + sb + w];
+		s_nr[w] = v ^ (par << 31);
+		s_sr[w] = par ? x.ws1[gwu + sb + w] : x.ws0[gwu + sb + w];
+	}
+	__syncthreads();
+	const uint32_t w0 = wv * 64u, w1 = (w0 + 64u < nsb) ? w0 + 64u : nsb;
+	xe_emit_segment(lane, sb, w0, w1, n, cap, d, out, mlen3 + mbase, moff + mbase, x.wtok + gwu, x.wmat + gwu, x.wfar + gwu, s_nr, s_sr, Nsb, Ssb,
+	                s_in_off[wv], s_in_len[wv], s_in_byte[wv], s_in_mask[wv], x.seam + ((u64)lc * 16u + wv) * 8u, x.seampos + ((u64)lc * 16u + wv) * 2u);
+}
+
+__global__ __launch_bounds__(64) void xe3_stitch_kernel(BatchTables bt, Xe3 x, uint8_t* __restrict__ d_out)
+{
+	const uint32_t lane = threadIdx.x;
+	const uint32_t u = blockIdx.x;
+	const u64 cap = bt.out_cap[u];
+	uint8_t* __restrict__ out = d_out + bt.out_off[u];
+	const uint32_t nk = bt.chunk_prefix[u + 1] - bt.chunk_prefix[u];
+	uint32_t g_acc = 0; u64 g_fpos = 0; bool g_pend = false; u64 g_pend_pos = 0; uint32_t g_pend_low = 0;
+	for (uint32_t k = 0; k < nk; ++k) {
+		const u64 sbase = ((u64)bt.chunk_prefix[u] + k) * 16u;
+		// one segment per lane: its record travels in registers, the stitching itself is serial
+		uint32_t r[8]; u64 rp[2];
+		#pragma unroll
+		for (int i = 0; i < 8; ++i) { r[i] = lane < 16u ? x.seam[(sbase + lane) * 8u + i] : 0u; }
+		rp[0] = lane < 16u ? x.seampos[(sbase + lane) * 2u] : 0; rp[1] = lane < 16u ? x.seampos[(sbase + lane) * 2u + 1u] : 0;
+		for (uint32_t j = 0; j < 16u; ++j) {
+			uint32_t q[8];
+			#pragma unroll
+			for (int i = 0; i < 8; ++i) { q[i] = (uint32_t)__builtin_amdgcn_readlane((int)r[i], (int)j); }
+			const u64 p0 = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rp[0] >> 32), (int)j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rp[0], (int)j);
+			const u64 p1 = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rp[1] >> 32), (int)j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rp[1], (int)j);
+			if (q[7] == 0) { continue; }                             // no token starts in this segment
+			if (q[1]) {                                              // the open word was completed inside segment j
+				const uint32_t wdv = g_acc | q[0];
+				if (lane == 0) { xe_store32(out, cap, g_fpos, __builtin_bitreverse32(wdv), true); }
+				g_acc = 0;
+			} else { g_acc |= q[0]; }
+			if (q[3]) { g_acc = q[2]; g_fpos = p0; }
+			const uint32_t ln = q[4];
+			if (ln & 0x100u) { if (g_pend && lane == 0) { put8(out, cap, g_pend_pos, g_pend_low | ((ln & 0xFu) << 4)); } g_pend = false; }
+			if (ln != 0xFFu) { g_pend = q[5] != 0; g_pend_pos = p1; g_pend_low = q[6]; }
+		}
+	}
+	// final flag word (:343-344); size and status were written by xe3_fix_kernel
+	if (lane == 0) {
+		u64 Nall = 0, Sall = 0;
+		if (nk) {                                                   // totals = before the last super-block + its own
+			const uint32_t lcl = bt.chunk_prefix[u + 1] - 1u;
+			Nall = x.sbpre[(u64)lcl * 3u] + x.sbtot[(u64)lcl * 4u];
+			Sall = x.sbpre[(u64)lcl * 3u + 1u] + x.sbtot[(u64)lcl * 4u + 2u + (uint32_t)(x.sbpre[(u64)lcl * 3u + 2u] & 1u)];
+		}
+		const uint32_t cnt = (uint32_t)(Nall & 31u);
+		const u64 total = 4u * (Nall / 32u + 1u) + Sall;
+		uint32_t wvv; u64 fp;
+		if (cnt) { wvv = __builtin_bitreverse32(g_acc) | ((1u << (32u - cnt)) - 1u); fp = g_fpos; }
+		else { wvv = 0xFFFFFFFFu; fp = total - 4u; }
+		put8(out, cap, fp, wvv); put8(out, cap, fp + 1u, wvv >> 8); put8(out, cap, fp + 2u, wvv >> 16); put8(out, cap, fp + 3u, wvv >> 24);
+	}
+}
+
+static int g_xpress_emit_mode = 0;                               // 0 = by batch size, 1 = one wave per unit, 2 / 3 = 4 / 16 waves per unit, 4 = a block per super-block (tests)
 void launch_xpress_emit(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* mlen3, const uint16_t* moff,
-                        u64* wtok, u64* wmat, uint32_t* wfar, uint8_t* d_out, u64* d_out_len, int32_t* d_status)
+                        const XpressWinBufs& wb, uint8_t* d_out, u64* d_out_len, int32_t* d_status)
 {
 	if (bt.n_units == 0) { return; }
-	// One wave per unit is the better use of a full GPU (the multi-wave kernel spends twice the wave-cycles); with few
-	// units the 4- or 16-wave kernel cuts the latency of each.
-	const int mode = g_xpress_emit_mode ? g_xpress_emit_mode : (bt.n_units <= 64u ? 3 : (bt.n_units <= 1024u ? 2 : 1));
+	// One wave per unit is the better use of a full GPU (the multi-wave kernels spend twice the wave-cycles); with few
+	// units the 4-wave in-block kernel cuts the latency of each, and with very few the super-blocks of a unit are
+	// spread over the GPU (four kernels).
+	const int mode = g_xpress_emit_mode ? g_xpress_emit_mode : (bt.n_units <= 64u ? 4 : (bt.n_units <= 1024u ? 2 : 1));
+	u64* wtok = wb.wtok; u64* wmat = wb.wmat; uint32_t* wfar = wb.wfar;
 	if (mode == 1) { hipLaunchKernelGGL(xpress_emit_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, mlen3, moff, d_out, d_out_len, d_status); }
 	else if (mode == 2) { hipLaunchKernelGGL(xpress_emit2_kernel<4u>, dim3(bt.n_units), dim3(256), 0, st, d_in, bt, mlen3, moff, wtok, wmat, wfar, d_out, d_out_len, d_status); }
-	else { hipLaunchKernelGGL(xpress_emit2_kernel<16u>, dim3(bt.n_units), dim3(1024), 0, st, d_in, bt, mlen3, moff, wtok, wmat, wfar, d_out, d_out_len, d_status); }
+	else if (mode == 3) { hipLaunchKernelGGL(xpress_emit2_kernel<16u>, dim3(bt.n_units), dim3(1024), 0, st, d_in, bt, mlen3, moff, wtok, wmat, wfar, d_out, d_out_len, d_status); }
+	else {
+		Xe3 x = { wb.wtok, wb.wmat, wb.wfar, wb.wecur, wb.weF, wb.wsum, wb.wnr, wb.ws0, wb.ws1, wb.sbtot, wb.sbpre, wb.seam, wb.seampos };
+		if (bt.n_chunks) { hipLaunchKernelGGL(xe3_walk_kernel, dim3(bt.n_chunks), dim3(1024), 0, st, d_in, bt, mlen3, moff, x); }
+		hipLaunchKernelGGL(xe3_fix_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, mlen3, moff, x, d_out_len, d_status);
+		if (bt.n_chunks) { hipLaunchKernelGGL(xe3_emit_kernel, dim3(bt.n_chunks), dim3(1024), 0, st, d_in, bt, mlen3, moff, x, d_out); }
+		hipLaunchKernelGGL(xe3_stitch_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, x, d_out);
+	}
 }
 void set_xpress_emit_mode(int mode) { g_xpress_emit_mode = mode; }
+int get_xpress_emit_mode() { return g_xpress_emit_mode; }
 
 } // namespace msc

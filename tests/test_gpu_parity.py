@@ -173,7 +173,7 @@ def test_lds_atomics_are_served_in_lane_order(gpu_ctx, nkeys):
     assert bad == 0, "%d lanes were served out of lane order" % bad
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
 def test_xpress_emit_kernels_agree(oracle, gpu_ctx, mode):
     """The Xpress parse/emit stage has two kernels (one wave per unit / four waves per unit with speculative segments and
     seam repair, 4 or 16 waves); the library picks by batch size. Both must produce the reference's bytes: edge families, a multi-
