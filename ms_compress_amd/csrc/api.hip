@@ -207,7 +207,7 @@ MSCompStatus mscomp_amd_plan_create(mscomp_amd_ctx* c, MSCompFormat format, size
 			ok = c->wtok.reserve(nw * 8) && c->wmat.reserve(nw * 8) && c->wfar.reserve(nw * 4);
 			if (ok && (p->n_units <= 64u || get_xpress_emit_mode() == 4)) {    // the block-per-super-block kernels (few units)
 				const size_t ns = (size_t)p->n_chunks + 1;
-				ok = c->wrec.reserve(nw * 6 * 4) && c->sbrec.reserve(ns * (16 + 24 + 16 * 8 * 4 + 16 * 2 * 8));
+				ok = c->wrec.reserve(nw * 6 * 4) && c->sbrec.reserve(ns * (16 + 24 + 16 * 8 * 4 + 16 * 2 * 8 + 8));
 			}
 		}
 	}
@@ -242,7 +242,8 @@ static XpressWinBufs xpress_win_bufs(mscomp_amd_ctx* c, uint32_t n_chunks)
 		b.sbpre = reinterpret_cast<u64*>(q); q += ns * 24;
 		b.seampos = reinterpret_cast<u64*>(q); q += ns * 16 * 2 * 8;
 		b.sbtot = reinterpret_cast<uint32_t*>(q); q += ns * 16;
-		b.seam = reinterpret_cast<uint32_t*>(q);
+		b.seam = reinterpret_cast<uint32_t*>(q); q += ns * 16 * 8 * 4;
+		b.used = reinterpret_cast<uint32_t*>(q);
 	}
 	return b;
 }

@@ -20,7 +20,7 @@ void set_xpress_emit_mode(int mode);
 int get_xpress_emit_mode();
 // per-window / per-super-block records of the Xpress parse (see xpress_emit.hip); the last 10 only for the block-per-super-block kernels
 struct XpressWinBufs { u64* wtok; u64* wmat; uint32_t* wfar; uint32_t* wecur; uint32_t* weF; uint32_t* wsum; uint32_t* wnr; uint32_t* ws0; uint32_t* ws1;
-                       uint32_t* sbtot; u64* sbpre; uint32_t* seam; u64* seampos; };
+                       uint32_t* sbtot; u64* sbpre; uint32_t* seam; u64* seampos; uint32_t* used; };
 void launch_xpress_emit(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* mlen3, const uint16_t* moff,
                         const XpressWinBufs& wb, uint8_t* d_out, u64* d_out_len, int32_t* d_status);
 

@@ -758,8 +758,10 @@ __global__ __launch_bounds__(NW * 64u) void xpress_emit2_kernel(const uint8_t* _
 //   xe3_walk_kernel   (block per super-block, 16 waves): speculative walk of the 16 segments -- the super-block's own
 //                     entry is speculative too, except for the first one of a unit -- in-block seam repair, per-window
 //                     records to global memory, in-block scans for both parities of the long-match rank at its entry;
-//   xe3_fix_kernel    (wave per unit): repairs the seams BETWEEN super-blocks (re-walk until the recorded state is met,
-//                     then re-scan that super-block), prefix of tokens / long matches / bytes over the super-blocks;
+//   xe3_seam_kernel   (wave per super-block): repairs the seam in FRONT of its super-block (re-walk until the recorded
+//                     state is met, then re-scan the super-block);
+//   xe3_fix_kernel    (wave per unit): cascades the rare repair that moved a super-block's end state, then the prefix
+//                     of tokens / long matches / bytes over the super-blocks, 64 per step;
 //   xe3_emit_kernel   (block per super-block): emission of its 16 segments, seam records to global memory;
 //   xe3_stitch_kernel (wave per unit): stitches every seam of the unit in order, final flag word, size, status.
 struct Xe3 {
@@ -867,59 +869,121 @@ __global__ __launch_bounds__(1024) void xe3_walk_kernel(const uint8_t* __restric
 	if (wv == 0) { xe3_scan_sb(lane, nsb, s_sum, x.wnr + gwu + sb, x.ws0 + gwu + sb, x.ws1 + gwu + sb, x.sbtot + (u64)lc * 4u); }
 }
 
+// Repair of the seam in front of super-block k of a unit (one wave): re-walk from the true entry state until the state
+// after a window equals the recorded one, then re-scan the super-block. Returns without touching anything when the
+// speculation was right. used[2 lc], used[2 lc + 1] remember the entry state this was decided on.
+__device__ __forceinline__ void xe3_repair_seam(const uint8_t* __restrict__ d, u64 n, u64 end2, uint32_t lane, uint32_t lc, u64 sb, uint32_t nsb,
+                                                uint16_t* __restrict__ mlen3u, const uint16_t* __restrict__ moffu, u64 gwu, const Xe3& x, uint32_t* __restrict__ used)
+{
+	const u64 wprev = (sb - 1u) * 64u;
+	const uint32_t pc = __hip_atomic_load(&x.wecur[gwu + sb - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const uint32_t pf = __hip_atomic_load(&x.weF[gwu + sb - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (lane == 0) { used[2u * lc] = pc; used[2u * lc + 1u] = pf; }
+	u64 cur = wprev + pc;
+	u64 F = (pf == 0xFFFFFFFFu) ? end2 : ((u64)pf << 13);
+	const u64 s0 = sb * 64u;
+	if (cur == s0 && F == ((s0 < end2) ? s0 : end2)) { return; }  // the speculation was right
+	for (uint32_t w = 0; w < nsb; ++w) {
+		const u64 wbase = (sb + w) * 64u;
+		const u64 q = wbase + lane, c = q < n ? q : n - 1u;
+		const uint32_t off = moffu[c];
+		uint32_t L = __hip_atomic_load(&mlen3u[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (L == 0xFFFFu) { L = __hip_atomic_load(&x.wfar[gwu + sb + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+		u64 tm, mk;
+		xe_walk_window(d, n, end2, lane, wbase, cur, F, off, L, tm, mk);
+		const uint32_t sc = __hip_atomic_load(&x.wecur[gwu + sb + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t sf = __hip_atomic_load(&x.weF[gwu + sb + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		xe_store_window(lane, wbase, n, sb + w, w, off, L, tm, mk, cur, F, end2, mlen3u, x.wtok + gwu, x.wmat + gwu, x.wfar + gwu,
+		                x.wecur + gwu + sb, x.weF + gwu + sb, x.wsum + gwu + sb);
+		if (xe_pack_cur(cur, wbase) == sc && xe_pack_F(F, end2) == sf) { break; }   // re-synchronised
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	xe3_scan_sb(lane, nsb, x.wsum + gwu + sb, x.wnr + gwu + sb, x.ws0 + gwu + sb, x.ws1 + gwu + sb, x.sbtot + (u64)lc * 4u);
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// all seams between super-blocks at once, one wave each (a repair that does not re-synchronise inside its super-block
+// changes that super-block's end state: xe3_fix_kernel notices and cascades)
+__global__ __launch_bounds__(64) void xe3_seam_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, uint16_t* __restrict__ mlen3,
+                                                     const uint16_t* __restrict__ moff, Xe3 x, uint32_t* __restrict__ used)
+{
+	const uint32_t lane = threadIdx.x;
+	const uint32_t lc = blockIdx.x;
+	const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, lc);
+	const uint32_t k = lc - bt.chunk_prefix[u];
+	if (k == 0) { return; }
+	const u64 n = bt.in_len[u];
+	const u64 mbase = (u64)bt.chunk_prefix[u] * 65536u;
+	const u64 nwin = (n + 63u) >> 6;
+	const u64 sb = (u64)k * 1024u;
+	const uint32_t nsb = sb >= nwin ? 0u : ((nwin - sb < 1024u) ? (uint32_t)(nwin - sb) : 1024u);
+	if (nsb == 0) { return; }
+	xe3_repair_seam(d_in + bt.in_off[u], n, n >= 2u ? n - 2u : 0u, lane, lc, sb, nsb, mlen3 + mbase, moff + mbase, mbase >> 6, x, used);
+}
+
+// per unit (one wave): cascade check of the seams (serial, but it only reads two words per super-block unless a repair
+// moved an end state), then the prefix of tokens / long matches / bytes over the super-blocks, 64 of them per step
 __global__ __launch_bounds__(64) void xe3_fix_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, uint16_t* __restrict__ mlen3,
-                                                    const uint16_t* __restrict__ moff, Xe3 x, u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
+                                                    const uint16_t* __restrict__ moff, Xe3 x, uint32_t* __restrict__ used,
+                                                    u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
 {
 	const uint32_t lane = threadIdx.x;
 	const uint32_t u = blockIdx.x;
 	const u64 n = bt.in_len[u];
 	const uint8_t* __restrict__ d = d_in + bt.in_off[u];
 	const u64 mbase = (u64)bt.chunk_prefix[u] * 65536u;
-	uint16_t* __restrict__ mlen3u = mlen3 + mbase;
-	const uint16_t* __restrict__ moffu = moff + mbase;
 	const u64 gwu = mbase >> 6;
 	const u64 end2 = n >= 2u ? n - 2u : 0u;
 	const u64 nwin = (n + 63u) >> 6;
-	const uint32_t nk = bt.chunk_prefix[u + 1] - bt.chunk_prefix[u];
-	u64 N = 0, S = 0, R = 0;
-	for (uint32_t k = 0; k < nk; ++k) {
-		const uint32_t lc = bt.chunk_prefix[u] + k;
-		const u64 sb = (u64)k * 1024u;
-		const uint32_t nsb = sb >= nwin ? 0u : ((nwin - sb < 1024u) ? (uint32_t)(nwin - sb) : 1024u);
-		if (k > 0 && nsb) {                                          // seam between super-blocks k-1 and k
-			const u64 wprev = (sb - 1u) * 64u;
+	const uint32_t lc0 = bt.chunk_prefix[u], nk = bt.chunk_prefix[u + 1] - lc0;
+	// ---- cascade check: does every seam still see the end state it was repaired against?
+	for (uint32_t k0 = 1; k0 < nk; k0 += 64u) {
+		const uint32_t k = k0 + lane;
+		bool bad = false;
+		if (k < nk && (u64)k * 1024u < nwin) {
+			const u64 sb = (u64)k * 1024u;
 			const uint32_t pc = __hip_atomic_load(&x.wecur[gwu + sb - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			const uint32_t pf = __hip_atomic_load(&x.weF[gwu + sb - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			u64 cur = wprev + pc;
-			u64 F = (pf == 0xFFFFFFFFu) ? end2 : ((u64)pf << 13);
-			const u64 s0 = sb * 64u;
-			if (!(cur == s0 && F == ((s0 < end2) ? s0 : end2))) {
-				for (uint32_t w = 0; w < nsb; ++w) {
-					const u64 wbase = (sb + w) * 64u;
-					const u64 q = wbase + lane, c = q < n ? q : n - 1u;
-					const uint32_t off = moffu[c];
-					uint32_t L = __hip_atomic_load(&mlen3u[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					if (L == 0xFFFFu) { L = __hip_atomic_load(&x.wfar[gwu + sb + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-					u64 tm, mk;
-					xe_walk_window(d, n, end2, lane, wbase, cur, F, off, L, tm, mk);
-					const uint32_t sc = __hip_atomic_load(&x.wecur[gwu + sb + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					const uint32_t sf = __hip_atomic_load(&x.weF[gwu + sb + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					xe_store_window(lane, wbase, n, sb + w, w, off, L, tm, mk, cur, F, end2, mlen3u, x.wtok + gwu, x.wmat + gwu, x.wfar + gwu,
-					                x.wecur + gwu + sb, x.weF + gwu + sb, x.wsum + gwu + sb);
-					if (xe_pack_cur(cur, wbase) == sc && xe_pack_F(F, end2) == sf) { break; }
-				}
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-				xe3_scan_sb(lane, nsb, x.wsum + gwu + sb, x.wnr + gwu + sb, x.ws0 + gwu + sb, x.ws1 + gwu + sb, x.sbtot + (u64)lc * 4u);
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			bad = pc != used[2u * (lc0 + k)] || pf != used[2u * (lc0 + k) + 1u];
+		}
+		u64 bm = __ballot(bad);
+		while (bm) {                                                // rare: repair in order; a repair may move the next seam too
+			uint32_t kk = k0 + ctz64(bm);
+			bm &= bm - 1u;
+			for (;;) {
+				const u64 sb = (u64)kk * 1024u;
+				const uint32_t nsb = (nwin - sb < 1024u) ? (uint32_t)(nwin - sb) : 1024u;
+				xe3_repair_seam(d, n, end2, lane, lc0 + kk, sb, nsb, mlen3 + mbase, moff + mbase, gwu, x, used);
+				++kk;
+				if (kk >= nk || (u64)kk * 1024u >= nwin) { break; }
+				const u64 sb2 = (u64)kk * 1024u;
+				const uint32_t pc = __hip_atomic_load(&x.wecur[gwu + sb2 - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const uint32_t pf = __hip_atomic_load(&x.weF[gwu + sb2 - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const uint32_t uc = __hip_atomic_load(&used[2u * (lc0 + kk)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const uint32_t uf = __hip_atomic_load(&used[2u * (lc0 + kk) + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (pc == uc && pf == uf) { break; }
+				if (kk < k0 + 64u) { bm &= ~(((u64)1) << (kk - k0)); }
 			}
 		}
-		if (lane == 0) { x.sbpre[(u64)lc * 3u] = N; x.sbpre[(u64)lc * 3u + 1u] = S; x.sbpre[(u64)lc * 3u + 2u] = R; }
-		const uint32_t t0 = __hip_atomic_load(&x.sbtot[(u64)lc * 4u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		const uint32_t t1 = __hip_atomic_load(&x.sbtot[(u64)lc * 4u + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		const uint32_t t2 = __hip_atomic_load(&x.sbtot[(u64)lc * 4u + 2u + (uint32_t)(R & 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (nsb) { N += t0; S += t2; R += t1; }
+	}
+	// ---- prefix over the super-blocks (lane = super-block)
+	u64 N = 0, S = 0, R = 0;
+	for (uint32_t k0 = 0; k0 < nk; k0 += 64u) {
+		const uint32_t k = k0 + lane;
+		const bool in = k < nk && (u64)k * 1024u < nwin;
+		const u64 ti = (u64)(lc0 + k) * 4u;
+		const uint32_t t0 = in ? __hip_atomic_load(&x.sbtot[ti], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+		const uint32_t t1 = in ? __hip_atomic_load(&x.sbtot[ti + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+		const uint32_t z0 = in ? __hip_atomic_load(&x.sbtot[ti + 2u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+		const uint32_t z1 = in ? __hip_atomic_load(&x.sbtot[ti + 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+		const uint32_t ri = wave_incl_scan_add(t1);
+		const u64 Rb = R + (ri - t1);                                // long matches before my super-block
+		const uint32_t sz = (Rb & 1u) ? z1 : z0;
+		const uint32_t ni = wave_incl_scan_add(t0), si = wave_incl_scan_add(sz);
+		if (k < nk) { x.sbpre[(u64)(lc0 + k) * 3u] = N + (ni - t0); x.sbpre[(u64)(lc0 + k) * 3u + 1u] = S + (si - sz); x.sbpre[(u64)(lc0 + k) * 3u + 2u] = Rb; }
+		N += (uint32_t)__builtin_amdgcn_readlane((int)ni, 63); S += (uint32_t)__builtin_amdgcn_readlane((int)si, 63); R += (uint32_t)__builtin_amdgcn_readlane((int)ri, 63);
 	}
 	if (lane == 0) {
 		const u64 total = 4u * (N / 32u + 1u) + S;
@@ -970,20 +1034,63 @@ __global__ __launch_bounds__(64) void xe3_stitch_kernel(BatchTables bt, Xe3 x, u
 	const u64 cap = bt.out_cap[u];
 	uint8_t* __restrict__ out = d_out + bt.out_off[u];
 	const uint32_t nk = bt.chunk_prefix[u + 1] - bt.chunk_prefix[u];
+	const u64 seg0 = (u64)bt.chunk_prefix[u] * 16u, nseg = (u64)nk * 16u;
 	uint32_t g_acc = 0; u64 g_fpos = 0; bool g_pend = false; u64 g_pend_pos = 0; uint32_t g_pend_low = 0;
-	for (uint32_t k = 0; k < nk; ++k) {
-		const u64 sbase = ((u64)bt.chunk_prefix[u] + k) * 16u;
-		// one segment per lane: its record travels in registers, the stitching itself is serial
-		uint32_t r[8]; u64 rp[2];
+	// 64 segments (4 super-blocks) per step, lane = segment. A segment's word-in-progress state after it is either a
+	// reset (it completed the open word and / or opened one of its own) or a pass-through that only ORs a few bits in
+	// (fewer than 32 tokens in 64 windows); likewise its pending-nibble state is a reset when it has long matches. With no
+	// OR-ing pass-through in the step every seam only needs the nearest reset before it: one shuffle. Otherwise: serial.
+	for (u64 sgb = 0; sgb < nseg; sgb += 64u) {
+		const bool in = sgb + lane < nseg;
+		uint32_t r[8]; u64 rp0 = 0, rp1 = 0;
 		#pragma unroll
-		for (int i = 0; i < 8; ++i) { r[i] = lane < 16u ? x.seam[(sbase + lane) * 8u + i] : 0u; }
-		rp[0] = lane < 16u ? x.seampos[(sbase + lane) * 2u] : 0; rp[1] = lane < 16u ? x.seampos[(sbase + lane) * 2u + 1u] : 0;
-		for (uint32_t j = 0; j < 16u; ++j) {
+		for (int i = 0; i < 8; ++i) { r[i] = in ? x.seam[(seg0 + sgb + lane) * 8u + i] : 0u; }
+		if (in) { rp0 = x.seampos[(seg0 + sgb + lane) * 2u]; rp1 = x.seampos[(seg0 + sgb + lane) * 2u + 1u]; }
+		const bool nonempty = in && r[7] != 0;
+		const bool wreset = nonempty && (r[1] != 0 || r[3] != 0);
+		const bool wpass = nonempty && !wreset;
+		const bool nreset = nonempty && r[4] != 0xFFu;
+		if (__ballot(wpass && r[0] != 0) == 0) {
+			const u64 below = (((u64)1) << lane) - 1u;
+			// word state in front of me
+			const u64 wm = __ballot(wreset) & below;
+			const uint32_t wp = wm ? 63u - (uint32_t)__builtin_clzll(wm) : 0u;
+			const uint32_t a_after = r[3] ? r[2] : 0u;                 // my state after me if I am a reset
+			uint32_t acc_in = (uint32_t)__shfl((int)a_after, (int)wp, 64);
+			u64 fpos_in = ((u64)(uint32_t)__shfl((int)(uint32_t)(rp0 >> 32), (int)wp, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)rp0, (int)wp, 64);
+			const uint32_t pv = (uint32_t)__shfl((int)r[3], (int)wp, 64);    // did that reset open a word (else the slot is not needed: acc is 0 and the next word opens later)
+			if (!wm) { acc_in = g_acc; fpos_in = g_fpos; } else if (!pv) { acc_in = 0; }
+			if (nonempty && r[1]) { xe_store32(out, cap, fpos_in, __builtin_bitreverse32(acc_in | r[0]), true); }
+			// pending nibble in front of me
+			const u64 nm = __ballot(nreset) & below;
+			const uint32_t np = nm ? 63u - (uint32_t)__builtin_clzll(nm) : 0u;
+			uint32_t pend_in = (uint32_t)__shfl((int)r[5], (int)np, 64), low_in = (uint32_t)__shfl((int)r[6], (int)np, 64);
+			u64 ppos_in = ((u64)(uint32_t)__shfl((int)(uint32_t)(rp1 >> 32), (int)np, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)rp1, (int)np, 64);
+			if (!nm) { pend_in = g_pend ? 1u : 0u; low_in = g_pend_low; ppos_in = g_pend_pos; }
+			if (nonempty && (r[4] & 0x100u) && pend_in) { put8(out, cap, ppos_in, low_in | ((r[4] & 0xFu) << 4)); }
+			// carry out of the step
+			const u64 wall = __ballot(wreset);
+			if (wall) {
+				const uint32_t l = 63u - (uint32_t)__builtin_clzll(wall);
+				const uint32_t v3 = (uint32_t)__builtin_amdgcn_readlane((int)r[3], (int)l);
+				g_acc = v3 ? (uint32_t)__builtin_amdgcn_readlane((int)r[2], (int)l) : 0u;
+				if (v3) { g_fpos = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rp0 >> 32), (int)l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rp0, (int)l); }
+			}
+			const u64 nall = __ballot(nreset);
+			if (nall) {
+				const uint32_t l = 63u - (uint32_t)__builtin_clzll(nall);
+				g_pend = __builtin_amdgcn_readlane((int)r[5], (int)l) != 0;
+				g_pend_low = (uint32_t)__builtin_amdgcn_readlane((int)r[6], (int)l);
+				g_pend_pos = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rp1 >> 32), (int)l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rp1, (int)l);
+			}
+			continue;
+		}
+		for (uint32_t j = 0; j < 64u; ++j) {                       // serial: a word spans more than two segments here
 			uint32_t q[8];
 			#pragma unroll
 			for (int i = 0; i < 8; ++i) { q[i] = (uint32_t)__builtin_amdgcn_readlane((int)r[i], (int)j); }
-			const u64 p0 = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rp[0] >> 32), (int)j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rp[0], (int)j);
-			const u64 p1 = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rp[1] >> 32), (int)j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rp[1], (int)j);
+			const u64 p0 = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rp0 >> 32), (int)j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rp0, (int)j);
+			const u64 p1 = ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rp1 >> 32), (int)j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rp1, (int)j);
 			if (q[7] == 0) { continue; }                             // no token starts in this segment
 			if (q[1]) {                                              // the open word was completed inside segment j
 				const uint32_t wdv = g_acc | q[0];
@@ -1029,7 +1136,8 @@ void launch_xpress_emit(hipStream_t st, const uint8_t* d_in, const BatchTables& 
 	else {
 		Xe3 x = { wb.wtok, wb.wmat, wb.wfar, wb.wecur, wb.weF, wb.wsum, wb.wnr, wb.ws0, wb.ws1, wb.sbtot, wb.sbpre, wb.seam, wb.seampos };
 		if (bt.n_chunks) { hipLaunchKernelGGL(xe3_walk_kernel, dim3(bt.n_chunks), dim3(1024), 0, st, d_in, bt, mlen3, moff, x); }
-		hipLaunchKernelGGL(xe3_fix_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, mlen3, moff, x, d_out_len, d_status);
+		if (bt.n_chunks) { hipLaunchKernelGGL(xe3_seam_kernel, dim3(bt.n_chunks), dim3(64), 0, st, d_in, bt, mlen3, moff, x, wb.used); }
+		hipLaunchKernelGGL(xe3_fix_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, mlen3, moff, x, wb.used, d_out_len, d_status);
 		if (bt.n_chunks) { hipLaunchKernelGGL(xe3_emit_kernel, dim3(bt.n_chunks), dim3(1024), 0, st, d_in, bt, mlen3, moff, x, d_out); }
 		hipLaunchKernelGGL(xe3_stitch_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, x, d_out);
 	}
