@@ -205,7 +205,7 @@ MSCompStatus mscomp_amd_plan_create(mscomp_amd_ctx* c, MSCompFormat format, size
 		if (ok && format == MSCOMP_XPRESS) {
 			const size_t nw = (size_t)p->n_chunks * 1024u + 64;
 			ok = c->wtok.reserve(nw * 8) && c->wmat.reserve(nw * 8) && c->wfar.reserve(nw * 4);
-			if (ok && (p->n_units <= 64u || get_xpress_emit_mode() == 4)) {    // the block-per-super-block kernels (few units)
+			if (ok && xpress_emit_mode_for(p->n_units, p->n_chunks) == 4) {    // the block-per-super-block kernels
 				const size_t ns = (size_t)p->n_chunks + 1;
 				ok = c->wrec.reserve(nw * 6 * 4) && c->sbrec.reserve(ns * (16 + 24 + 16 * 8 * 4 + 16 * 2 * 8 + 8));
 			}

@@ -17,7 +17,7 @@ void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, 
 
 // ---- Xpress stream emission (xpress_emit.hip): one wavefront per unit ----
 void set_xpress_emit_mode(int mode);
-int get_xpress_emit_mode();
+int xpress_emit_mode_for(uint32_t n_units, uint32_t n_chunks);
 // per-window / per-super-block records of the Xpress parse (see xpress_emit.hip); the last 10 only for the block-per-super-block kernels
 struct XpressWinBufs { u64* wtok; u64* wmat; uint32_t* wfar; uint32_t* wecur; uint32_t* weF; uint32_t* wsum; uint32_t* wnr; uint32_t* ws0; uint32_t* ws1;
                        uint32_t* sbtot; u64* sbpre; uint32_t* seam; u64* seampos; uint32_t* used; };

@@ -1121,14 +1121,23 @@ __global__ __launch_bounds__(64) void xe3_stitch_kernel(BatchTables bt, Xe3 x, u
 }
 
 static int g_xpress_emit_mode = 0;                               // 0 = by batch size, 1 = one wave per unit, 2 / 3 = 4 / 16 waves per unit, 4 = a block per super-block (tests)
+// Which parse/emit kernels a batch gets. Few units, or long ones (on average more than four 64 KiB super-blocks each):
+// a block per super-block, so that a long stream is spread over the GPU (needs 24 B of records per 64 input bytes).
+// Otherwise the per-unit kernels: four waves per unit up to 1024 units, one wave per unit beyond (a full GPU is
+// issue-bound and the multi-wave kernels spend more wave-cycles; at 3 239 units of 64 KiB the three variants are within
+// 10 % of each other: 5.5 / 5.6 / 6.2 ms per pass).
+int xpress_emit_mode_for(uint32_t n_units, uint32_t n_chunks)
+{
+	if (g_xpress_emit_mode) { return g_xpress_emit_mode; }
+	if ((n_units <= 64u || n_chunks >= 4u * n_units) && n_chunks <= 32768u) { return 4; }
+	return n_units <= 1024u ? 2 : 1;
+}
 void launch_xpress_emit(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* mlen3, const uint16_t* moff,
                         const XpressWinBufs& wb, uint8_t* d_out, u64* d_out_len, int32_t* d_status)
 {
 	if (bt.n_units == 0) { return; }
-	// One wave per unit is the better use of a full GPU (the multi-wave kernels spend twice the wave-cycles); with few
-	// units the 4-wave in-block kernel cuts the latency of each, and with very few the super-blocks of a unit are
-	// spread over the GPU (four kernels).
-	const int mode = g_xpress_emit_mode ? g_xpress_emit_mode : (bt.n_units <= 64u ? 4 : (bt.n_units <= 1024u ? 2 : 1));
+	int mode = xpress_emit_mode_for(bt.n_units, bt.n_chunks);
+	if (mode == 4 && !wb.wecur) { mode = 2; }                    // (records not reserved: the plan was made under another forced mode)
 	u64* wtok = wb.wtok; u64* wmat = wb.wmat; uint32_t* wfar = wb.wfar;
 	if (mode == 1) { hipLaunchKernelGGL(xpress_emit_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, mlen3, moff, d_out, d_out_len, d_status); }
 	else if (mode == 2) { hipLaunchKernelGGL(xpress_emit2_kernel<4u>, dim3(bt.n_units), dim3(256), 0, st, d_in, bt, mlen3, moff, wtok, wmat, wfar, d_out, d_out_len, d_status); }
@@ -1143,6 +1152,5 @@ void launch_xpress_emit(hipStream_t st, const uint8_t* d_in, const BatchTables& 
 	}
 }
 void set_xpress_emit_mode(int mode) { g_xpress_emit_mode = mode; }
-int get_xpress_emit_mode() { return g_xpress_emit_mode; }
 
 } // namespace msc
