@@ -172,12 +172,11 @@ __global__ __launch_bounds__(1024) void xp_links_kernel(const uint8_t* __restric
 	}
 }
 
-// Find for a tile of 4096 positions per 256-thread block. The tile's whole match window is staged in LDS:
+// Find for a tile of XP_TILE positions per block. The tile's whole match window is staged in LDS:
 //   data  [P0-WINDOW, P0+4096+64)  (WINDOW = 8192 for Xpress, 65536 for Xpress+Huffman; clipped at the unit start),
 //   links of the same positions when they fit (Xpress: 24 KiB; Xpress+Huffman would need 136 KiB -> read from L2),
 // so the chain walk (<= 11 dependent steps) and the byte compares are LDS gathers instead of L2 gathers.
 // clip != 0: positions with fewer than 3 bytes left in their 64 KiB chunk get no match (xpress_huff_compress.cpp:90).
-#define XP_TILE 4096u
 #ifdef XF_PROFILE
 __device__ unsigned long long g_xf_prof[8];
 extern "C" void mscomp_amd_debug_xf_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xf_prof), 64); unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xf_prof), z, 64); }
@@ -185,7 +184,7 @@ extern "C" void mscomp_amd_debug_xf_prof(unsigned long long* out) { (void)hipMem
 #else
 #define XF_CNT(i, v)
 #endif
-template <uint32_t WINDOW, uint32_t LINKW, uint32_t NT>   // LINKW: how many positions before the tile have their links in LDS
+template <uint32_t WINDOW, uint32_t LINKW, uint32_t NT, uint32_t XP_TILE>   // LINKW: how many positions before the tile have their links in LDS
 __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                      const uint16_t* __restrict__ links, const uint16_t* __restrict__ lasthead,
                                                      uint16_t* __restrict__ mlen3, uint16_t* __restrict__ moff,
@@ -197,12 +196,13 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 
 	const uint32_t tid = threadIdx.x;
 	// XCD-aware tile order: consecutive workgroup ids go to different XCDs (private L2s). Inside every group of 128 ids
-	// (= 8 chunks x 16 tiles) XCD x takes the 16 tiles of chunk x, which re-stage the same window, so they share one L2;
+	// XCD x takes 16 consecutive tiles (one or two chunks), which re-stage the same window, so they share one L2;
 	// across groups the chunks stay round-robin over the XCDs (cheap and expensive files are spread evenly).
 	uint32_t bid = blockIdx.x;
 	if ((bid | 127u) < gridDim.x) { const uint32_t wi = bid & 127u; bid = (bid & ~127u) + (wi & 7u) * 16u + (wi >> 3); }
-	const uint32_t lc = bid >> 4;
-	const uint32_t tstart = (bid & 15u) * XP_TILE;                            // tile start inside the chunk
+	constexpr uint32_t TPC = 65536u / XP_TILE;                                // tiles per chunk
+	const uint32_t lc = bid / TPC;
+	const uint32_t tstart = (bid % TPC) * XP_TILE;                            // tile start inside the chunk
 	const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, lc);
 	const uint32_t k = lc - bt.chunk_prefix[u];
 	const u64 n = bt.in_len[u];
@@ -335,22 +335,26 @@ void launch_xp_links(hipStream_t st, const uint8_t* d_in, const BatchTables& bt,
 	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_links_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
 	hipLaunchKernelGGL(xp_links_kernel, dim3(bt.n_chunks), dim3(1024), lds, st, d_in, bt, links, lasthead);
 }
+// tile = positions per block: 4096 for Xpress (4 blocks/CU), 8192 for Xpress+Huffman (the 64 KiB window is re-staged
+// half as often; 72 KiB of LDS, still 2 blocks/CU)
+#define XH_TILE_SEL 8192u
 void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead,
                     uint16_t* mlen3, uint16_t* moff, uint32_t max_off, int clip)
 {
 	if (bt.n_chunks == 0) { return; }
 	static bool attr_set = false;
-	const uint32_t lds_xp = 0x2000u + XP_TILE + 64u + (0x2000u + XP_TILE) * 2u;      // data + all links of the window in LDS
-	const uint32_t lds_xh = 0x10000u + XP_TILE + 64u;                               // data only (2 blocks/CU); links come from L2
+	constexpr uint32_t TXP = 4096u, TXH = XH_TILE_SEL;
+	const uint32_t lds_xp = 0x2000u + TXP + 64u + (0x2000u + TXP) * 2u;           // data + all links of the window in LDS
+	const uint32_t lds_xh = 0x10000u + TXH + 64u;                                // data only (2 blocks/CU); links come from L2
 	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x2000u, 0x2000u, 512u>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xp);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x10000u, 0u, 1024u>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xh);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x2000u, 0x2000u, 512u, TXP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xp);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x10000u, 0u, 1024u, TXH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xh);
 		attr_set = true;
 	}
 	if (max_off <= 0x2000u) {
-		hipLaunchKernelGGL((xp_find_kernel<0x2000u, 0x2000u, 512u>), dim3(bt.n_chunks * 16u), dim3(512), lds_xp, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip);
+		hipLaunchKernelGGL((xp_find_kernel<0x2000u, 0x2000u, 512u, TXP>), dim3(bt.n_chunks * (65536u / TXP)), dim3(512), lds_xp, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip);
 	} else {
-		hipLaunchKernelGGL((xp_find_kernel<0x10000u, 0u, 1024u>), dim3(bt.n_chunks * 16u), dim3(1024), lds_xh, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip);
+		hipLaunchKernelGGL((xp_find_kernel<0x10000u, 0u, 1024u, TXH>), dim3(bt.n_chunks * (65536u / TXH)), dim3(1024), lds_xh, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip);
 	}
 }
 
