@@ -86,6 +86,140 @@ __device__ __forceinline__ uint32_t lz_lcp(const uint8_t* d, uint32_t q, bool va
 	return l < maxlen ? l : maxlen;
 }
 
+// One window (64 positions, lane = position) of the lazy parse of a chunk: Find for the positions at / after the parse
+// position `entry` (the 4 oldest candidates per lane, the rest on demand), greedy walk, token mask. Returns the parse
+// position after the window; key = (len << 12) | (4095 - q) of this lane's match (valid where matchmask is set),
+// o0 = the 4 bytes at this lane's position, shift = its token split.
+struct LzWin { uint32_t key, o0, shift; u64 tokmask, matchmask; };
+__device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint16_t* s_cnt, const uint16_t* s_bucket, uint32_t n, uint32_t lane,
+                                              uint32_t wbase, uint32_t entry, LzWin& r)
+{
+	const uint32_t wend = (wbase + 64u < n) ? wbase + 64u : n;
+	const uint32_t p = wbase + lane;
+	const uint32_t o0 = ld32(s_data + p), o1 = ld32(s_data + p + 4u), o2 = ld32(s_data + p + 8u), o3 = ld32(s_data + p + 12u);
+	const uint32_t shift = lz_shift(p);
+	uint32_t maxlen = 0, s = 0, e = 0;                        // my candidates: bucket[s..e) entries that are < p (ascending)
+	if (p >= entry && p > 0 && p + 3u <= n) {
+		const uint32_t mask3 = (1u << shift) + 2u;
+		maxlen = (n - p < mask3) ? n - p : mask3;
+		const uint32_t h = lz_hash(o0 & 0xFFFFFFu);
+		e = s_cnt[h];                                          // bucket h = [end[h-1], end[h])
+		s = h ? (uint32_t)s_cnt[h - 1u] : 0u;
+	}
+	// 1. the oldest LZ_SELF candidates, in order, early exit at maxlen (LZNT1Dictionary.h:124-135)
+	uint32_t key = 0;                                       // (len << 12) | (4095 - q): larger = longer, then older
+	bool done = false;
+	// All loads are UNCONDITIONAL (clamped index) so that they issue back to back and are waited for once; lanes and
+	// candidates that do not exist are masked afterwards.
+	uint32_t q[LZ_SELF + 1u];
+	#pragma unroll
+	for (uint32_t j = 0; j <= LZ_SELF; ++j) { q[j] = s_bucket[(s + j) & 4095u]; }
+	#pragma unroll
+	for (uint32_t j = 0; j <= LZ_SELF; ++j) { if (s + j >= e) { q[j] = 4096u; } }                          // 4096 = none (>= p)
+	#pragma unroll
+	for (uint32_t j = 0; j < LZ_SELF; j += 4u) {
+		uint4 c[4];
+		#pragma unroll
+		for (int k = 0; k < 4; ++k) { __builtin_memcpy(&c[k], s_data + (q[j + k] < p ? q[j + k] : 0u), 16); }
+		#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t f = first_nz_byte16(c[k].x ^ o0, c[k].y ^ o1, c[k].z ^ o2, c[k].w ^ o3);
+			uint32_t lk = (q[j + k] < p && f >= 3u) ? f : 0u;                  // no such candidate / hash collision
+			if (lk == 16u && maxlen > 16u) { lk = lz_lcp_tail(s_data, q[j + k], p, maxlen); }   // long match
+			lk = lk < maxlen ? lk : maxlen;
+			const bool take = !done && lk > (key >> 12);
+			key = take ? ((lk << 12) | (4095u - q[j + k])) : key;
+			done = done || (take && lk == maxlen);
+		}
+	}
+	bool unres = !done && q[LZ_SELF] < p;                    // a 9th older candidate exists and max_len was not reached
+	// 2. greedy walk; positions with rem != 0 are finished by the whole wave when (and only when) the walk lands on them
+	u64 un = __ballot(unres);                                // unresolved positions
+	u64 mm = __ballot(!unres && (key >> 12) >= 3u);          // resolved positions that have a match
+	// The serial loop only decides which candidates are TAKEN; everything else (which positions are literal tokens)
+	// is derived in parallel afterwards.
+	u64 matchmask = 0;
+	const uint32_t wn = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wend - wbase));
+	// Every resolved match lane precomputes where the walk goes after taking it: the first stop (match or unresolved
+	// position) at or after its end, relative to the window (>= wn leaves it). The scalar walk is then one
+	// v_readlane per taken match; it leaves the asm block on an unresolved position (st = 1), which is finished by
+	// the whole wave. Stops are only ever removed at the walk's own position, so the table never goes stale ahead.
+	un = sgpr64(un); mm = sgpr64(mm);
+	const uint32_t nx = lane + (key >> 12);
+	const u64 restl = nx < 64u ? (un | mm) >> nx : (u64)0;
+	const uint32_t J = nx >= wn ? nx : (restl ? nx + ctz64(restl) : wn);
+	uint32_t mp;
+	{
+		const uint32_t rel = entry > wbase ? entry - wbase : 0u;   // next token start, relative to the window
+		const u64 rest = rel < 64u ? (un | mm) >> rel : (u64)0;
+		mp = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rest ? rel + ctz64(rest) : wn));
+	}
+	while (mp < wn) {
+		uint32_t st;
+		matchmask = sgpr64(matchmask);
+		// v_readlane needs 4 wait states after the write of its lane select (mp): on the loop edge the five scalar
+		// instructions in between provide them, on entry the s_nop does.
+		asm volatile(
+			"s_nop 3\n\t"
+			"1:\n\t"
+			"s_bitcmp1_b64 %[un], %[mp]\n\t"
+			"s_cbranch_scc1 3f\n\t"
+			"s_bitset1_b64 %[mk], %[mp]\n\t"
+			"v_readlane_b32 %[mp], %[J], %[mp]\n\t"
+			"s_cmp_lt_u32 %[mp], %[wn]\n\t"
+			"s_cbranch_scc1 1b\n\t"
+			"s_mov_b32 %[st], 0\n\t"
+			"s_branch 4f\n\t"
+			"3:\n\t"
+			"s_mov_b32 %[st], 1\n\t"
+			"4:\n\t"
+			: [mp] "+s"(mp), [mk] "+s"(matchmask), [st] "=&s"(st)
+			: [un] "s"(un), [wn] "s"(wn), [J] "v"(J)
+			: "scc");
+		if (st == 0) { break; }
+		{
+			// finish position wbase+mp: the candidates after the first LZ_SELF of its bucket, oldest first, 64 per step
+			const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)s, (int)mp);
+			const uint32_t eL = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)mp);
+			const uint32_t maxL = (uint32_t)__builtin_amdgcn_readlane((int)maxlen, (int)mp);
+			const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)o0, (int)mp), a1 = (uint32_t)__builtin_amdgcn_readlane((int)o1, (int)mp);
+			const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)o2, (int)mp), a3 = (uint32_t)__builtin_amdgcn_readlane((int)o3, (int)mp);
+			uint32_t kbest = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)mp);
+			const uint32_t pL = wbase + mp;
+			for (uint32_t base = sL + LZ_SELF; base < eL; base += 64u) {
+				const uint32_t idx = base + lane;
+				const uint32_t qq = s_bucket[idx & 4095u];         // unconditional load, masked below
+				const bool valid = idx < eL && qq < pL;            // !valid: this lane is at or beyond pL's own entry
+				const uint32_t l2 = lz_lcp(s_data, qq, valid, pL, maxL, a0, a1, a2, a3);
+				const uint32_t k2 = l2 ? ((l2 << 12) | (4095u - qq)) : 0u;
+				const bool past = !valid;
+				const uint32_t m = wave_max_u32(k2);
+				if ((m >> 12) > (kbest >> 12)) { kbest = m; }    // strictly longer only: older blocks win ties
+				if ((kbest >> 12) == maxL || __ballot(past)) { break; }   // max_len reached / all older candidates seen
+			}
+			if (lane == mp) { key = kbest; }
+			un = sgpr64(un & ~(((u64)1) << mp));
+			// literals before mp are settled; mp itself is now resolved: take its match, or step over it as a literal
+			uint32_t nxs = mp + 1u;
+			if ((kbest >> 12) >= 3u) { matchmask |= ((u64)1) << mp; nxs = mp + (kbest >> 12); }
+			const u64 rest = nxs < 64u ? (un | mm) >> nxs : (u64)0;
+			mp = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nxs >= wn ? nxs : (rest ? nxs + ctz64(rest) : wn)));
+		}
+	}
+	// tokens of the window = positions >= entry that no taken match covers: covered <=> the furthest end of the taken
+	// matches starting at or before me lies beyond me and I am not such a start myself
+	const bool is_m = (matchmask >> lane) & (u64)1;
+	const uint32_t mend = is_m ? p + (key >> 12) : 0u;
+	const uint32_t reach = wave_incl_scan_max(mend);
+	const bool is_tok = p >= entry && p < wend && (is_m || reach <= p);
+	const u64 tokmask = __ballot(is_tok);
+	const uint32_t wreach = (uint32_t)__builtin_amdgcn_readlane((int)reach, 63);
+	const uint32_t cur = wreach > wend ? wreach : wend;
+
+	r.key = key; r.o0 = o0; r.shift = shift; r.tokmask = tokmask; r.matchmask = matchmask;
+	return cur;
+}
+
 __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                         uint8_t* __restrict__ slots, uint32_t* __restrict__ slot_size)
 {
@@ -183,143 +317,12 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 		const uint32_t wbase = w * 64u;
 		const uint32_t wend = (wbase + 64u < n) ? wbase + 64u : n;
 		if (entry >= wend) { continue; }                         // window wholly covered by a match
+		LzWin r;
+		const uint32_t cur = lz_window(s_data, s_cnt, s_bucket, n, lane, wbase, entry, r);
 		const uint32_t p = wbase + lane;
-		const uint32_t o0 = ld32(s_data + p), o1 = ld32(s_data + p + 4u), o2 = ld32(s_data + p + 8u), o3 = ld32(s_data + p + 12u);
-		const uint32_t shift = lz_shift(p);
-		uint32_t maxlen = 0, s = 0, e = 0;                        // my candidates: bucket[s..e) entries that are < p (ascending)
-		if (p >= entry && p > 0 && p + 3u <= n) {
-			const uint32_t mask3 = (1u << shift) + 2u;
-			maxlen = (n - p < mask3) ? n - p : mask3;
-			const uint32_t h = lz_hash(o0 & 0xFFFFFFu);
-			e = s_cnt[h];                                          // bucket h = [end[h-1], end[h])
-			s = h ? (uint32_t)s_cnt[h - 1u] : 0u;
-		}
-		// 1. the oldest LZ_SELF candidates, in order, early exit at maxlen (LZNT1Dictionary.h:124-135)
-		uint32_t key = 0;                                       // (len << 12) | (4095 - q): larger = longer, then older
-		bool done = false;
-		// All loads are UNCONDITIONAL (clamped index) so that they issue back to back and are waited for once; lanes and
-		// candidates that do not exist are masked afterwards.
-		uint32_t q[LZ_SELF + 1u];
-		#pragma unroll
-		for (uint32_t j = 0; j <= LZ_SELF; ++j) { q[j] = s_bucket[(s + j) & 4095u]; }
-		#pragma unroll
-		for (uint32_t j = 0; j <= LZ_SELF; ++j) { if (s + j >= e) { q[j] = 4096u; } }                          // 4096 = none (>= p)
-		#pragma unroll
-		for (uint32_t j = 0; j < LZ_SELF; j += 4u) {
-			uint4 c[4];
-			#pragma unroll
-			for (int k = 0; k < 4; ++k) { __builtin_memcpy(&c[k], s_data + (q[j + k] < p ? q[j + k] : 0u), 16); }
-			#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				const uint32_t f = first_nz_byte16(c[k].x ^ o0, c[k].y ^ o1, c[k].z ^ o2, c[k].w ^ o3);
-				uint32_t lk = (q[j + k] < p && f >= 3u) ? f : 0u;                  // no such candidate / hash collision
-				if (lk == 16u && maxlen > 16u) { lk = lz_lcp_tail(s_data, q[j + k], p, maxlen); }   // long match
-				lk = lk < maxlen ? lk : maxlen;
-				const bool take = !done && lk > (key >> 12);
-				key = take ? ((lk << 12) | (4095u - q[j + k])) : key;
-				done = done || (take && lk == maxlen);
-			}
-		}
-		bool unres = !done && q[LZ_SELF] < p;                    // a 9th older candidate exists and max_len was not reached
-		LZ_T(3)
-		// 2. greedy walk; positions with rem != 0 are finished by the whole wave when (and only when) the walk lands on them
-		u64 un = __ballot(unres);                                // unresolved positions
-		LZ_CNT(10, __popcll(un))
-		u64 mm = __ballot(!unres && (key >> 12) >= 3u);          // resolved positions that have a match
-		// The serial loop only decides which candidates are TAKEN; everything else (which positions are literal tokens)
-		// is derived in parallel afterwards.
-		u64 matchmask = 0;
-		const uint32_t wn = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wend - wbase));
-		// Every resolved match lane precomputes where the walk goes after taking it: the first stop (match or unresolved
-		// position) at or after its end, relative to the window (>= wn leaves it). The scalar walk is then one
-		// v_readlane per taken match; it leaves the asm block on an unresolved position (st = 1), which is finished by
-		// the whole wave. Stops are only ever removed at the walk's own position, so the table never goes stale ahead.
-		un = sgpr64(un); mm = sgpr64(mm);
-		const uint32_t nx = lane + (key >> 12);
-		const u64 restl = nx < 64u ? (un | mm) >> nx : (u64)0;
-		const uint32_t J = nx >= wn ? nx : (restl ? nx + ctz64(restl) : wn);
-		uint32_t mp;
-		{
-			const uint32_t rel = entry > wbase ? entry - wbase : 0u;   // next token start, relative to the window
-			const u64 rest = rel < 64u ? (un | mm) >> rel : (u64)0;
-			mp = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rest ? rel + ctz64(rest) : wn));
-		}
-		while (mp < wn) {
-#ifdef LZ_PROFILE
-			const unsigned long long tw0 = __builtin_readcyclecounter();
-#endif
-			uint32_t st;
-			matchmask = sgpr64(matchmask);
-			// v_readlane needs 4 wait states after the write of its lane select (mp): on the loop edge the five scalar
-			// instructions in between provide them, on entry the s_nop does.
-			asm volatile(
-				"s_nop 3\n\t"
-				"1:\n\t"
-				"s_bitcmp1_b64 %[un], %[mp]\n\t"
-				"s_cbranch_scc1 3f\n\t"
-				"s_bitset1_b64 %[mk], %[mp]\n\t"
-				"v_readlane_b32 %[mp], %[J], %[mp]\n\t"
-				"s_cmp_lt_u32 %[mp], %[wn]\n\t"
-				"s_cbranch_scc1 1b\n\t"
-				"s_mov_b32 %[st], 0\n\t"
-				"s_branch 4f\n\t"
-				"3:\n\t"
-				"s_mov_b32 %[st], 1\n\t"
-				"4:\n\t"
-				: [mp] "+s"(mp), [mk] "+s"(matchmask), [st] "=&s"(st)
-				: [un] "s"(un), [wn] "s"(wn), [J] "v"(J)
-				: "scc");
-#ifdef LZ_PROFILE
-			t_acc[12] += __builtin_readcyclecounter() - tw0; t_acc[13] += 1;
-#endif
-			if (st == 0) { break; }
-			{
-				// finish position wbase+mp: the candidates after the first LZ_SELF of its bucket, oldest first, 64 per step
-				const uint32_t sL = (uint32_t)__builtin_amdgcn_readlane((int)s, (int)mp);
-				const uint32_t eL = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)mp);
-				const uint32_t maxL = (uint32_t)__builtin_amdgcn_readlane((int)maxlen, (int)mp);
-				const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)o0, (int)mp), a1 = (uint32_t)__builtin_amdgcn_readlane((int)o1, (int)mp);
-				const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)o2, (int)mp), a3 = (uint32_t)__builtin_amdgcn_readlane((int)o3, (int)mp);
-				uint32_t kbest = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)mp);
-				const uint32_t pL = wbase + mp;
-				LZ_CNT(11, 1)
-#ifdef LZ_PROFILE
-				const unsigned long long tf0 = __builtin_readcyclecounter();
-#endif
-				for (uint32_t base = sL + LZ_SELF; base < eL; base += 64u) {
-					const uint32_t idx = base + lane;
-					const uint32_t qq = s_bucket[idx & 4095u];         // unconditional load, masked below
-					const bool valid = idx < eL && qq < pL;            // !valid: this lane is at or beyond pL's own entry
-					const uint32_t l2 = lz_lcp(s_data, qq, valid, pL, maxL, a0, a1, a2, a3);
-					const uint32_t k2 = l2 ? ((l2 << 12) | (4095u - qq)) : 0u;
-					const bool past = !valid;
-					LZ_CNT(9, 1)
-					const uint32_t m = wave_max_u32(k2);
-					if ((m >> 12) > (kbest >> 12)) { kbest = m; }    // strictly longer only: older blocks win ties
-					if ((kbest >> 12) == maxL || __ballot(past)) { break; }   // max_len reached / all older candidates seen
-				}
-#ifdef LZ_PROFILE
-				t_acc[15] += __builtin_readcyclecounter() - tf0;
-#endif
-				if (lane == mp) { key = kbest; }
-				un = sgpr64(un & ~(((u64)1) << mp));
-				// literals before mp are settled; mp itself is now resolved: take its match, or step over it as a literal
-				uint32_t nxs = mp + 1u;
-				if ((kbest >> 12) >= 3u) { matchmask |= ((u64)1) << mp; nxs = mp + (kbest >> 12); }
-				const u64 rest = nxs < 64u ? (un | mm) >> nxs : (u64)0;
-				mp = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nxs >= wn ? nxs : (rest ? nxs + ctz64(rest) : wn)));
-			}
-		}
-		// tokens of the window = positions >= entry that no taken match covers: covered <=> the furthest end of the taken
-		// matches starting at or before me lies beyond me and I am not such a start myself
-		LZ_CNT(14, __popcll(matchmask))
-		const bool is_m = (matchmask >> lane) & (u64)1;
-		const uint32_t mend = is_m ? p + (key >> 12) : 0u;
-		const uint32_t reach = wave_incl_scan_max(mend);
-		const bool is_tok = p >= entry && p < wend && (is_m || reach <= p);
-		const u64 tokmask = __ballot(is_tok);
-		const uint32_t wreach = (uint32_t)__builtin_amdgcn_readlane((int)reach, 63);
-		const uint32_t cur = wreach > wend ? wreach : wend;
+		const uint32_t key = r.key, o0 = r.o0, shift = r.shift;
+		const u64 tokmask = r.tokmask, matchmask = r.matchmask;
+		const bool is_m = (matchmask >> lane) & (u64)1, is_tok = (tokmask >> lane) & (u64)1;
 		entry = cur;
 		LZ_T(4)
 
