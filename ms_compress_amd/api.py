@@ -28,7 +28,7 @@ EXPORTS = [  # every symbol include/mscomp_amd.h declares (tests check the libra
     "xpress_huff_compress", "xpress_huff_max_compressed_size",
     "mscomp_amd_ctx_create", "mscomp_amd_ctx_destroy", "mscomp_amd_plan_create", "mscomp_amd_plan_destroy",
     "mscomp_amd_plan_execute", "mscomp_amd_compress_batch", "mscomp_amd_profile_enable", "mscomp_amd_profile_read",
-    "mscomp_amd_version", "mscomp_amd_debug_xpress_matches", "mscomp_amd_debug_lds_lane_order", "mscomp_amd_debug_set_xpress_emit",
+    "mscomp_amd_version", "mscomp_amd_debug_xpress_matches", "mscomp_amd_debug_lds_lane_order", "mscomp_amd_debug_set_xpress_emit", "mscomp_amd_debug_set_lznt1",
 ]
 
 
@@ -87,6 +87,8 @@ def load_library():
     lib.mscomp_amd_debug_lds_lane_order.restype = C.c_uint32
     lib.mscomp_amd_debug_set_xpress_emit.argtypes = [C.c_int]
     lib.mscomp_amd_debug_set_xpress_emit.restype = None
+    lib.mscomp_amd_debug_set_lznt1.argtypes = [C.c_int]
+    lib.mscomp_amd_debug_set_lznt1.restype = None
     _lib = lib
     return lib
 

@@ -337,6 +337,8 @@ MSCompStatus mscomp_amd_debug_xpress_matches(mscomp_amd_ctx* c, const uint8_t* d
 
 // Test hook: which Xpress parse/emit kernel runs (0 = chosen by batch size, 1 = one wave per unit, 2 = four waves per unit).
 void mscomp_amd_debug_set_xpress_emit(int mode) { set_xpress_emit_mode(mode); }
+// ... and which LZNT1 chunk kernel (0 = default, 1 = one wave per chunk, 2 = four waves per chunk).
+void mscomp_amd_debug_set_lznt1(int mode) { set_lznt1_mode(mode); }
 
 // Hardware self-check (see util.hip): lanes whose returning LDS atomic was NOT served in lane order, summed over
 // blocks x rounds x 64 lanes x {add, exchange}; 0 on gfx950. 0xFFFFFFFF = the check could not run.

@@ -6,6 +6,7 @@ namespace msc {
 
 // ---- LZNT1 (lznt1.hip) ----
 #define LZNT1_SLOT 4352u     // scratch bytes per 4 KiB chunk image (2 B header + <=4096 B payload + emit slack)
+void set_lznt1_mode(int mode);
 void launch_lznt1_chunks(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* slots, uint32_t* slot_size);
 
 // ---- Xpress / Xpress+Huffman match finder (xpress_match.hip) ----

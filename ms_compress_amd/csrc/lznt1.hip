@@ -381,10 +381,260 @@ extern "C" void mscomp_amd_debug_lz_prof(unsigned long long* out, int reset)
 }
 #endif
 
+// ===================================================================================================================
+// Four waves per chunk (same bytes as the kernel above)
+// ===================================================================================================================
+// The sort (B) stays with wave 0 -- the rank trick needs the positions in order -- but the lazy parse (C), 85 % of the
+// time, is split: the parse's only state is the position of the next token, so wave j parses the windows
+// [16 j, 16 j + 16) SPECULATIVELY as if a token started at position 1024 j, records per window the token mask, the match
+// mask, the 16-bit match tokens (a match token depends on its position only) and the parse position after it; then wave
+// j repairs the seam BEHIND its segment (it continues with its true position into segment j+1 until the position after
+// a window equals the recorded one), wave 0 checks that no repair ran through a whole segment (else it cascades,
+// serially), scans tokens / bytes per window, and the four waves emit their segments at known offsets; the flag bytes
+// are OR-ed into a per-group LDS array and stored at the end.
+#define LZ4_SEGW 8u                                              // windows per segment (8 segments per chunk)
+#define LZ4_MAXM 22u                                             // matches that can START in one window of 64 positions
+#ifdef LZ4_PROFILE
+__device__ unsigned long long g_lz4_prof[8];
+extern "C" void mscomp_amd_debug_lz4_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lz4_prof), 64); unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lz4_prof), z, 64); }
+#endif
+__global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
+                                                          uint8_t* __restrict__ slots, uint32_t* __restrict__ slot_size)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t  s_data[4096 + 32];
+	__shared__ __attribute__((aligned(16))) uint16_t s_cnt[LZ_TBL];       // counts -> bucket ends; after the parse: prefixes and flags (below)
+	__shared__ __attribute__((aligned(16))) uint16_t s_bucket[4096];
+	__shared__ u64      s_tok[64], s_mat[64];                              // per window
+	__shared__ uint16_t s_endc[64];                                        // parse position after the window
+	__shared__ uint16_t s_ptok[64][LZ4_MAXM];                              // its match tokens, in order
+	__shared__ uint32_t s_prog[8];                                         // windows finished in segment j (index + 1)
+	__shared__ uint32_t s_used[8];                                         // entry position the seam in front of segment j was repaired against
+	__shared__ uint32_t s_segctr;                                          // next segment to hand out
+	__shared__ uint32_t s_total[2];
+	uint16_t* const s_T = s_cnt;                                           // [64] tokens before window w          } after the parse
+	uint16_t* const s_S = s_cnt + 64;                                      // [64] token bytes before window w     }
+	uint16_t* const s_flagpos = s_cnt + 128;                               // [512] byte position of group g's flag byte
+	uint32_t* const s_flagacc = reinterpret_cast<uint32_t*>(s_cnt + 640);  // [512] its bits (LZ_TBL u16 = 4096 B >= 1280 + 2048)
+
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+	const uint32_t c = blockIdx.x;
+	const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, c);
+	const u64 coff = (u64)(c - bt.chunk_prefix[u]) * 4096u;
+	const u64 left = bt.in_len[u] - coff;
+	const uint32_t n = left < 4096u ? (uint32_t)left : 4096u;
+	const uint8_t* __restrict__ src = d_in + bt.in_off[u] + coff;
+	uint8_t* __restrict__ img = slots + (u64)c * LZNT1_SLOT;
+
+#ifdef LZ4_PROFILE
+	unsigned long long z_prev = __builtin_readcyclecounter();
+#define LZ4_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); if (tid == 0) { atomicAdd(&g_lz4_prof[i], t_ - z_prev); } z_prev = t_; }
+#else
+#define LZ4_T(i)
+#endif
+	// ---- A. stage the chunk, clear the count table (all waves) ------------------------------------------------------
+	{
+		const uint32_t nvec = (((uintptr_t)src & 15u) == 0) ? (n & ~15u) : 0u;
+		for (uint32_t i = tid * 16u; i < nvec; i += 4096u) { *reinterpret_cast<uint4*>(s_data + i) = *reinterpret_cast<const uint4*>(src + i); }
+		for (uint32_t i = nvec + tid; i < n; i += 256u) { s_data[i] = src[i]; }
+		for (uint32_t i = n + tid; i < 4096u + 32u; i += 256u) { s_data[i] = 0; }
+		for (uint32_t i = tid * 8u; i < LZ_TBL; i += 2048u) { *reinterpret_cast<uint4*>(s_cnt + i) = make_uint4(0, 0, 0, 0); }
+		if (tid < 8u) { s_prog[tid] = 0; s_used[tid] = 0; }
+		if (tid == 0) { s_segctr = 0; }
+	}
+	__syncthreads();
+	LZ4_T(0)
+	// ---- B. position-sorted buckets (wave 0; see the kernel above) ---------------------------------------------------
+	// histogram (all waves: the counts commute) -> exclusive scan (bucket starts) -> ordered scatter through the start
+	// cursors (wave 0): the returning atomic hands out the slots of a bucket in position order (batches ascending, lane
+	// order inside a batch) and leaves every cursor at its bucket's END, which is what the parse looks up. (No
+	// per-position ranks to keep in registers: this kernel wants 8 blocks of 4 waves per CU.)
+	{
+		const uint32_t nb = (n + 63u) >> 6;
+		for (uint32_t b = wv; b < nb; b += 4u) {
+			const uint32_t p = b * 64u + lane;
+			if (p + 2u < n) {
+				const uint32_t h = lz_hash(ld32(s_data + p) & 0xFFFFFFu);
+				atomicAdd(reinterpret_cast<uint32_t*>(s_cnt) + (h >> 1), (h & 1u) ? 0x10000u : 1u);
+			}
+		}
+	}
+	__syncthreads();
+	if (wv == 0) {
+		const uint32_t nb = (n + 63u) >> 6;
+		wave_fence();
+		{
+			uint32_t run = 0;
+			for (uint32_t k = 0; k < LZ_TBL / 512u; ++k) {
+				uint4 a = reinterpret_cast<uint4*>(s_cnt)[k * 64u + lane];
+				uint32_t w[4] = { a.x, a.y, a.z, a.w };
+				uint32_t sum = 0;
+				#pragma unroll
+				for (int i = 0; i < 4; ++i) { sum += (w[i] & 0xFFFFu) + (w[i] >> 16); }
+				const uint32_t incl = wave_incl_scan_add_u32(sum);
+				uint32_t r = run + incl - sum;
+				#pragma unroll
+				for (int i = 0; i < 4; ++i) { const uint32_t lo = w[i] & 0xFFFFu, hi = w[i] >> 16; w[i] = r | ((r + lo) << 16); r += lo + hi; }
+				reinterpret_cast<uint4*>(s_cnt)[k * 64u + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+				run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+			}
+		}
+		wave_fence();
+		// 8 batches per round: their 8 atomics are issued back to back (DS operations of a wave execute in order; the
+		// wavefront-scope form keeps the compiler from waiting for each one)
+		for (uint32_t b0 = 0; b0 < nb; b0 += 8u) {
+			uint32_t h[8], old[8];
+			#pragma unroll
+			for (int j = 0; j < 8; ++j) { h[j] = lz_hash(ld32(s_data + (((b0 + j) * 64u + lane) & 4095u)) & 0xFFFFFFu); }
+			#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				old[j] = 0;
+				if ((b0 + j) * 64u + lane + 2u < n) {
+					old[j] = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(s_cnt) + (h[j] >> 1), (h[j] & 1u) ? 0x10000u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				}
+			}
+			#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				const uint32_t p = (b0 + j) * 64u + lane;
+				if (p + 2u < n) { s_bucket[(h[j] & 1u) ? old[j] >> 16 : old[j] & 0xFFFFu] = (uint16_t)p; }
+			}
+		}
+	}
+	__syncthreads();
+	LZ4_T(1)
+
+	// ---- C1. speculative parse of my segment ------------------------------------------------------------------------
+	const uint32_t nw = (n + 63u) >> 6;
+	const uint32_t w0 = wv * 16u, w1 = (w0 + 16u < nw) ? w0 + 16u : nw;
+	// one window: parse, record. Returns the parse position after it.
+#define LZ4_WINDOW(w_, entry_, cur_out) { \
+		const uint32_t wb_ = (w_) * 64u; const uint32_t we_ = (wb_ + 64u < n) ? wb_ + 64u : n; \
+		if ((entry_) >= we_) { if (lane == 0) { s_tok[w_] = 0; s_mat[w_] = 0; } cur_out = (entry_); } \
+		else { \
+			LzWin r_; cur_out = lz_window(s_data, s_cnt, s_bucket, n, lane, wb_, (entry_), r_); \
+			if ((r_.matchmask >> lane) & (u64)1) { \
+				const uint32_t p_ = wb_ + lane, best_ = r_.key >> 12; \
+				s_ptok[w_][popc_below(r_.matchmask)] = (uint16_t)(((p_ - (4095u - (r_.key & 0xFFFu)) - 1u) << r_.shift) | (best_ - 3u)); \
+			} \
+			if (lane == 0) { s_tok[w_] = r_.tokmask; s_mat[w_] = r_.matchmask; } \
+		} }
+	// segments of 8 windows, handed out in order: later windows cost more (fuller buckets), equal shares would not be equal
+	for (;;) {
+		uint32_t seg = 0;
+		if (lane == 0) { seg = atomicAdd(&s_segctr, 1u); }
+		seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg);
+		const uint32_t a0 = seg * LZ4_SEGW;
+		if (a0 >= nw) { break; }
+		const uint32_t a1 = (a0 + LZ4_SEGW < nw) ? a0 + LZ4_SEGW : nw;
+		uint32_t entry = a0 * 64u;                                 // (exact for segment 0)
+		for (uint32_t w = a0; w < a1; ++w) {
+			uint32_t cur;
+			LZ4_WINDOW(w, entry, cur)
+			entry = cur;
+			if (lane == 0) { s_endc[w] = (uint16_t)cur; }
+			wave_fence();
+			if (lane == 0) { __hip_atomic_store(&s_prog[seg], w + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+		}
+		// repair the seam behind my segment: continue with my position (true unless my own segment never re-synchronised)
+		// into the next segment until the position after a window equals the recorded one
+		if (a1 < nw) {
+			if (lane == 0) { s_used[seg + 1u] = entry; }
+			if (entry != a1 * 64u) {
+				const uint32_t wlim = (a1 + LZ4_SEGW < nw) ? a1 + LZ4_SEGW : nw;
+				for (uint32_t w = a1; w < wlim; ++w) {
+					while (__hip_atomic_load(&s_prog[seg + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= w) { __builtin_amdgcn_s_sleep(2); }
+					wave_fence();
+					const uint32_t spec = s_endc[w];
+					uint32_t cur;
+					LZ4_WINDOW(w, entry, cur)
+					entry = cur;
+					if (lane == 0) { s_endc[w] = (uint16_t)cur; }
+					if (cur == spec) { break; }
+				}
+			}
+		}
+	}
+	LZ4_T(2)
+	LZ4_T(3)
+	__syncthreads();
+	LZ4_T(4)
+	// ---- C3. (wave 0) cascade check, then tokens / bytes before every window -----------------------------------------
+	if (wv == 0) {
+		for (uint32_t j = 1; j * LZ4_SEGW < nw; ++j) {
+			uint32_t e2 = s_endc[j * LZ4_SEGW - 1u];
+			if (e2 == s_used[j]) { continue; }                        // (else a repair ran through the whole of segment j-1: rare)
+			uint32_t wl = j * LZ4_SEGW;                               // first window NOT walked
+			for (uint32_t w = j * LZ4_SEGW; w < nw; ++w) {
+				const uint32_t spec = s_endc[w];
+				uint32_t cur;
+				LZ4_WINDOW(w, e2, cur)
+				e2 = cur;
+				if (lane == 0) { s_endc[w] = (uint16_t)cur; }
+				wave_fence();
+				wl = w + 1u;
+				if (cur == spec) { break; }
+			}
+			// every seam this walk crossed is consistent now
+			if (lane == 0) { for (uint32_t jj = j + 1u; jj < 8u && jj * LZ4_SEGW < wl; ++jj) { s_used[jj] = s_endc[jj * LZ4_SEGW - 1u]; } }
+			wave_fence();
+		}
+	}
+	__syncthreads();                                              // s_cnt is dead from here on: prefixes and flags take its place
+	for (uint32_t i = tid; i < 512u; i += 256u) { s_flagacc[i] = 0; }
+	if (wv == 0) {
+		const u64 tm = lane < nw ? s_tok[lane] : (u64)0, mk = lane < nw ? s_mat[lane] : (u64)0;
+		const uint32_t nt = (uint32_t)__popcll(tm), ns = nt + (uint32_t)__popcll(mk);
+		const uint32_t ti = wave_incl_scan_add_u32(nt), si = wave_incl_scan_add_u32(ns);
+		s_T[lane] = (uint16_t)(ti - nt); s_S[lane] = (uint16_t)(si - ns);
+		if (lane == 63u) { s_total[0] = ti; s_total[1] = si; }
+	}
+	__syncthreads();
+	LZ4_T(5)
+	const uint32_t T = s_total[0], S = s_total[1];
+	const uint32_t csize = ((T + 7u) >> 3) + S;
+	uint32_t total;
+	if (csize < n) {
+		// ---- D1. emission of my segment: pos(t) = 2 (header) + (t div 8 + 1) + sum size(u<t) --------------------------
+		for (uint32_t w = w0; w < w1; ++w) {
+			const u64 tokmask = s_tok[w];
+			if (tokmask == 0) { continue; }
+			const u64 matchmask = s_mat[w];
+			const bool is_tok = (tokmask >> lane) & (u64)1, is_m = (matchmask >> lane) & (u64)1;
+			const uint32_t tb = popc_below(tokmask), mbl = popc_below(matchmask);
+			const uint32_t t = (uint32_t)s_T[w] + tb;
+			const uint32_t pos = 3u + (t >> 3) + (uint32_t)s_S[w] + tb + mbl;
+			if (is_tok) {
+				if ((t & 7u) == 0) { s_flagpos[t >> 3] = (uint16_t)(pos - 1u); }
+				if (is_m) {
+					const uint32_t tok = s_ptok[w][mbl];
+					img[pos] = (uint8_t)tok; img[pos + 1u] = (uint8_t)(tok >> 8);
+					atomicOr(&s_flagacc[t >> 3], 1u << (t & 7u));
+				} else { img[pos] = s_data[w * 64u + lane]; }
+			}
+		}
+		__syncthreads();
+		for (uint32_t g = tid; g < ((T + 7u) >> 3); g += 256u) { img[s_flagpos[g]] = (uint8_t)s_flagacc[g]; }
+		if (tid == 0) { img[0] = (uint8_t)(0xB000u | (csize - 1u)); img[1] = (uint8_t)((0xB000u | (csize - 1u)) >> 8); }
+		total = 2u + csize;
+	} else {
+		const uint32_t hdr = 0x3000u | (n - 1u);
+		for (uint32_t k = tid; k < (n + 2u + 3u) / 4u; k += 256u) {
+			reinterpret_cast<uint32_t*>(img)[k] = (k == 0) ? (hdr | (ld16(s_data) << 16)) : ld32(s_data + 4u * k - 2u);
+		}
+		total = 2u + n;
+	}
+	if (tid == 0) { slot_size[c] = total; }
+	LZ4_T(6)
+#undef LZ4_WINDOW
+}
+
+static int g_lznt1_mode = 0;                                     // 0 = default, 1 = one wave per chunk, 2 = four waves per chunk (tests)
+void set_lznt1_mode(int mode) { g_lznt1_mode = mode; }
 void launch_lznt1_chunks(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* slots, uint32_t* slot_size)
 {
 	if (bt.n_chunks == 0) { return; }
-	hipLaunchKernelGGL(lznt1_chunk_kernel, dim3(bt.n_chunks), dim3(64), 0, st, d_in, bt, slots, slot_size);
+	const int mode = g_lznt1_mode ? g_lznt1_mode : 2;                 // four waves per chunk: 1.43 vs 1.74 ms on the headline workload
+	if (mode == 1) { hipLaunchKernelGGL(lznt1_chunk_kernel, dim3(bt.n_chunks), dim3(64), 0, st, d_in, bt, slots, slot_size); }
+	else { hipLaunchKernelGGL(lznt1_chunk4_kernel, dim3(bt.n_chunks), dim3(256), 0, st, d_in, bt, slots, slot_size); }
 }
 
 } // namespace msc

@@ -197,3 +197,22 @@ def test_xpress_emit_kernels_agree(oracle, gpu_ctx, mode):
         assert all(s == -5 for s in st)
     finally:
         gpu_ctx.lib.mscomp_amd_debug_set_xpress_emit(0)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_lznt1_chunk_kernels_agree(oracle, gpu_ctx, mode):
+    """The LZNT1 chunk stage has two kernels (one wave per chunk; four waves per chunk with speculative segments, seam
+    repair and a cascade check). Both must produce the reference's bytes."""
+    import ms_compress_amd as m
+    gpu_ctx.lib.mscomp_amd_debug_set_lznt1(mode)
+    try:
+        units = list(cases.edge_cases())
+        rng = np.random.default_rng(5)
+        # chunks whose parse never re-synchronises quickly: period-3 / period-5 runs with phase shifts, long runs, mixtures
+        for period in (3, 5, 7, 64, 65):
+            base = rng.integers(0, 256, period, dtype=np.uint8)
+            units.append(np.tile(base, 20000 // period + 1)[:20000])
+        units.append(np.concatenate([np.zeros(5000, np.uint8), rng.integers(0, 2, 6000, dtype=np.uint8), np.frombuffer(b"abcabcabd" * 900, dtype=np.uint8)]))
+        _check_units(m, oracle, FMTS["lznt1"], units, gpu_ctx)
+    finally:
+        gpu_ctx.lib.mscomp_amd_debug_set_lznt1(0)
