@@ -58,6 +58,18 @@ __device__ __forceinline__ uint32_t first_nz_byte16(uint32_t x0, uint32_t x1, ui
 	return min3u(min3u(ffbl_raw(x0), a, b), c, 128u) >> 3;
 }
 
+// 16 bytes at ANY byte offset of an LDS array whose base is 4-byte aligned. A byte-misaligned ds_read_b128 is replayed
+// by the LDS pipe (about 64 cycles; SQ_LDS_UNALIGNED_STALL was 77 % of the match finder's LDS cycles), so read 5 ALIGNED
+// dwords and funnel-shift (v_alignbyte).
+__device__ __forceinline__ uint4 lds_ld128(const uint8_t* base, uint32_t off)
+{
+	const uint32_t* a = reinterpret_cast<const uint32_t*>(base + (off & ~3u));
+	const uint32_t sh = off & 3u;
+	const uint32_t w0 = a[0], w1 = a[1], w2 = a[2], w3 = a[3], w4 = a[4];
+	return make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+	                  __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh));
+}
+
 // ---- batch tables (uploaded once per plan) ------------------------------------------------------------
 // unit u owns chunks [chunk_prefix[u], chunk_prefix[u+1]); input = in_off/in_len, output = out_off/out_cap.
 struct BatchTables {

@@ -66,7 +66,7 @@ __device__ __forceinline__ uint32_t lz_lcp_tail(const uint8_t* d, uint32_t q, ui
 	uint32_t l = 16u;
 	for (;;) {
 		uint4 a, b;
-		__builtin_memcpy(&a, d + q + l, 16); __builtin_memcpy(&b, d + p + l, 16);
+		a = lds_ld128(d, q + l); b = lds_ld128(d, p + l);
 		const uint32_t f = first_nz_byte16(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
 		l += f;
 		if (f < 16u || l >= maxlen) { break; }
@@ -79,7 +79,7 @@ __device__ __forceinline__ uint32_t lz_lcp(const uint8_t* d, uint32_t q, bool va
                                            uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3)
 {
 	uint4 c;
-	__builtin_memcpy(&c, d + (valid ? q : 0u), 16);
+	c = lds_ld128(d, valid ? q : 0u);
 	const uint32_t f = first_nz_byte16(c.x ^ o0, c.y ^ o1, c.z ^ o2, c.w ^ o3);
 	uint32_t l = (valid && f >= 3u) ? f : 0u;
 	if (l == 16u && maxlen > 16u) { l = lz_lcp_tail(d, q, p, maxlen); }
@@ -96,7 +96,8 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 {
 	const uint32_t wend = (wbase + 64u < n) ? wbase + 64u : n;
 	const uint32_t p = wbase + lane;
-	const uint32_t o0 = ld32(s_data + p), o1 = ld32(s_data + p + 4u), o2 = ld32(s_data + p + 8u), o3 = ld32(s_data + p + 12u);
+	const uint4 own = lds_ld128(s_data, p);                       // (aligned dword reads: a misaligned 16-byte read is replayed)
+	const uint32_t o0 = own.x, o1 = own.y, o2 = own.z, o3 = own.w;
 	const uint32_t shift = lz_shift(p);
 	uint32_t maxlen = 0, s = 0, e = 0;                        // my candidates: bucket[s..e) entries that are < p (ascending)
 	if (p >= entry && p > 0 && p + 3u <= n) {
@@ -120,7 +121,7 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 	for (uint32_t j = 0; j < LZ_SELF; j += 4u) {
 		uint4 c[4];
 		#pragma unroll
-		for (int k = 0; k < 4; ++k) { __builtin_memcpy(&c[k], s_data + (q[j + k] < p ? q[j + k] : 0u), 16); }
+		for (int k = 0; k < 4; ++k) { c[k] = lds_ld128(s_data, q[j + k] < p ? q[j + k] : 0u); }
 		#pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const uint32_t f = first_nz_byte16(c[k].x ^ o0, c[k].y ^ o1, c[k].z ^ o2, c[k].w ^ o3);
