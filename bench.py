@@ -14,6 +14,7 @@ after the headline region and reported under "extra" (N=1 only, or with --all).
 """
 import argparse
 import json
+import re
 import os
 import sys
 import threading
@@ -108,7 +109,8 @@ def pmc_traffic(kernel):
     try:
         doc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
         for k, v in doc["kernels"].items():
-            if k.split("<")[0].endswith(kernel):
+            # (the library times kernel FAMILIES: lznt1_chunk_kernel covers lznt1_chunk4_kernel, the four-wave variant)
+            if re.sub(r"\d+_kernel$", "_kernel", k.split("<")[0]).endswith(kernel):
                 return v["hbm_bytes_per_launch_corrected"]
     except Exception:
         pass
