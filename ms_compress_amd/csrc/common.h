@@ -70,6 +70,13 @@ __device__ __forceinline__ uint4 lds_ld128(const uint8_t* base, uint32_t off)
 	                  __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh));
 }
 
+// 4 bytes at any byte offset of such an array, same reason (two aligned dwords + v_alignbyte)
+__device__ __forceinline__ uint32_t lds_ld32(const uint8_t* base, uint32_t off)
+{
+	const uint32_t* a = reinterpret_cast<const uint32_t*>(base + (off & ~3u));
+	return __builtin_amdgcn_alignbyte(a[1], a[0], off & 3u);
+}
+
 // ---- batch tables (uploaded once per plan) ------------------------------------------------------------
 // unit u owns chunks [chunk_prefix[u], chunk_prefix[u+1]); input = in_off/in_len, output = out_off/out_cap.
 struct BatchTables {

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __rest
 		for (uint32_t b = wv; b < nb; b += 4u) {
 			const uint32_t p = b * 64u + lane;
 			if (p + 2u < n) {
-				const uint32_t h = lz_hash(ld32(s_data + p) & 0xFFFFFFu);
+				const uint32_t h = lz_hash(lds_ld32(s_data, p) & 0xFFFFFFu);
 				atomicAdd(reinterpret_cast<uint32_t*>(s_cnt) + (h >> 1), (h & 1u) ? 0x10000u : 1u);
 			}
 		}
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __rest
 		for (uint32_t b0 = 0; b0 < nb; b0 += 8u) {
 			uint32_t h[8], old[8];
 			#pragma unroll
-			for (int j = 0; j < 8; ++j) { h[j] = lz_hash(ld32(s_data + (((b0 + j) * 64u + lane) & 4095u)) & 0xFFFFFFu); }
+			for (int j = 0; j < 8; ++j) { h[j] = lz_hash(lds_ld32(s_data, ((b0 + j) * 64u + lane) & 4095u) & 0xFFFFFFu); }
 			#pragma unroll
 			for (int j = 0; j < 8; ++j) {
 				old[j] = 0;
