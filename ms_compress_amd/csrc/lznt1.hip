@@ -393,7 +393,17 @@ extern "C" void mscomp_amd_debug_lz_prof(unsigned long long* out, int reset)
 // a window equals the recorded one), wave 0 checks that no repair ran through a whole segment (else it cascades,
 // serially), scans tokens / bytes per window, and the four waves emit their segments at known offsets; the flag bytes
 // are OR-ed into a per-group LDS array and stored at the end.
-#define LZ4_SEGW 8u                                              // windows per segment (8 segments per chunk)
+// Segments (in windows): 4 of shrinking length (24 / 19 / 12 / 9) -- a window costs more the later it lies in the chunk
+// (fuller buckets) and every seam costs a repair. Headline workload: 16 equal segments handed out in order 1.37 ms,
+// 8: 1.23, 4 equal: 1.20; boundaries 20/36/50: 1.17, 24/43/55: 1.13, 26/46/57: 1.10, 28/49/59: 1.23; on the other corpus
+// members the less skewed splits are 2-3 % better, hence the middle.
+#define LZ4_NSEG 4u
+#ifndef LZ4_B1
+#define LZ4_B1 24u
+#define LZ4_B2 43u
+#define LZ4_B3 55u
+#endif
+__device__ __forceinline__ uint32_t lz4_seg_start(uint32_t j) { return j == 0 ? 0u : j == 1 ? LZ4_B1 : j == 2 ? LZ4_B2 : j == 3 ? LZ4_B3 : 64u; }
 #define LZ4_MAXM 22u                                             // matches that can START in one window of 64 positions
 #ifdef LZ4_PROFILE
 __device__ unsigned long long g_lz4_prof[8];
@@ -408,8 +418,8 @@ __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __rest
 	__shared__ u64      s_tok[64], s_mat[64];                              // per window
 	__shared__ uint16_t s_endc[64];                                        // parse position after the window
 	__shared__ uint16_t s_ptok[64][LZ4_MAXM];                              // its match tokens, in order
-	__shared__ uint32_t s_prog[8];                                         // windows finished in segment j (index + 1)
-	__shared__ uint32_t s_used[8];                                         // entry position the seam in front of segment j was repaired against
+	__shared__ uint32_t s_prog[LZ4_NSEG];                                         // windows finished in segment j (index + 1)
+	__shared__ uint32_t s_used[LZ4_NSEG];                                         // entry position the seam in front of segment j was repaired against
 	__shared__ uint32_t s_segctr;                                          // next segment to hand out
 	__shared__ uint32_t s_total[2];
 	uint16_t* const s_T = s_cnt;                                           // [64] tokens before window w          } after the parse
@@ -439,7 +449,7 @@ __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __rest
 		for (uint32_t i = nvec + tid; i < n; i += 256u) { s_data[i] = src[i]; }
 		for (uint32_t i = n + tid; i < 4096u + 32u; i += 256u) { s_data[i] = 0; }
 		for (uint32_t i = tid * 8u; i < LZ_TBL; i += 2048u) { *reinterpret_cast<uint4*>(s_cnt + i) = make_uint4(0, 0, 0, 0); }
-		if (tid < 8u) { s_prog[tid] = 0; s_used[tid] = 0; }
+		if (tid < LZ4_NSEG) { s_prog[tid] = 0; s_used[tid] = 0; }
 		if (tid == 0) { s_segctr = 0; }
 	}
 	__syncthreads();
@@ -518,14 +528,14 @@ __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __rest
 			} \
 			if (lane == 0) { s_tok[w_] = r_.tokmask; s_mat[w_] = r_.matchmask; } \
 		} }
-	// segments of 8 windows, handed out in order: later windows cost more (fuller buckets), equal shares would not be equal
+	// the segments are handed out in order (with four of them: one per wave)
 	for (;;) {
 		uint32_t seg = 0;
 		if (lane == 0) { seg = atomicAdd(&s_segctr, 1u); }
 		seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg);
-		const uint32_t a0 = seg * LZ4_SEGW;
+		const uint32_t a0 = lz4_seg_start(seg);
 		if (a0 >= nw) { break; }
-		const uint32_t a1 = (a0 + LZ4_SEGW < nw) ? a0 + LZ4_SEGW : nw;
+		const uint32_t a1 = (lz4_seg_start(seg + 1u) < nw) ? lz4_seg_start(seg + 1u) : nw;
 		uint32_t entry = a0 * 64u;                                 // (exact for segment 0)
 		for (uint32_t w = a0; w < a1; ++w) {
 			uint32_t cur;
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __rest
 		if (a1 < nw) {
 			if (lane == 0) { s_used[seg + 1u] = entry; }
 			if (entry != a1 * 64u) {
-				const uint32_t wlim = (a1 + LZ4_SEGW < nw) ? a1 + LZ4_SEGW : nw;
+				const uint32_t wlim = (lz4_seg_start(seg + 2u) < nw) ? lz4_seg_start(seg + 2u) : nw;
 				for (uint32_t w = a1; w < wlim; ++w) {
 					while (__hip_atomic_load(&s_prog[seg + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= w) { __builtin_amdgcn_s_sleep(2); }
 					wave_fence();
@@ -560,11 +570,11 @@ __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __rest
 	LZ4_T(4)
 	// ---- C3. (wave 0) cascade check, then tokens / bytes before every window -----------------------------------------
 	if (wv == 0) {
-		for (uint32_t j = 1; j * LZ4_SEGW < nw; ++j) {
-			uint32_t e2 = s_endc[j * LZ4_SEGW - 1u];
+		for (uint32_t j = 1; j < LZ4_NSEG && lz4_seg_start(j) < nw; ++j) {
+			uint32_t e2 = s_endc[lz4_seg_start(j) - 1u];
 			if (e2 == s_used[j]) { continue; }                        // (else a repair ran through the whole of segment j-1: rare)
-			uint32_t wl = j * LZ4_SEGW;                               // first window NOT walked
-			for (uint32_t w = j * LZ4_SEGW; w < nw; ++w) {
+			uint32_t wl = lz4_seg_start(j);                           // first window NOT walked
+			for (uint32_t w = lz4_seg_start(j); w < nw; ++w) {
 				const uint32_t spec = s_endc[w];
 				uint32_t cur;
 				LZ4_WINDOW(w, e2, cur)
@@ -575,7 +585,7 @@ __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __rest
 				if (cur == spec) { break; }
 			}
 			// every seam this walk crossed is consistent now
-			if (lane == 0) { for (uint32_t jj = j + 1u; jj < 8u && jj * LZ4_SEGW < wl; ++jj) { s_used[jj] = s_endc[jj * LZ4_SEGW - 1u]; } }
+			if (lane == 0) { for (uint32_t jj = j + 1u; jj < LZ4_NSEG && lz4_seg_start(jj) < wl; ++jj) { s_used[jj] = s_endc[lz4_seg_start(jj) - 1u]; } }
 			wave_fence();
 		}
 	}

@@ -17,7 +17,7 @@ for mode in (1, 2):
     for u, g, s in zip(units, got, st):
         es, exp = orc.oracle_compress(2, u)
         bad += (s != 0) or (g != exp)
-    data = corpus.by_name("mozilla"); n = len(data)
+    data = np.concatenate([corpus.by_name(x) for x in (sys.argv[1:] or ["mozilla"])]); n = len(data)
     ctx = m.Context(); dev = torch.device("cuda", 0)
     cap = m.max_compressed_size(2, n) + 2
     d_in = torch.from_numpy(data).to(dev); d_out = torch.empty(cap + 16, dtype=torch.uint8, device=dev)
@@ -28,7 +28,7 @@ for mode in (1, 2):
     for _ in range(10): plan.execute(d_in, d_out, d_len, d_st)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
     import hashlib
-    print("lznt1 mode %d: edge units %d bad %d; mozilla %.3f ms per pass (%.1f GB/s), out %d sha %s" % (mode, len(units), bad, dt * 1e3, n / dt / 1e9, int(d_len[0]), hashlib.sha256(bytes(d_out[: int(d_len[0])].cpu().numpy())).hexdigest()[:16]))
+    print(("lznt1 mode %d: edge units %d bad %d; " + "+".join(sys.argv[1:] or ["mozilla"]) + " %.3f ms per pass (%.1f GB/s), out %d sha %s") % (mode, len(units), bad, dt * 1e3, n / dt / 1e9, int(d_len[0]), hashlib.sha256(bytes(d_out[: int(d_len[0])].cpu().numpy())).hexdigest()[:16]))
 lib.mscomp_amd_debug_set_lznt1(0)
 if hasattr(lib, "mscomp_amd_debug_lz4_prof") or True:
     import ctypes as C
