@@ -216,3 +216,44 @@ def test_lznt1_chunk_kernels_agree(oracle, gpu_ctx, mode):
         _check_units(m, oracle, FMTS["lznt1"], units, gpu_ctx)
     finally:
         gpu_ctx.lib.mscomp_amd_debug_set_lznt1(0)
+
+
+@pytest.mark.parametrize("fmt", list(FMTS))
+def test_plan_reuse_replays_a_graph(oracle, gpu_ctx, fmt):
+    """A plan executed repeatedly replays its launches as a hipGraph from the second execution on; the graph must be
+    re-captured when the buffers change (different input tensor, different output tensor) and when another plan grows the
+    context's scratch. Every execution must give the reference's bytes."""
+    import torch
+    import ms_compress_amd as m
+    rng = np.random.default_rng(11)
+    def batch(seed):
+        r = np.random.default_rng(seed)
+        return [np.frombuffer((b"lorem ipsum dolor sit amet %d " % seed) * 900, dtype=np.uint8), r.integers(0, 3, 40000, dtype=np.uint8),
+                np.zeros(70000, dtype=np.uint8), r.integers(0, 256, 9000, dtype=np.uint8)]
+    dev = torch.device("cuda", 0)
+    def run(plan, units, d_in, d_out, caps, out_off):
+        d_len = torch.zeros(len(units), dtype=torch.int64, device=dev); d_st = torch.full((len(units),), -99, dtype=torch.int32, device=dev)
+        plan.execute(d_in, d_out, d_len, d_st); torch.cuda.synchronize()
+        out = d_out.cpu().numpy(); ln = d_len.cpu().numpy()
+        for i, u in enumerate(units):
+            es, exp = oracle.oracle_compress(FMTS[fmt], u)
+            assert int(d_st[i]) == 0 and bytes(out[int(out_off[i]): int(out_off[i]) + int(ln[i])]) == exp
+    units = batch(1)
+    lens = [len(u) for u in units]
+    in_off, in_total = m.pack_offsets(lens)
+    caps = [m.max_compressed_size(FMTS[fmt], n) + 2 for n in lens]
+    out_off, out_total = m.pack_offsets(caps)
+    plan = m.Plan(gpu_ctx, FMTS[fmt], in_off, lens, out_off, caps)
+    def upload(us):
+        buf = np.zeros(in_total + 16, dtype=np.uint8)
+        for o, u in zip(in_off, us): buf[int(o): int(o) + len(u)] = u
+        return torch.from_numpy(buf).to(dev)
+    d_in1 = upload(units); d_out1 = torch.zeros(out_total + 16, dtype=torch.uint8, device=dev)
+    for _ in range(3): run(plan, units, d_in1, d_out1, caps, out_off)          # eager, capture, replay
+    units2 = [rng.permutation(u) if i == 1 else u for i, u in enumerate(units)]  # same lengths, other bytes, other tensors
+    d_in2 = upload(units2); d_out2 = torch.zeros(out_total + 16, dtype=torch.uint8, device=dev)
+    for _ in range(2): run(plan, units2, d_in2, d_out2, caps, out_off)         # re-capture, replay
+    big = [np.tile(units[0], 40)]                                               # a larger plan grows (moves) the shared scratch
+    m.compress_units(FMTS[fmt], big, ctx=gpu_ctx)
+    for _ in range(2): run(plan, units, d_in1, d_out1, caps, out_off)          # re-capture after the scratch moved, replay
+    plan.close()
