@@ -52,6 +52,14 @@ size_t       xpress_max_compressed_size(size_t in_len);
 MSCompStatus xpress_huff_compress(const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
 size_t       xpress_huff_max_compressed_size(size_t in_len);
 
+/* Decompressors. Same contract as the reference: *out_len holds the capacity on entry and the number of
+ * bytes produced on MSCOMP_OK; MSCOMP_BUF_ERROR when the output (or what is left of the input) does not fit,
+ * MSCOMP_DATA_ERROR for a malformed stream.
+ *   ms_decompress      include/mscomp.h:79,   src/mscomp.cpp:119-134               -> ms_decompress
+ *   lznt1_decompress   include/lznt1.h:51,    src/lznt1_decompress.cpp:293 (the inflate wrapper, internal.h:616-630) -> lznt1_decompress */
+MSCompStatus ms_decompress(MSCompFormat format, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
+MSCompStatus lznt1_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
+
 /* ================= Part 2: batch interface (device pointers) ================= */
 typedef struct mscomp_amd_ctx  mscomp_amd_ctx;    /* one per (device, stream); owns scratch in HBM  */
 typedef struct mscomp_amd_plan mscomp_amd_plan;   /* unit layout of one batch, uploaded once        */
@@ -85,6 +93,18 @@ MSCompStatus mscomp_amd_compress_batch(mscomp_amd_ctx* ctx, MSCompFormat format,
                                        const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len,
                                        uint8_t* d_out, const uint64_t* out_off, const uint64_t* out_cap,
                                        uint64_t* d_out_len, int32_t* d_status);
+
+/* The same for decompression: unit i holds one compressed buffer (what one ms_decompress call takes), out_cap[i] is the
+ * capacity the caller passes in *out_len. d_status[i] is MSCOMP_OK / MSCOMP_BUF_ERROR / MSCOMP_DATA_ERROR exactly as the
+ * reference's one-shot call returns them; d_out_len[i] is the decompressed size on MSCOMP_OK (0 otherwise; the output bytes
+ * of a failed unit are unspecified). Executed with mscomp_amd_plan_execute. Units are limited to 4 GiB - 256 of input. */
+MSCompStatus mscomp_amd_plan_create_decompress(mscomp_amd_ctx* ctx, MSCompFormat format, size_t n_units,
+                                               const uint64_t* in_off, const uint64_t* in_len,
+                                               const uint64_t* out_off, const uint64_t* out_cap, mscomp_amd_plan** plan);
+MSCompStatus mscomp_amd_decompress_batch(mscomp_amd_ctx* ctx, MSCompFormat format, size_t n_units,
+                                         const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len,
+                                         uint8_t* d_out, const uint64_t* out_off, const uint64_t* out_cap,
+                                         uint64_t* d_out_len, int32_t* d_status);
 
 /* ---- measurement hooks (bench.py / profiles) ---- */
 /* When enabled, every kernel launch of plan_execute is bracketed by hipEvents on the ctx stream. */

@@ -28,6 +28,7 @@ EXPORTS = [  # every symbol include/mscomp_amd.h declares (tests check the libra
     "xpress_huff_compress", "xpress_huff_max_compressed_size",
     "mscomp_amd_ctx_create", "mscomp_amd_ctx_destroy", "mscomp_amd_plan_create", "mscomp_amd_plan_destroy",
     "mscomp_amd_plan_execute", "mscomp_amd_compress_batch", "mscomp_amd_profile_enable", "mscomp_amd_profile_read",
+    "ms_decompress", "lznt1_decompress", "mscomp_amd_plan_create_decompress", "mscomp_amd_decompress_batch",
     "mscomp_amd_version", "mscomp_amd_debug_xpress_matches", "mscomp_amd_debug_lds_lane_order", "mscomp_amd_debug_set_xpress_emit", "mscomp_amd_debug_set_lznt1",
 ]
 
@@ -76,6 +77,16 @@ def load_library():
     lib.mscomp_amd_compress_batch.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mscomp_amd_compress_batch.restype = C.c_int
+    lib.ms_decompress.argtypes = [C.c_int] + one_shot
+    lib.ms_decompress.restype = C.c_int
+    for name in ("lznt1",):
+        f = getattr(lib, name + "_decompress")
+        f.argtypes = one_shot
+        f.restype = C.c_int
+    lib.mscomp_amd_plan_create_decompress.argtypes = lib.mscomp_amd_plan_create.argtypes
+    lib.mscomp_amd_plan_create_decompress.restype = C.c_int
+    lib.mscomp_amd_decompress_batch.argtypes = lib.mscomp_amd_compress_batch.argtypes
+    lib.mscomp_amd_decompress_batch.restype = C.c_int
     lib.mscomp_amd_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.mscomp_amd_profile_enable.restype = None
     lib.mscomp_amd_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -109,6 +120,20 @@ def compress(fmt, data, out_capacity=None):
     st = lib.ms_compress(int(fmt), data, len(data), out, C.byref(n))
     if st != MSCOMP_OK:
         raise MSCompError(st, "ms_compress(format=%d, in_len=%d, capacity=%d)" % (fmt, len(data), cap))
+    return out.raw[: n.value]
+
+
+def decompress(fmt, data, out_capacity):
+    """One-shot ``ms_decompress`` with HOST buffers (mscomp.h:79): ``out_capacity`` is what the caller passes in *out_len.
+    Returns the decompressed bytes or raises MSCompError(status)."""
+    lib = load_library()
+    data = bytes(data)
+    cap = int(out_capacity)
+    out = C.create_string_buffer(cap + 1)
+    n = C.c_size_t(cap)
+    st = lib.ms_decompress(int(fmt), data, len(data), out, C.byref(n))
+    if st != MSCOMP_OK:
+        raise MSCompError(st, "ms_decompress(format=%d, in_len=%d, capacity=%d)" % (fmt, len(data), cap))
     return out.raw[: n.value]
 
 
@@ -167,14 +192,15 @@ class Context:
 class Plan:
     """mscomp_amd_plan: the unit layout of one batch (offset tables uploaded once, scratch sized once)."""
 
-    def __init__(self, ctx, fmt, in_off, in_len, out_off, out_cap):
+    def __init__(self, ctx, fmt, in_off, in_len, out_off, out_cap, decompress=False):
         self.ctx, self.fmt = ctx, int(fmt)
         arrs = [np.ascontiguousarray(a, dtype=np.uint64) for a in (in_off, in_len, out_off, out_cap)]
         assert all(a.ndim == 1 and a.shape == arrs[0].shape for a in arrs)
         self.in_off, self.in_len, self.out_off, self.out_cap = arrs
         self.n_units = len(self.in_off)
         self._h = C.c_void_p()
-        st = ctx.lib.mscomp_amd_plan_create(ctx._h, self.fmt, self.n_units, *[a.ctypes.data for a in arrs], C.byref(self._h))
+        create = ctx.lib.mscomp_amd_plan_create_decompress if decompress else ctx.lib.mscomp_amd_plan_create
+        st = create(ctx._h, self.fmt, self.n_units, *[a.ctypes.data for a in arrs], C.byref(self._h))
         if st != MSCOMP_OK:
             raise MSCompError(st, "mscomp_amd_plan_create")
 
@@ -197,7 +223,13 @@ class Plan:
             pass
 
 
-def compress_units(fmt, units, ctx=None, capacities=None):
+def decompress_units(fmt, units, capacities, ctx=None):
+    """Decompress a list of independent compressed buffers on the GPU (each exactly as one ms_decompress call would, with
+    *out_len = capacities[i] on entry). Returns (list of bytes, or None where the status is not MSCOMP_OK; list of status)."""
+    return compress_units(fmt, units, ctx=ctx, capacities=capacities, decompress=True)
+
+
+def compress_units(fmt, units, ctx=None, capacities=None, decompress=False):
     """Compress a list of independent byte strings on the GPU (each exactly as one ms_compress call would).
     ``capacities`` (optional) gives the exact output capacity of every unit (default: ms_max_compressed_size+2).
     Returns (list of compressed bytes, or None where the unit got MSCOMP_BUF_ERROR; list of status)."""
@@ -222,7 +254,7 @@ def compress_units(fmt, units, ctx=None, capacities=None):
         d_out = torch.zeros(out_total + 16, dtype=torch.uint8, device=dev)
         d_len = torch.zeros(max(1, len(units)), dtype=torch.int64, device=dev)
         d_st = torch.zeros(max(1, len(units)), dtype=torch.int32, device=dev)
-        plan = Plan(ctx, fmt, in_off, lens, out_off, caps)
+        plan = Plan(ctx, fmt, in_off, lens, out_off, caps, decompress=decompress)
         plan.execute(d_in, d_out, d_len, d_st)
         ctx.stream.synchronize()
         h_out, h_len, h_st = d_out.cpu().numpy(), d_len.cpu().numpy(), d_st.cpu().numpy()

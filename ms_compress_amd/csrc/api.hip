@@ -45,6 +45,7 @@ struct mscomp_amd_ctx {
 	DevBuf wtok, wmat, wfar;                           // Xpress parse records per 64-position window (token mask, match mask, far length)
 	DevBuf wrec, sbrec;                                // ... state / counts / prefixes per window (6 x u32), per super-block (tot 4 x u32, pre 3 x u64, seams)
 	DevBuf tokbits, counts, extra, lens, codes, fb_list, fbflag;   // Xpress+Huffman per-chunk scratch
+	DevBuf dz_cin, dz_csize, dz_unit;                  // LZNT1 decompression: header offset / decoded size per chunk slot, per-unit records
 	DevBuf one_in, one_out, one_meta;                  // staging of the host-pointer one-shot path
 	bool profiling = false;
 	std::vector<ProfRec> recs;
@@ -54,6 +55,7 @@ struct mscomp_amd_ctx {
 struct mscomp_amd_plan {
 	mscomp_amd_ctx* ctx = nullptr;
 	MSCompFormat format = MSCOMP_NONE;
+	bool decompress = false;
 	uint32_t n_units = 0, n_chunks = 0;
 	uint64_t total_in = 0;
 	DevBuf tables;                                     // in_off | out_off | chunk_prefix
@@ -86,8 +88,9 @@ struct KernelTimer {
 	~KernelTimer() { if (c->profiling) { (void)hipEventRecord(r.b, c->stream); c->recs.push_back(r); } }
 };
 
-uint32_t chunks_of(MSCompFormat f, uint64_t n)
+uint32_t chunks_of(MSCompFormat f, bool decompress, uint64_t n)
 {
+	if (decompress) { return f == MSCOMP_LZNT1 ? (uint32_t)(n / 3u + 1u) : 1u; }   // LZNT1: a chunk is at least a header and one byte
 	switch (f) {
 	case MSCOMP_LZNT1:       return (uint32_t)((n + 4095u) / 4096u);
 	case MSCOMP_XPRESS_HUFF: return (uint32_t)((n + 65535u) / 65536u);   // n==0 -> 0 chunks, 0 bytes of output
@@ -143,6 +146,7 @@ void mscomp_amd_ctx_destroy(mscomp_amd_ctx* c)
 	c->wtok.release(); c->wmat.release(); c->wfar.release(); c->wrec.release(); c->sbrec.release();
 	c->tokbits.release(); c->counts.release(); c->extra.release(); c->lens.release(); c->codes.release();
 	c->fb_list.release(); c->fbflag.release();
+	c->dz_cin.release(); c->dz_csize.release(); c->dz_unit.release();
 	delete c;
 }
 
@@ -166,9 +170,9 @@ int mscomp_amd_profile_read(mscomp_amd_ctx* c, const char** names, double* ms, u
 	return n;
 }
 
-MSCompStatus mscomp_amd_plan_create(mscomp_amd_ctx* c, MSCompFormat format, size_t n_units,
-                                    const uint64_t* in_off, const uint64_t* in_len,
-                                    const uint64_t* out_off, const uint64_t* out_cap, mscomp_amd_plan** out)
+static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, bool decompress, size_t n_units,
+                                     const uint64_t* in_off, const uint64_t* in_len,
+                                     const uint64_t* out_off, const uint64_t* out_cap, mscomp_amd_plan** out)
 {
 	if (!out) { return MSCOMP_ARG_ERROR; }
 	*out = nullptr;
@@ -178,7 +182,7 @@ MSCompStatus mscomp_amd_plan_create(mscomp_amd_ctx* c, MSCompFormat format, size
 	if (!g.ok) { return MSCOMP_ERRNO; }
 	mscomp_amd_plan* p = new (std::nothrow) mscomp_amd_plan();
 	if (!p) { return MSCOMP_MEM_ERROR; }
-	p->ctx = c; p->format = format; p->n_units = (uint32_t)n_units;
+	p->ctx = c; p->format = format; p->decompress = decompress; p->n_units = (uint32_t)n_units;
 
 	std::vector<uint64_t> host(n_units * 4 + (n_units + 2) / 2 + 1);
 	uint64_t* h = host.data();
@@ -187,7 +191,8 @@ MSCompStatus mscomp_amd_plan_create(mscomp_amd_ctx* c, MSCompFormat format, size
 	for (size_t i = 0; i < n_units; ++i) {
 		h[i] = in_off[i]; h[n_units + i] = in_len[i]; h[2 * n_units + i] = out_off[i]; h[3 * n_units + i] = out_cap[i];
 		h_cp[i] = (uint32_t)chunks;
-		chunks += chunks_of(format, in_len[i]);
+		if (decompress && in_len[i] > 0xFFFFFF00u) { delete p; return MSCOMP_ARG_ERROR; }   // chunk offsets inside a unit are 32-bit
+		chunks += chunks_of(format, decompress, in_len[i]);
 		total += in_len[i];
 		if (chunks > 0x7FFFFFF0u) { delete p; return MSCOMP_ARG_ERROR; }
 	}
@@ -204,6 +209,16 @@ MSCompStatus mscomp_amd_plan_create(mscomp_amd_ctx* c, MSCompFormat format, size
 	p->bt.n_units = p->n_units; p->bt.n_chunks = p->n_chunks;
 
 	// size the ctx scratch now so that execute() never allocates
+	if (decompress) {
+		bool okd = c->prefix.reserve(((size_t)n_units + 2) * sizeof(uint64_t)) && c->tile_sums.reserve(((size_t)n_units / 1024 + 4) * sizeof(uint64_t));
+		if (okd && format == MSCOMP_LZNT1) {
+			okd = c->dz_cin.reserve((size_t)p->n_chunks * 4 + 64) && c->dz_csize.reserve((size_t)p->n_chunks * 2 + 64) &&
+			      c->dz_unit.reserve(((size_t)n_units + 1) * 16 + 64);
+		}
+		if (!okd) { p->tables.release(); delete p; return MSCOMP_MEM_ERROR; }
+		*out = p;
+		return MSCOMP_OK;
+	}
 	bool ok = c->slot_size.reserve(((size_t)p->n_chunks + 1) * sizeof(uint32_t)) &&
 	          c->prefix.reserve(((size_t)p->n_chunks + 2) * sizeof(uint64_t)) &&
 	          c->tile_sums.reserve(((size_t)p->n_chunks / 1024 + 4) * sizeof(uint64_t));
@@ -228,6 +243,17 @@ MSCompStatus mscomp_amd_plan_create(mscomp_amd_ctx* c, MSCompFormat format, size
 	if (!ok) { p->tables.release(); delete p; return MSCOMP_MEM_ERROR; }
 	*out = p;
 	return MSCOMP_OK;
+}
+
+MSCompStatus mscomp_amd_plan_create(mscomp_amd_ctx* c, MSCompFormat format, size_t n_units, const uint64_t* in_off, const uint64_t* in_len,
+                                    const uint64_t* out_off, const uint64_t* out_cap, mscomp_amd_plan** out)
+{
+	return plan_create_impl(c, format, false, n_units, in_off, in_len, out_off, out_cap, out);
+}
+MSCompStatus mscomp_amd_plan_create_decompress(mscomp_amd_ctx* c, MSCompFormat format, size_t n_units, const uint64_t* in_off, const uint64_t* in_len,
+                                               const uint64_t* out_off, const uint64_t* out_cap, mscomp_amd_plan** out)
+{
+	return plan_create_impl(c, format, true, n_units, in_off, in_len, out_off, out_cap, out);
 }
 
 void mscomp_amd_plan_destroy(mscomp_amd_plan* p)
@@ -265,6 +291,24 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 	uint32_t* slot_size = static_cast<uint32_t*>(c->slot_size.p);
 	u64* prefix = static_cast<u64*>(c->prefix.p);
 	u64* tile_sums = static_cast<u64*>(c->tile_sums.p);
+	if (p->decompress) {
+		switch (p->format) {
+		case MSCOMP_LZNT1: {
+			LzdBufs b;
+			b.cin = static_cast<uint32_t*>(c->dz_cin.p); b.csize = static_cast<uint16_t*>(c->dz_csize.p);
+			b.cnt = static_cast<uint32_t*>(c->dz_unit.p); b.stop = b.cnt + (p->n_units + 1u); b.irregular = b.stop + 2u * (p->n_units + 1u);
+			b.start = prefix;
+			{ KernelTimer t(c, "lzd_scan_kernel"); launch_lzd_scan(st, d_in, p->bt, b); }
+			{ KernelTimer t(c, "scan_sizes"); launch_scan_sizes(st, b.cnt, prefix, p->n_units, tile_sums); }
+			{ KernelTimer t(c, "lzd_chunk_kernel"); launch_lzd_chunks(st, d_in, p->bt, b, d_out, 0); }
+			{ KernelTimer t(c, "lzd_finalize_kernel"); launch_lzd_finalize(st, p->bt, b, d_out_len, d_status); }
+			{ KernelTimer t(c, "lzd_replace_kernel"); launch_lzd_chunks(st, d_in, p->bt, b, d_out, 1); }
+			return MSCOMP_OK;
+		}
+		default:
+			return MSCOMP_ARG_ERROR;
+		}
+	}
 	switch (p->format) {
 	case MSCOMP_LZNT1: {
 		uint8_t* slots = static_cast<uint8_t*>(c->slots.p);
@@ -354,6 +398,21 @@ MSCompStatus mscomp_amd_compress_batch(mscomp_amd_ctx* c, MSCompFormat format, s
 	return s;
 }
 
+MSCompStatus mscomp_amd_decompress_batch(mscomp_amd_ctx* c, MSCompFormat format, size_t n_units,
+                                       const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len,
+                                       uint8_t* d_out, const uint64_t* out_off, const uint64_t* out_cap,
+                                       uint64_t* d_out_len, int32_t* d_status)
+{
+	mscomp_amd_plan* p = nullptr;
+	MSCompStatus s = mscomp_amd_plan_create_decompress(c, format, n_units, in_off, in_len, out_off, out_cap, &p);
+	if (s != MSCOMP_OK) { return s; }
+	s = mscomp_amd_plan_execute(p, d_in, d_out, d_out_len, d_status);
+	DeviceGuard g(c->device);
+	if (hipStreamSynchronize(c->stream) != hipSuccess && s == MSCOMP_OK) { s = MSCOMP_ERRNO; }
+	mscomp_amd_plan_destroy(p);
+	return s;
+}
+
 // Stage-level test hook: per-position (len-3 capped at 45, offset) of ONE unit as found by the HIP match finder.
 // h_len3/h_off: host arrays of in_len u16. max_off 0x2000 (Xpress) or 0xFFFF (Xpress+Huffman, clip to 64 KiB chunks).
 MSCompStatus mscomp_amd_debug_xpress_matches(mscomp_amd_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t max_off, int clip,
@@ -392,7 +451,7 @@ uint32_t mscomp_amd_debug_lds_lane_order(mscomp_amd_ctx* c, uint32_t seed, uint3
 }
 
 // ---- drop-in one-shot path (host pointers): H2D, one-unit batch on the GPU, D2H. No CPU encoder exists here. ----
-static MSCompStatus one_shot(MSCompFormat format, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len)
+static MSCompStatus one_shot(MSCompFormat format, bool decompress, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len)
 {
 	if (!out_len || (in_len && !in) || (*out_len && !out)) { return MSCOMP_ARG_ERROR; }
 	thread_local mscomp_amd_ctx* tl_ctx = nullptr;            // reentrant: one context per calling host thread
@@ -407,27 +466,42 @@ static MSCompStatus one_shot(MSCompFormat format, const uint8_t* in, size_t in_l
 	uint8_t* d_in = static_cast<uint8_t*>(c->one_in.p); uint8_t* d_out = static_cast<uint8_t*>(c->one_out.p);
 	uint64_t* d_len = static_cast<uint64_t*>(c->one_meta.p); int32_t* d_st = reinterpret_cast<int32_t*>(d_len + 1);
 	if (in_len && hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, c->stream) != hipSuccess) { return MSCOMP_ERRNO; }
-	MSCompStatus s = mscomp_amd_compress_batch(c, format, 1, d_in, in_off, in_ln, d_out, out_off, out_cp, d_len, d_st);
+	MSCompStatus s = decompress ? mscomp_amd_decompress_batch(c, format, 1, d_in, in_off, in_ln, d_out, out_off, out_cp, d_len, d_st)
+	                            : mscomp_amd_compress_batch(c, format, 1, d_in, in_off, in_ln, d_out, out_off, out_cp, d_len, d_st);
 	if (s != MSCOMP_OK) { return s; }
 	struct { uint64_t len; int32_t st; int32_t pad; } meta;
 	if (hipMemcpy(&meta, d_len, sizeof meta, hipMemcpyDeviceToHost) != hipSuccess) { return MSCOMP_ERRNO; }
 	if (meta.st != MSCOMP_OK) { return (MSCompStatus)meta.st; }
 	size_t copy = (size_t)meta.len;
-	if (format == MSCOMP_LZNT1 && cap - copy >= 2) { copy += 2; }    // the uncounted End_of_buffer bytes (lznt1_compress.cpp:270)
+	if (!decompress && format == MSCOMP_LZNT1 && cap - copy >= 2) { copy += 2; }    // the uncounted End_of_buffer bytes (lznt1_compress.cpp:270)
 	if (copy && hipMemcpy(out, d_out, copy, hipMemcpyDeviceToHost) != hipSuccess) { return MSCOMP_ERRNO; }
 	*out_len = (size_t)meta.len;
 	return MSCOMP_OK;
 }
 
-MSCompStatus lznt1_compress(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)       { return one_shot(MSCOMP_LZNT1, in, n, out, out_len); }
-MSCompStatus xpress_compress(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)      { return one_shot(MSCOMP_XPRESS, in, n, out, out_len); }
-MSCompStatus xpress_huff_compress(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len) { return one_shot(MSCOMP_XPRESS_HUFF, in, n, out, out_len); }
+MSCompStatus lznt1_compress(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)       { return one_shot(MSCOMP_LZNT1, false, in, n, out, out_len); }
+MSCompStatus xpress_compress(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)      { return one_shot(MSCOMP_XPRESS, false, in, n, out, out_len); }
+MSCompStatus xpress_huff_compress(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len) { return one_shot(MSCOMP_XPRESS_HUFF, false, in, n, out, out_len); }
+
+// the decompressors (lznt1_decompress.cpp:293 via internal.h:616-630, ...): same staging, the decoding happens on the GPU
+MSCompStatus lznt1_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)       { return one_shot(MSCOMP_LZNT1, true, in, n, out, out_len); }
 
 #ifndef MSCOMP_AMD_NO_FACADE
+MSCompStatus ms_decompress(MSCompFormat format, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len)
+{
+	switch ((int)format) {
+	case MSCOMP_LZNT1: return one_shot(format, true, in, in_len, out, out_len);
+	case MSCOMP_NONE:                                               // mscomp.cpp:26-32
+		if (!out_len || in_len > *out_len) { return out_len ? MSCOMP_BUF_ERROR : MSCOMP_ARG_ERROR; }
+		if (in_len) { memcpy(out, in, in_len); }
+		*out_len = in_len; return MSCOMP_OK;
+	default: return MSCOMP_ARG_ERROR;                                // mscomp.cpp:131
+	}
+}
 MSCompStatus ms_compress(MSCompFormat format, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len)
 {
 	switch ((int)format) {
-	case MSCOMP_LZNT1: case MSCOMP_XPRESS: case MSCOMP_XPRESS_HUFF: return one_shot(format, in, in_len, out, out_len);
+	case MSCOMP_LZNT1: case MSCOMP_XPRESS: case MSCOMP_XPRESS_HUFF: return one_shot(format, false, in, in_len, out, out_len);
 	case MSCOMP_NONE:                                               // the reference's "copy" codec (mscomp.cpp:26-32): host memcpy
 		if (!out_len || in_len > *out_len) { return out_len ? MSCOMP_BUF_ERROR : MSCOMP_ARG_ERROR; }
 		if (in_len) { memcpy(out, in, in_len); }

@@ -35,6 +35,14 @@ void launch_xh_fallback(hipStream_t st, const uint8_t* d_in, const BatchTables& 
 void launch_xh_encode(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* mlen3, const uint16_t* moff,
                       const u64* tokbits, const uint8_t* lens, const uint16_t* codes, const uint32_t* fbflag, const u64* prefix, uint8_t* d_out);
 
+// ---- decompressors (decompress.hip) ----
+// LZNT1: chunk_prefix[u] = first of the in_len/3+1 chunk slots of unit u. cin: header offset per slot (u32), csize: decoded size or
+// 0x8000 (u16), cnt / stop (2 x u32) / irregular (+1 global flag) per unit, start: u64 exclusive scan of cnt (n_units+1).
+struct LzdBufs { uint32_t* cin; uint16_t* csize; uint32_t* cnt; uint32_t* stop; uint32_t* irregular; u64* start; };
+void launch_lzd_scan(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const LzdBufs& b);
+void launch_lzd_chunks(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const LzdBufs& b, uint8_t* d_out, int exact);
+void launch_lzd_finalize(hipStream_t st, const BatchTables& bt, const LzdBufs& b, u64* d_out_len, int32_t* d_status);
+
 // ---- utilities (util.hip) ----
 // prefix[0..n] = exclusive scan of sizes[0..n) as u64 (prefix[n] = total). block_sums: scratch of ceil(n/1024)+1 u64.
 void launch_scan_sizes(hipStream_t st, const uint32_t* sizes, u64* prefix, uint32_t n, u64* block_sums);

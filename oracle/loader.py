@@ -39,6 +39,7 @@ def load_oracle():
         lib.orc_compress.restype = C.c_int
         lib.orc_decompress.argtypes = lib.orc_compress.argtypes
         lib.orc_decompress.restype = C.c_int
+        lib.orc_last_undefined.restype = C.c_int
         lib.orc_max_compressed_size.argtypes = [C.c_int, C.c_size_t]
         lib.orc_max_compressed_size.restype = C.c_size_t
         lib.orc_huff_lengths.argtypes = [C.c_void_p, C.c_void_p]
@@ -86,6 +87,14 @@ def oracle_compress(fmt, data, cap=None):
 
 def oracle_decompress(fmt, data, out_len):
     return _one_shot(load_oracle().orc_decompress, fmt, data, out_len)
+
+
+def oracle_decompress_ex(fmt, data, cap):
+    """(status, bytes, undefined): ``undefined`` is True when the reference's behaviour on this stream is undefined
+    (the restatement then says DATA_ERROR and the compiled reference must not be asked)."""
+    lib = load_oracle()
+    st, out = _one_shot(lib.orc_decompress, fmt, data, cap)
+    return st, out, bool(lib.orc_last_undefined())
 
 
 def ref_compress(fmt, data, cap=None):

@@ -137,38 +137,72 @@ void orc_lznt1_match_table(const uint8_t* c, unsigned n, uint16_t* len, uint16_t
 	free(d);
 }
 
-/* LZNT1 decoder (format only; used for round trips). */
+/* LZNT1 decoder with the one-shot semantics of the reference: lznt1_decompress is the streaming inflate run once over the
+ * whole buffer (ALL_AT_ONCE_WRAPPER_DECOMPRESS, internal.h:616-630, over lznt1_inflate, lznt1_decompress.cpp:230-273, and
+ * lznt1_decompress_chunk_read, :122-209). One place of the reference is undefined behaviour: a literal token when the 4096-byte
+ * chunk limit is already reached is stored without a bounds check (:113). We report DATA_ERROR there and raise
+ * orc_last_undefined() so that the tests do not ask the compiled reference about such streams. */
+static __thread int orc_undefined_flag;
+int orc_last_undefined(void) { return orc_undefined_flag; }
+
+/* lznt1_decompress_chunk (:37-121) against a 4096-byte limit (:158,:179): 0 or ORC_DATA_ERROR (the callers turn every chunk
+ * error into DATA_ERROR, :160-166) */
+static int lznt1_chunk_decode_o(const uint8_t* in, size_t n, uint8_t* out, size_t* out_size)
+{
+	size_t ip = 0, op = 0;
+	while (ip < n) {
+		unsigned flags = in[ip++];
+		for (unsigned i = 0; i < 8; ++i, flags >>= 1) {
+			if (ip == n) { *out_size = op; return ORC_OK; }                                     /* :84 */
+			if (!(flags & 1)) {
+				if (op >= 4096) { orc_undefined_flag = 1; return ORC_DATA_ERROR; }              /* :113 (unchecked in the reference) */
+				out[op++] = in[ip++]; continue;
+			}
+			if (ip + 2 > n) { return ORC_DATA_ERROR; }                                          /* :88 */
+			unsigned shift, mask3; lznt1_split((unsigned)op, &shift, &mask3);                   /* :89 */
+			const uint32_t t = get16(in + ip); ip += 2;
+			const size_t off = (t >> shift) + 1; size_t len = (t & ((1u << shift) - 1)) + 3;
+			if (off > op) { return ORC_DATA_ERROR; }                                            /* :96 */
+			if (op + len > 4096) { return ORC_DATA_ERROR; }                                     /* :97 */
+			while (len--) { out[op] = out[op - off]; ++op; }
+		}
+	}
+	*out_size = op;
+	return ORC_OK;
+}
+
 static int lznt1_decompress_o(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)
 {
 	const size_t cap = *out_len;
 	size_t ip = 0, op = 0;
-	while (ip + 2 <= n) {
+	uint8_t tmp[4096 + 32];
+	orc_undefined_flag = 0;
+	while (cap - op && n - ip >= 2) {                                                           /* :252 */
 		const uint32_t hdr = get16(in + ip);
-		if (hdr == 0) { break; }
-		const size_t sz = (hdr & 0xFFF) + 1;
-		ip += 2;
-		if (ip + sz > n) { return ORC_DATA_ERROR; }
-		if (!(hdr & 0x8000)) {
-			if (op + sz > cap) { return ORC_BUF_ERROR; }
-			memcpy(out + op, in + ip, sz); op += sz; ip += sz; continue;
+		if (hdr == 0) {                                                                         /* :128-134 */
+			if (n - ip != 2) { return ORC_DATA_ERROR; }
+			*out_len = op; return ORC_OK;                                                       /* STREAM_END -> inflate_end OK */
 		}
-		const size_t end = ip + sz, base = op;
-		while (ip < end) {
-			unsigned flags = in[ip++];
-			for (unsigned i = 0; i < 8 && ip < end; ++i, flags >>= 1) {
-				if (!(flags & 1)) { if (op >= cap) { return ORC_BUF_ERROR; } out[op++] = in[ip++]; continue; }
-				if (ip + 2 > end) { return ORC_DATA_ERROR; }
-				unsigned shift, mask3; lznt1_split((unsigned)(op - base), &shift, &mask3);
-				const uint32_t t = get16(in + ip); ip += 2;
-				const size_t off = (t >> shift) + 1; size_t len = (t & ((1u << shift) - 1)) + 3;
-				if (off > op - base) { return ORC_DATA_ERROR; }
-				if (op + len > cap) { return ORC_BUF_ERROR; }
-				while (len--) { out[op] = out[op - off]; ++op; }
-			}
+		const size_t in_size = (hdr & 0xFFF) + 3;
+		if (in_size > n - ip) { return ORC_BUF_ERROR; }                                         /* :136-143: partial chunk kept as state, the call ends with MSCOMP_OK -> BUF_ERROR (wrapper :627) */
+		if ((hdr & 0x7000) != 0x3000) { return ORC_DATA_ERROR; }                                /* :151 */
+		size_t size;
+		if (hdr & 0x8000) {
+			if (lznt1_chunk_decode_o(in + ip + 2, in_size - 2, tmp, &size) != ORC_OK) { return ORC_DATA_ERROR; }   /* :160-166, :181-187 */
+			const size_t copy = size < cap - op ? size : cap - op;
+			memcpy(out + op, tmp, copy); op += copy;
+			if (copy < size) { return ORC_BUF_ERROR; }                                          /* :167-171: the rest waits in the state -> not a stream end */
+		} else {
+			size = in_size - 2;                                                                 /* :192-209 */
+			const size_t copy = size < cap - op ? size : cap - op;
+			memcpy(out + op, in + ip + 2, copy); op += copy;
+			if (copy < size) { return ORC_BUF_ERROR; }
 		}
+		ip += in_size;
 	}
-	*out_len = op;
-	return ORC_OK;
+	/* lznt1_is_possible_stream_end (:223-227): nothing left, or a single 0 byte */
+	if (n - ip == 0 || (n - ip == 1 && in[ip] == 0)) { *out_len = op; return ORC_OK; }
+	return ORC_BUF_ERROR;
 }
 
 /* ===================================================================================================

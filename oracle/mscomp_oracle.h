@@ -25,6 +25,7 @@ enum { ORC_OK = 0, ORC_ARG_ERROR = -2, ORC_DATA_ERROR = -3, ORC_MEM_ERROR = -4, 
 int    orc_compress(int format, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
 int    orc_decompress(int format, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
 size_t orc_max_compressed_size(int format, size_t in_len);
+int    orc_last_undefined(void);   /* 1 when the last orc_decompress of this thread met a stream on which the reference is undefined */
 
 /* Component oracles (intermediate goldens so kernel stages can be diffed one by one). */
 void orc_huff_lengths(const uint32_t counts[512], uint8_t lens[512]);            /* CreateCodes      */

@@ -42,3 +42,39 @@ def mixed_buffer(seed=2):
     rnd = random.Random(seed)
     return (b"some text here " * 7000 + bytes(100000) + bytes(rnd.getrandbits(8) for _ in range(70000))
             + b"ab" * 40000 + b"more text over there " * 3000)
+
+
+def decode_streams(fmt, compress, seed=5, n_corrupt=60):
+    """(stream, capacity) pairs for the decompressors: valid streams with exact / larger / smaller capacities, streams
+    with terminators and trailing bytes, truncated streams, concatenated streams (short chunks in the middle for LZNT1) and
+    randomly corrupted streams. ``compress(data) -> bytes`` is the checker's encoder."""
+    rnd = random.Random(seed)
+    plain = [family(k, n, rnd) for n in (0, 1, 2, 3, 17, 100, 4095, 4096, 4097, 8192, 12288 + 5, 70000) for k in ("words", "run", "random", "lz")]
+    plain.append(mixed_buffer()[60000:60000 + 150000])
+    out = []
+    comps = [(d, compress(d)) for d in plain]
+    for d, c in comps:
+        for cap in sorted({len(d), len(d) + 1, len(d) + 5000, max(0, len(d) - 1), len(d) // 2, 0}):
+            out.append((c, cap))
+        out.append((c + b"\0\0", len(d)))
+        out.append((c + b"\0\0", len(d) + 1))
+        out.append((c + b"\0\0\0", len(d) + 10))
+        out.append((c + b"\0", len(d) + 10))
+        out.append((c + b"\x07", len(d) + 10))
+        for k in sorted({1, 2, 3, len(c) // 3, len(c) // 2, len(c) - 2, len(c) - 1}):
+            if 0 < k < len(c):
+                out.append((c[:k], len(d) + 10))
+    for _ in range(12):                                      # concatenations
+        (d1, c1), (d2, c2), (d3, c3) = rnd.choice(comps), rnd.choice(comps), rnd.choice(comps)
+        out.append((c1 + c2 + c3, len(d1) + len(d2) + len(d3)))
+        out.append((c1 + c2 + c3, len(d1) + len(d2) + len(d3) + 4096))
+        out.append((c1 + c2, len(d1) + len(d2) // 2))
+    big = [x for x in comps if len(x[1]) > 200]
+    for _ in range(n_corrupt):                               # corruptions
+        d, c = rnd.choice(big)
+        b = bytearray(c)
+        for _ in range(rnd.choice((1, 1, 2, 5))):
+            i = rnd.randrange(len(b))
+            b[i] = rnd.choice((b[i] ^ (1 << rnd.randrange(8)), rnd.getrandbits(8), 0, 0xFF))
+        out.append((bytes(b), len(d) + rnd.choice((0, 0, 100, 5000))))
+    return out

@@ -1,0 +1,85 @@
+"""GPU: the HIP decompressors against the checker (oracle restatement of the reference's one-shot
+semantics, itself pinned against the compiled reference in test_oracle_vs_ref.py) and against the compiled reference
+where it travelled (oracle/_ref)."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+FMTS = {"lznt1": 2}
+
+
+@pytest.mark.parametrize("fmt", list(FMTS))
+def test_decode_streams_match_checker(oracle, gpu_ctx, fmt):
+    """status and bytes of every stream family: valid / terminated / truncated / concatenated / corrupted, all capacities"""
+    import ms_compress_amd as m
+    f = FMTS[fmt]
+    streams = cases.decode_streams(f, lambda d: oracle.oracle_compress(f, d)[1])
+    outs, sts = m.decompress_units(f, [s for s, _ in streams], [c for _, c in streams], ctx=gpu_ctx)
+    ref = oracle.load_ref()
+    for (stream, cap), out, st in zip(streams, outs, sts):
+        so, oo, undefined = oracle.oracle_decompress_ex(f, stream, cap)
+        assert st == so, (len(stream), cap, st, so)
+        if so == 0:
+            assert out == oo, (len(stream), cap)
+        if ref is not None and not undefined:
+            sr, orf = oracle.ref_decompress(f, stream, cap)
+            assert (st, out if st == 0 else b"") == (sr, orf), (len(stream), cap)
+
+
+@pytest.mark.parametrize("fmt", list(FMTS))
+def test_round_trip_on_device(oracle, gpu_ctx, fmt):
+    """compress on the GPU, decompress on the GPU: the edge units of the compressor tests, in one batch"""
+    import ms_compress_amd as m
+    f = FMTS[fmt]
+    units = cases.edge_cases() + [cases.mixed_buffer()]
+    comp, st = m.compress_units(f, units, ctx=gpu_ctx)
+    assert all(s == 0 for s in st)
+    back, st2 = m.decompress_units(f, comp, [len(u) for u in units], ctx=gpu_ctx)
+    assert st2 == [0] * len(units)
+    assert back == units
+
+
+@pytest.mark.parametrize("fmt", list(FMTS))
+def test_one_shot_decompress_host_pointers(oracle, gpu_ctx, fmt):
+    import ms_compress_amd as m
+    f = FMTS[fmt]
+    data = cases.mixed_buffer()
+    comp = oracle.oracle_compress(f, data)[1]
+    assert m.decompress(f, comp, len(data)) == data
+    assert m.decompress(f, comp, len(data) + 77) == data
+    with pytest.raises(m.MSCompError) as e:
+        m.decompress(f, comp, len(data) - 1)
+    assert e.value.status == m.MSCOMP_BUF_ERROR
+    bad = comp[:1] + bytes([comp[1] ^ 0x40]) + comp[2:]           # first chunk header: wrong signature
+    want = oracle.oracle_decompress_ex(f, bad, len(data))[0]
+    assert want != 0
+    with pytest.raises(m.MSCompError) as e:
+        m.decompress(f, bad, len(data))
+    assert e.value.status == want
+    assert m.decompress(f, b"", 10) == b""
+
+
+def test_round_trip_full_size_lznt1(oracle, gpu_ctx):
+    """BASELINE configs[1] (mozilla-like, 51 220 480 B as one unit): GPU compress -> GPU decompress gives the input back"""
+    import torch
+    import ms_compress_amd as m
+    from ms_compress_amd import corpus
+    data = corpus.file_bytes(corpus.NAMES.index("mozilla"), 51_220_480)
+    n = len(data)
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(np.ascontiguousarray(data)).to(dev)
+    cap = m.max_compressed_size(2, n) + 2
+    d_c = torch.zeros(cap + 16, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(1, dtype=torch.int64, device=dev); d_st = torch.zeros(1, dtype=torch.int32, device=dev)
+    p = m.Plan(gpu_ctx, 2, [0], [n], [0], [cap]); p.execute(d_in, d_c, d_len, d_st); torch.cuda.synchronize(); p.close()
+    clen = int(d_len[0]); assert int(d_st[0]) == 0
+    d_back = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
+    q = m.Plan(gpu_ctx, 2, [0], [clen], [0], [n], decompress=True)
+    for _ in range(2):
+        d_len.zero_(); d_st.fill_(-9)
+        q.execute(d_c, d_back, d_len, d_st); torch.cuda.synchronize()
+        assert int(d_st[0]) == 0 and int(d_len[0]) == n
+        assert torch.equal(d_back[:n], d_in)
+    q.close()

@@ -78,3 +78,20 @@ def test_huffman_builders(oracle, ref):
         assert lens.tolist() == _huff_ref("fast", counts), "CreateCodes case %d" % case
         lib.orc_huff_lengths_slow(c.ctypes.data, lens.ctypes.data)
         assert lens.tolist() == _huff_ref("slow", counts), "CreateCodesSlow case %d" % case
+
+
+@pytest.mark.parametrize("fmt", [2])
+def test_decompress_semantics(oracle, ref, fmt):
+    """The restated decoders return the reference's status and bytes on valid, truncated, concatenated and corrupted
+    streams, for exact / larger / smaller capacities (streams on which the reference is undefined are not put to it)."""
+    streams = cases.decode_streams(fmt, lambda d: oracle.oracle_compress(fmt, d)[1])
+    asked = 0
+    for stream, cap in streams:
+        so, oo, undefined = oracle.oracle_decompress_ex(fmt, stream, cap)
+        if undefined:
+            assert so == -3
+            continue
+        sr, orf = oracle.ref_decompress(fmt, stream, cap)
+        assert (so, oo) == (sr, orf), (fmt, len(stream), cap, so, sr)
+        asked += 1
+    assert asked > len(streams) * 0.9
