@@ -29,7 +29,7 @@ EXPORTS = [  # every symbol include/mscomp_amd.h declares (tests check the libra
     "mscomp_amd_ctx_create", "mscomp_amd_ctx_destroy", "mscomp_amd_plan_create", "mscomp_amd_plan_destroy",
     "mscomp_amd_plan_execute", "mscomp_amd_compress_batch", "mscomp_amd_profile_enable", "mscomp_amd_profile_read",
     "ms_decompress", "lznt1_decompress", "mscomp_amd_plan_create_decompress", "mscomp_amd_decompress_batch",
-    "mscomp_amd_version", "mscomp_amd_debug_xpress_matches", "mscomp_amd_debug_lds_lane_order", "mscomp_amd_debug_set_xpress_emit", "mscomp_amd_debug_set_lznt1",
+    "mscomp_amd_version", "mscomp_amd_debug_xpress_matches", "mscomp_amd_debug_lds_lane_order", "mscomp_amd_debug_set_xpress_emit", "mscomp_amd_debug_set_lznt1", "mscomp_amd_debug_lzd_walked",
 ]
 
 
@@ -100,6 +100,8 @@ def load_library():
     lib.mscomp_amd_debug_set_xpress_emit.restype = None
     lib.mscomp_amd_debug_set_lznt1.argtypes = [C.c_int]
     lib.mscomp_amd_debug_set_lznt1.restype = None
+    lib.mscomp_amd_debug_lzd_walked.argtypes = [C.c_void_p]
+    lib.mscomp_amd_debug_lzd_walked.restype = C.c_uint32
     _lib = lib
     return lib
 

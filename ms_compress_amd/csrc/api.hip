@@ -90,7 +90,7 @@ struct KernelTimer {
 
 uint32_t chunks_of(MSCompFormat f, bool decompress, uint64_t n)
 {
-	if (decompress) { return f == MSCOMP_LZNT1 ? (uint32_t)(n / 3u + 1u) : 1u; }   // LZNT1: a chunk is at least a header and one byte
+	if (decompress) { return f == MSCOMP_LZNT1 ? (uint32_t)(n ? (n + LZD_SEG - 1u) / LZD_SEG : 1u) : 1u; }   // LZNT1: segments of the header walk
 	switch (f) {
 	case MSCOMP_LZNT1:       return (uint32_t)((n + 4095u) / 4096u);
 	case MSCOMP_XPRESS_HUFF: return (uint32_t)((n + 65535u) / 65536u);   // n==0 -> 0 chunks, 0 bytes of output
@@ -210,10 +210,10 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 
 	// size the ctx scratch now so that execute() never allocates
 	if (decompress) {
-		bool okd = c->prefix.reserve(((size_t)n_units + 2) * sizeof(uint64_t)) && c->tile_sums.reserve(((size_t)n_units / 1024 + 4) * sizeof(uint64_t));
+		bool okd = c->prefix.reserve(((size_t)p->n_chunks + 2) * sizeof(uint64_t)) && c->tile_sums.reserve(((size_t)p->n_chunks / 1024 + 4) * sizeof(uint64_t));
 		if (okd && format == MSCOMP_LZNT1) {
-			okd = c->dz_cin.reserve((size_t)p->n_chunks * 4 + 64) && c->dz_csize.reserve((size_t)p->n_chunks * 2 + 64) &&
-			      c->dz_unit.reserve(((size_t)n_units + 1) * 16 + 64);
+			okd = c->dz_cin.reserve((size_t)p->n_chunks * LZD_SLOTS * 4 + 64) && c->dz_csize.reserve((size_t)p->n_chunks * LZD_SLOTS * 2 + 64) &&
+			      c->dz_unit.reserve(((size_t)p->n_chunks * (5 * LZD_K + 2) + (size_t)n_units * 2 + 8) * 4);
 		}
 		if (!okd) { p->tables.release(); delete p; return MSCOMP_MEM_ERROR; }
 		*out = p;
@@ -296,10 +296,14 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 		case MSCOMP_LZNT1: {
 			LzdBufs b;
 			b.cin = static_cast<uint32_t*>(c->dz_cin.p); b.csize = static_cast<uint16_t*>(c->dz_csize.p);
-			b.cnt = static_cast<uint32_t*>(c->dz_unit.p); b.stop = b.cnt + (p->n_units + 1u); b.irregular = b.stop + 2u * (p->n_units + 1u);
-			b.start = prefix;
-			{ KernelTimer t(c, "lzd_scan_kernel"); launch_lzd_scan(st, d_in, p->bt, b); }
-			{ KernelTimer t(c, "scan_sizes"); launch_scan_sizes(st, b.cnt, prefix, p->n_units, tile_sums); }
+			const size_t nk = (size_t)p->n_chunks * LZD_K;
+			b.segL = static_cast<uint32_t*>(c->dz_unit.p); b.segE = b.segL + nk; b.segcnt = b.segE + nk; b.segstop = b.segcnt + nk; b.segoff = b.segstop + nk;
+			b.selcnt = b.segoff + nk; b.seloff = b.selcnt + p->n_chunks;
+			b.stop = b.seloff + p->n_chunks; b.irregular = b.stop + p->n_units + 1u;
+			b.flat = prefix;
+			{ KernelTimer t(c, "lzd_seg_kernel"); launch_lzd_segments(st, d_in, p->bt, b); }
+			{ KernelTimer t(c, "lzd_verify_kernel"); launch_lzd_verify(st, d_in, p->bt, b); }
+			{ KernelTimer t(c, "scan_sizes"); launch_scan_sizes(st, b.selcnt, prefix, p->n_chunks, tile_sums); }
 			{ KernelTimer t(c, "lzd_chunk_kernel"); launch_lzd_chunks(st, d_in, p->bt, b, d_out, 0); }
 			{ KernelTimer t(c, "lzd_finalize_kernel"); launch_lzd_finalize(st, p->bt, b, d_out_len, d_status); }
 			{ KernelTimer t(c, "lzd_replace_kernel"); launch_lzd_chunks(st, d_in, p->bt, b, d_out, 1); }
@@ -438,6 +442,14 @@ MSCompStatus mscomp_amd_debug_xpress_matches(mscomp_amd_ctx* c, const uint8_t* d
 // Test hook: which Xpress parse/emit kernel runs (0 = chosen by batch size, 1 = one wave per unit, 2 = four waves per unit).
 void mscomp_amd_debug_set_xpress_emit(int mode) { set_xpress_emit_mode(mode); ++g_scratch_epoch; }
 // ... and which LZNT1 chunk kernel (0 = default, 1 = one wave per chunk, 2 = four waves per chunk).
+uint32_t mscomp_amd_debug_lzd_walked(mscomp_amd_ctx* c)
+{
+	if (!c) { return 0xFFFFFFFFu; }
+	DeviceGuard g(c->device);
+	if (!g.ok || hipStreamSynchronize(c->stream) != hipSuccess) { return 0xFFFFFFFFu; }
+	return lzd_read_walked();
+}
+
 void mscomp_amd_debug_set_lznt1(int mode) { set_lznt1_mode(mode); ++g_scratch_epoch; }
 
 // Hardware self-check (see util.hip): lanes whose returning LDS atomic was NOT served in lane order, summed over

@@ -10,75 +10,207 @@
 //   * a chunk may decode to fewer than 4096 bytes anywhere in the stream - the next chunk continues right behind it;
 //   * output that does not fit (or input left when the output is full) gives BUF_ERROR; a single trailing byte is accepted
 //     when it is 0 (:223-227).
-// The chunks of a unit are independent once their headers are known, so the work is: (1) one block per unit walks the
-// header chain through an LDS window, (2) one wave per chunk decodes in LDS and writes the chunk where it lands if every
-// earlier chunk holds 4096 bytes, (3) one wave per unit adds the sizes up, decides the status and notices units with short
-// chunks in the middle, (4) whose chunks are decoded again to their exact places.
+// The chunks of a unit are independent once their headers are known, but the headers form a chain (each gives the distance
+// to the next). The chain is walked in parallel, speculatively: (1) the compressed input of a unit is cut into segments of
+// LZD_SEG bytes; the block of segment s tries every offset of the 4098 bytes that start LZD_HEAD bytes before the segment
+// as a header and follows it: wrong guesses die at the first header without the 011 signature (7 of 8 random words), the
+// ones that live until the segment begins all arrive at the same header - the landing L_s - which is then followed through
+// the segment to the first header of the next one, E_s. (2) One wave per unit checks E_s == L_(s+1) for all s (segment 0
+// starts at offset 0, so by induction every chain is the true one), walks the segments again where that fails, and
+// counts. (3) One wave per chunk decodes in LDS and writes the chunk where it lands if every earlier chunk holds 4096
+// bytes, (4) one wave per unit adds the sizes up, decides the status and notices units with short chunks in the middle,
+// (5) whose chunks are decoded again to their exact places.
 #include "kernels.h"
 
 namespace msc {
 
 // ===================================================================================================================
-// (1) header chain
+// (1) header chain, speculative per segment
 // ===================================================================================================================
-#define LZD_WIN 65536u                  // bytes per LDS window (two windows: the next one loads while the chain walks this one)
-#define LZD_SCAN_THREADS 1024u
-#define LZD_SCAN_LDS (2u * (LZD_WIN + 16u))
+#define LZD_THREADS 1024u
+#define LZD_WINDOW (LZD_HEAD + LZD_SEG + 16u)                      // candidate region + segment + the header that ends it
+#define LZD_LDS (LZD_WINDOW + 48u)
+#define LZD_NONE  0xFFFFFFFFu                                      // no (unique) landing
+#define LZD_ENDED 0xFFFFFFFEu                                      // the chain ended (end of input or a stop) before the segment / inside it
 enum { LZD_EOI0 = 0, LZD_EOI1 = 1, LZD_ZERO_OK = 2, LZD_ZERO_BAD = 3, LZD_TRUNC = 4, LZD_BADSIG = 5 };
 
-// cin[chunk_prefix[u] + j] = offset of the header of chunk j in unit u; cnt[u] chunks; stop[2u] = what ended the walk | last byte << 8, stop[2u+1] = where
-__global__ __launch_bounds__(LZD_SCAN_THREADS) void lzd_scan_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, uint32_t* __restrict__ cin,
-                                                                 uint32_t* __restrict__ cnt, uint32_t* __restrict__ stop)
+// One step of the walk of :122-153 at offset pos of a unit of n bytes whose bytes are read through rd(pos):
+// returns 0 and advances pos, or 1 + the reason the walk ends here.
+template <typename RD>
+__device__ __forceinline__ uint32_t lzd_step(uint32_t& pos, uint32_t n, RD rd, uint32_t& last)
 {
-	extern __shared__ __attribute__((aligned(16))) uint8_t s_win[];      // [2][LZD_WIN + 16]
-	__shared__ uint32_t s_done;
-	const uint32_t tid = threadIdx.x, u = blockIdx.x;
-	const u64 n = bt.in_len[u];
+	if (pos + 2u > n) { if (pos < n) { last = rd(pos); return 1u + LZD_EOI1; } return 1u + LZD_EOI0; }
+	const uint32_t hdr = rd(pos) | (rd(pos + 1u) << 8);
+	if (hdr == 0) { return 1u + (n - pos == 2u ? LZD_ZERO_OK : LZD_ZERO_BAD); }      // :128-134
+	const uint32_t sz = (hdr & 0xFFFu) + 3u;
+	if (sz > n - pos) { return 1u + LZD_TRUNC; }                                     // :136-143
+	if ((hdr & 0x7000u) != 0x3000u) { return 1u + LZD_BADSIG; }                      // :151
+	pos += sz;
+	return 0;
+}
+
+// per segment g and chain k < LZD_K: segL (landing), segE (first header of the next segment, or LZD_ENDED), segcnt (headers inside the segment),
+// segstop (what ended the chain | last byte << 8), segoff (where its header offsets start in cin[g * LZD_SLOTS ...]; LZD_NONE: not recorded)
+__global__ __launch_bounds__(LZD_THREADS) void lzd_seg_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, uint32_t* __restrict__ cin,
+                                                            uint32_t* __restrict__ segL, uint32_t* __restrict__ segE,
+                                                            uint32_t* __restrict__ segcnt, uint32_t* __restrict__ segstop, uint32_t* __restrict__ segoff)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t s_win[];
+	__shared__ uint32_t s_min, s_land[LZD_K], s_cnt[LZD_K];
+	const uint32_t tid = threadIdx.x, g = blockIdx.x;
+	const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, g), s = g - bt.chunk_prefix[u];
+	const uint32_t n = (uint32_t)bt.in_len[u];
 	const uint8_t* base = d_in + bt.in_off[u];
-	const uint32_t a0 = (uint32_t)((uintptr_t)base & 15u);
-	const uint8_t* ab = base - a0;                                       // 16-byte aligned; stream coordinate q = unit offset + a0
-	const u64 end = n + a0;
-	uint32_t* __restrict__ my_cin = cin + bt.chunk_prefix[u];
-	if (tid == 0) { s_done = 0; }
-	uint4 r[4]; uint4 rt = make_uint4(0, 0, 0, 0);
-	// window k: q in [k*W, (k+1)*W + 16)
-	#define LZD_LOAD(k) { const u64 w0_ = (u64)(k) * LZD_WIN; \
-		_Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { const u64 q_ = w0_ + ((u64)i_ * LZD_SCAN_THREADS + tid) * 16u; \
-			r[i_] = q_ < end ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } \
-		if (tid == 0) { const u64 q_ = w0_ + LZD_WIN; rt = q_ < end ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } }
-	#define LZD_STORE(k) { uint8_t* b_ = s_win + ((k) & 1u) * (LZD_WIN + 16u); \
-		_Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { *reinterpret_cast<uint4*>(b_ + ((uint32_t)i_ * LZD_SCAN_THREADS + tid) * 16u) = r[i_]; } \
-		if (tid == 0) { *reinterpret_cast<uint4*>(b_ + LZD_WIN) = rt; } }
-	LZD_LOAD(0) LZD_STORE(0)
+	const uint32_t seg0 = s * LZD_SEG, seg1 = seg0 + LZD_SEG;           // the segment owns the headers in [seg0, seg1)
+	const uint32_t w0 = s ? seg0 - LZD_HEAD : 0u;
+	const uint32_t wend = n < seg1 + 2u ? n : seg1 + 2u;
+	const uint32_t a0 = (uint32_t)((uintptr_t)(base + w0) & 15u);
+	const uint8_t* ab = base + w0 - a0;
+	const uint32_t nw = wend > w0 ? (a0 + (wend - w0) + 15u) >> 4 : 0u;
+	for (uint32_t i = tid; i < nw; i += LZD_THREADS) { *reinterpret_cast<uint4*>(s_win + i * 16u) = *reinterpret_cast<const uint4*>(ab + (size_t)i * 16u); }
+	if (tid < LZD_K) { s_land[tid] = LZD_NONE; s_cnt[tid] = 0; }
+	if (tid == 0) { s_min = LZD_NONE; }
 	__syncthreads();
-	u64 pos = a0; uint32_t count = 0;                                    // lane 0 of wave 0
-	for (u64 k = 0; ; ++k) {
-		const bool more = (k + 1) * LZD_WIN < end;
-		if (more) { LZD_LOAD(k + 1) }
-		if (tid == 0) {
-			const uint8_t* b = s_win + (k & 1u) * (LZD_WIN + 16u);
-			const u64 wend = (k + 1) * LZD_WIN;
-			uint32_t done = 0, kind = 0;
-			while (pos < wend) {
-				if (pos + 2 > end) { kind = (pos < end) ? (LZD_EOI1 | ((uint32_t)b[pos - k * LZD_WIN] << 8)) : LZD_EOI0; done = 1; break; }
-				const uint32_t o = (uint32_t)(pos - k * LZD_WIN);
-				const uint32_t hdr = (uint32_t)b[o] | ((uint32_t)b[o + 1] << 8);
-				if (hdr == 0) { kind = (end - pos == 2) ? LZD_ZERO_OK : LZD_ZERO_BAD; done = 1; break; }   // :128-134
-				const uint32_t sz = (hdr & 0xFFFu) + 3u;
-				if (sz > end - pos) { kind = LZD_TRUNC; done = 1; break; }                                  // :136-143
-				if ((hdr & 0x7000u) != 0x3000u) { kind = LZD_BADSIG; done = 1; break; }                     // :151
-				my_cin[count++] = (uint32_t)(pos - a0);
-				pos += sz;
+	const uint8_t* wb = s_win + a0 - w0;                                // wb[pos] = byte at unit offset pos
+	auto rd = [&](uint32_t p) -> uint32_t { return wb[p]; };
+	if (s) {
+		// every offset of the candidate region followed to the segment: where does it land (LZD_NONE: it died)
+		uint32_t land[5];
+		#pragma unroll
+		for (int q = 0; q < 5; ++q) {
+			const uint32_t c = (uint32_t)q * LZD_THREADS + tid;
+			uint32_t pos = w0 + c, last = 0;
+			land[q] = LZD_NONE;
+			if (c < 4098u && pos <= n) {
+				for (;;) {
+					if (pos >= seg0) { land[q] = pos; break; }
+					const uint32_t r = lzd_step(pos, n, rd, last);
+					if (r) { break; }                                    // an end before the segment: nothing of this chain is ours
+				}
 			}
-			if (!done && !more) { kind = LZD_EOI0; done = 1; }           // the chain left the last window: pos == end
-			if (done) { cnt[u] = count; stop[2u * u] = kind; stop[2u * u + 1u] = (uint32_t)(pos - a0); s_done = 1; }
 		}
-		if (more) { LZD_STORE(k + 1) }
+		// the LZD_K smallest distinct landings
+		uint32_t prev = 0; bool first = true;
+		for (uint32_t k = 0; k < LZD_K; ++k) {
+			#pragma unroll
+			for (int q = 0; q < 5; ++q) { if (land[q] != LZD_NONE && (first || land[q] > prev)) { atomicMin(&s_min, land[q]); } }
+			__syncthreads();
+			const uint32_t m = s_min;
+			__syncthreads();
+			if (m == LZD_NONE) { break; }
+			if (tid == 0) { s_land[k] = m; s_min = LZD_NONE; }
+			prev = m; first = false;
+			__syncthreads();
+		}
+		// more than LZD_K different landings: remember nothing (the verify kernel walks such a segment itself)
+		bool more = false;
+		#pragma unroll
+		for (int q = 0; q < 5; ++q) { more |= land[q] != LZD_NONE && !first && land[q] > prev; }
+		if (__syncthreads_or(more ? 1 : 0)) { if (tid < LZD_K) { s_land[tid] = LZD_NONE; } }
 		__syncthreads();
-		if (s_done) { break; }
+	} else if (tid == 0) { s_land[0] = 0; }
+	__syncthreads();
+	// wave k follows chain k through the segment: first to count, then (offsets known) to record
+	const uint32_t k = tid >> 6;
+	uint32_t L = LZD_NONE, E = LZD_ENDED, count = 0, stopk = 0;
+	if (k < LZD_K && (tid & 63u) == 0) {
+		L = s_land[k];
+		if (L != LZD_NONE) {
+			uint32_t pos = L, last = 0;
+			for (;;) {
+				if (pos >= seg1) { E = pos; break; }
+				const uint32_t r = lzd_step(pos, n, rd, last);
+				if (r) { stopk = (r - 1u) | (last << 8); break; }
+				++count;
+			}
+			s_cnt[k] = count;
+		}
 	}
-	#undef LZD_LOAD
-	#undef LZD_STORE
+	__syncthreads();
+	if (k < LZD_K && (tid & 63u) == 0) {
+		uint32_t off = 0;
+		for (uint32_t q = 0; q < k; ++q) { off += s_cnt[q]; }
+		if (L == LZD_NONE || off + count > LZD_SLOTS) { off = LZD_NONE; }
+		else {
+			uint32_t* __restrict__ my = cin + (size_t)g * LZD_SLOTS + off;
+			uint32_t pos = L, last = 0;
+			for (uint32_t i = 0; i < count; ++i) { my[i] = pos; (void)lzd_step(pos, n, rd, last); }
+		}
+		const size_t r = (size_t)g * LZD_K + k;
+		segL[r] = L; segE[r] = E; segcnt[r] = count; segstop[r] = stopk; segoff[r] = off;
+	}
+}
+
+__device__ unsigned int g_lzd_walked;                                // segments the verify kernel had to walk itself (test hook)
+uint32_t lzd_read_walked()
+{
+	unsigned int v = 0xFFFFFFFFu, z = 0;
+	if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_lzd_walked), 4) != hipSuccess) { return 0xFFFFFFFFu; }
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(g_lzd_walked), &z, 4);
+	return v;
+}
+
+// (2) per unit, one wave: thread the true chain through the segments (segment 0 starts at offset 0; the chain of segment s + 1 is
+// the one that lands where the chosen chain of segment s arrives); a segment without such a chain is walked here, by one lane
+// from global memory. Leaves per segment: selcnt (chunks), seloff (where their header offsets are); per unit: stop.
+__global__ __launch_bounds__(64) void lzd_verify_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, uint32_t* __restrict__ cin,
+                                                       const uint32_t* __restrict__ segL, const uint32_t* __restrict__ segE,
+                                                       const uint32_t* __restrict__ segcnt, const uint32_t* __restrict__ segstop, const uint32_t* __restrict__ segoff,
+                                                       uint32_t* __restrict__ selcnt, uint32_t* __restrict__ seloff, uint32_t* __restrict__ stop)
+{
+	const uint32_t lane = threadIdx.x, u = blockIdx.x;
+	const uint32_t g0 = bt.chunk_prefix[u], S = bt.chunk_prefix[u + 1] - g0;
+	const uint32_t n = (uint32_t)bt.in_len[u];
+	const uint8_t* base = d_in + bt.in_off[u];
+	auto rd = [&](uint32_t p) -> uint32_t { return base[p]; };
+	uint32_t pos = 0, stopk = 0, last = 0;
+	bool ended = false;
+	for (uint32_t s0 = 0; s0 < S; s0 += 64u) {
+		// lane t holds the LZD_K chains of segment s0 + t
+		const uint32_t sl = s0 + lane;
+		uint32_t cl[LZD_K], ce[LZD_K];
+		#pragma unroll
+		for (uint32_t k = 0; k < LZD_K; ++k) {
+			const size_t r = (size_t)(g0 + (sl < S ? sl : S - 1u)) * LZD_K + k;
+			cl[k] = segL[r]; ce[k] = (segoff[r] == LZD_NONE) ? LZD_NONE : segE[r];     // an unrecorded chain cannot be used
+		}
+		uint32_t mycnt = 0, mysel = LZD_K + 1u;                          // what lane t learns about its segment (LZD_K + 1: not reached, LZD_K: walked here)
+		const uint32_t tiles = S - s0 < 64u ? S - s0 : 64u;
+		for (uint32_t t = 0; t < tiles; ++t) {
+			if (ended) { break; }
+			uint32_t sel = LZD_K, e = LZD_NONE;
+			#pragma unroll
+			for (uint32_t k = 0; k < LZD_K; ++k) {
+				const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)cl[k], (int)t), ek = (uint32_t)__builtin_amdgcn_readlane((int)ce[k], (int)t);
+				if (sel == LZD_K && lk == pos && ek != LZD_NONE) { sel = k; e = ek; }
+			}
+			const uint32_t g = g0 + s0 + t;
+			if (sel < LZD_K) {
+				if (lane == t) { mysel = sel; }
+				if (e == LZD_ENDED) { stopk = segstop[(size_t)g * LZD_K + sel]; ended = true; } else { pos = e; }
+			} else {                                                     // no recorded chain starts here: walk the segment now
+				uint32_t count = 0;
+				uint32_t* __restrict__ my = cin + (size_t)g * LZD_SLOTS;
+				const uint32_t seg1 = (s0 + t + 1u) * LZD_SEG;
+				for (;;) {
+					if (pos >= seg1) { break; }
+					const uint32_t at = pos;
+					const uint32_t r = lzd_step(pos, n, rd, last);
+					if (r) { stopk = (r - 1u) | (last << 8); ended = true; break; }
+					if (lane == 0 && count < LZD_SLOTS) { my[count] = at; }
+					++count;
+				}
+				if (lane == t) { mycnt = count; mysel = LZD_K; }
+				if (lane == 0) { atomicAdd(&g_lzd_walked, 1u); }
+			}
+		}
+		if (sl < S) {
+			uint32_t myoff = 0;
+			if (mysel < LZD_K) { const size_t r = (size_t)(g0 + sl) * LZD_K + mysel; mycnt = segcnt[r]; myoff = segoff[r]; }
+			selcnt[g0 + sl] = mycnt; seloff[g0 + sl] = myoff;
+		}
+	}
+	if (lane == 0) { stop[u] = stopk; }
 }
 
 // ===================================================================================================================
@@ -199,34 +331,37 @@ __device__ __forceinline__ void lzd_store(uint8_t* __restrict__ dst, const uint8
 	for (uint32_t i = head + body * 4u + lane; i < n; i += 64u) { dst[i] = lds[i]; }
 }
 
-// largest u with prefix[u] <= c (prefix: u64 exclusive scan of the chunk counts; empty units share an entry with their successor)
-__device__ __forceinline__ uint32_t unit_of_flat(const u64* __restrict__ prefix, uint32_t n_units, u64 c)
+// largest g with prefix[g] <= c (prefix: u64 exclusive scan of the per-segment chunk counts; empty segments share an entry with their successor)
+__device__ __forceinline__ uint32_t seg_of_flat(const u64* __restrict__ prefix, uint32_t n_seg, u64 c)
 {
-	uint32_t lo = 0, hi = n_units;
+	uint32_t lo = 0, hi = n_seg;
 	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (prefix[mid] <= c) { lo = mid; } else { hi = mid; } }
 	return lo;
 }
 
 // EXACT = false: every chunk, written where it lands if all earlier chunks hold 4096 bytes; records the size.
 // EXACT = true: only units flagged irregular; chunks whose place differs are decoded again to the exact place.
+// Chunks are numbered through the batch in stream order (flat[g] = number of the first chunk of segment g).
 template <bool EXACT>
 __global__ __launch_bounds__(64) void lzd_chunk_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, const uint32_t* __restrict__ cin,
-                                                      const u64* __restrict__ start, uint16_t* __restrict__ csize,
+                                                      const uint32_t* __restrict__ seloff, const u64* __restrict__ flat, uint16_t* __restrict__ csize,
                                                       const uint32_t* __restrict__ irregular, uint8_t* __restrict__ d_out)
 {
 	__shared__ LzdLds L;
 	const uint32_t lane = threadIdx.x;
-	const u64 total_chunks = start[bt.n_units];
+	const u64 total_chunks = flat[bt.n_chunks];
 	if (EXACT && irregular[bt.n_units] == 0) { return; }
 	for (u64 c = blockIdx.x; c < total_chunks; c += gridDim.x) {
-		const uint32_t u = unit_of_flat(start, bt.n_units, c);
+		const uint32_t g = seg_of_flat(flat, bt.n_chunks, c);
+		const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, g);
 		if (EXACT && !irregular[u]) { continue; }
-		const uint32_t j = (uint32_t)(c - start[u]);
-		const uint32_t slot = bt.chunk_prefix[u] + j;
-		u64 pos = (u64)j * 4096u;
+		const u64 ufirst = flat[bt.chunk_prefix[u]];
+		const u64 j = c - ufirst;
+		const size_t slot = (size_t)g * LZD_SLOTS + seloff[g] + (size_t)(c - flat[g]);
+		u64 pos = j * 4096u;
 		if (EXACT) {
-			u64 acc = 0;                                                 // sum of the sizes of the chunks before j
-			for (uint32_t i = lane; i < j; i += 64u) { acc += csize[bt.chunk_prefix[u] + i] & 0x1FFFu; }
+			u64 acc = 0;                                                 // sum of the sizes of the chunks before this one
+			for (u64 i = lane; i < j; i += 64u) { acc += csize[ufirst + i] & 0x1FFFu; }
 			for (int o = 32; o; o >>= 1) { acc += __shfl_xor(acc, o, 64); }
 			if (acc == pos) { continue; }
 			pos = acc;
@@ -242,7 +377,7 @@ __global__ __launch_bounds__(64) void lzd_chunk_kernel(const uint8_t* __restrict
 			for (uint32_t i = lane; i < size; i += 64u) { L.out[i] = src[2u + i]; }
 			__syncthreads();
 		}
-		if (!EXACT && lane == 0) { csize[slot] = (uint16_t)size; }
+		if (!EXACT && lane == 0) { csize[c] = (uint16_t)size; }
 		const u64 cap = bt.out_cap[u];
 		if (size != LZD_ERR && pos < cap) {
 			const u64 room = cap - pos;
@@ -255,30 +390,54 @@ __global__ __launch_bounds__(64) void lzd_chunk_kernel(const uint8_t* __restrict
 // ===================================================================================================================
 // (3) per unit: positions, status, out_len
 // ===================================================================================================================
-__global__ __launch_bounds__(64) void lzd_finalize_kernel(BatchTables bt, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ stop,
-                                                         const uint16_t* __restrict__ csize, uint32_t* __restrict__ irregular,
-                                                         u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
+__global__ __launch_bounds__(256) void lzd_finalize_kernel(BatchTables bt, const u64* __restrict__ flat, const uint32_t* __restrict__ stop,
+                                                          const uint16_t* __restrict__ csize, uint32_t* __restrict__ irregular,
+                                                          u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
 {
-	const uint32_t lane = threadIdx.x, u = blockIdx.x;
-	const uint32_t count = cnt[u], kind = stop[2u * u] & 0xFFu, last = stop[2u * u] >> 8;
-	const u64 cap = bt.out_cap[u], n = bt.in_len[u];
-	const uint16_t* __restrict__ sz = csize + bt.chunk_prefix[u];
+	__shared__ uint32_t s_wsum[4], s_wev[4], s_wirr[4];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, u = blockIdx.x;
+	const u64 ufirst = flat[bt.chunk_prefix[u]], count = flat[bt.chunk_prefix[u + 1]] - ufirst;
+	const uint32_t kind = stop[u] & 0xFFu, last = stop[u] >> 8;
+	const u64 cap = bt.out_cap[u];
+	const uint16_t* __restrict__ sz = csize + ufirst;
 	u64 pos = 0; int32_t status = 1; bool irr = false;                   // status 1 = undecided
-	for (uint32_t j0 = 0; j0 < count && status == 1; j0 += 64u) {
-		const uint32_t j = j0 + lane;
-		const uint32_t raw = j < count ? sz[j] : 0u;
-		const bool bad = raw == LZD_ERR;
-		const uint32_t size = bad ? 0u : raw;
-		uint32_t incl = size;
-		for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if ((int)lane >= o) { incl += t; } }
-		const u64 p = pos + incl - size;
+	for (u64 j0 = 0; j0 < count; j0 += 1024u) {                          // thread t: chunks j0 + 4t .. j0 + 4t + 3
+		uint32_t raw[4], size[4], mine = 0;
+		#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const u64 j = j0 + tid * 4u + q;
+			raw[q] = j < count ? sz[j] : 0u;
+			size[q] = raw[q] == LZD_ERR ? 0u : raw[q];
+			mine += size[q];
+			irr |= j + 1u < count && raw[q] != 4096u;
+		}
+		const uint32_t incl = wave_incl_scan_add_u32(mine);
+		if (lane == 63u) { s_wsum[w] = incl; }
+		__syncthreads();
+		uint32_t before = incl - mine, total = 0;
+		#pragma unroll
+		for (uint32_t q = 0; q < 4u; ++q) { if (q < w) { before += s_wsum[q]; } total += s_wsum[q]; }
 		// the walk of :252-259 at chunk j: no room left -> the caller sees BUF_ERROR; chunk error -> DATA_ERROR; chunk does not fit -> BUF_ERROR
-		const uint32_t ev = j < count ? (p >= cap ? 5u : bad ? 3u : p + size > cap ? 5u : 0u) : 0u;
+		u64 p = pos + before; uint32_t ev = 0;
+		#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const u64 j = j0 + tid * 4u + q;
+			if (!ev && j < count) { ev = p >= cap ? 5u : raw[q] == LZD_ERR ? 3u : p + size[q] > cap ? 5u : 0u; }
+			p += size[q];
+		}
 		const u64 m = __ballot(ev != 0);
-		irr |= __ballot(j + 1u < count && raw != 4096u) != 0;
-		if (m) { status = -(int32_t)__builtin_amdgcn_readlane((int)ev, (int)ctz64(m)); break; }
-		pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		if (lane == 0) { s_wev[w] = m ? (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)ctz64(m)) : 0u; }
+		__syncthreads();
+		uint32_t first = 0;
+		#pragma unroll
+		for (uint32_t q = 0; q < 4u; ++q) { if (!first) { first = s_wev[q]; } }
+		__syncthreads();
+		if (first) { status = -(int32_t)first; break; }
+		pos += total;
 	}
+	const u64 mi = __ballot(irr);
+	if (lane == 0) { s_wirr[w] = mi != 0; }
+	__syncthreads();
 	if (status == 1) {
 		const bool room = pos < cap;
 		switch (kind) {
@@ -289,36 +448,42 @@ __global__ __launch_bounds__(64) void lzd_finalize_kernel(BatchTables bt, const 
 		case LZD_TRUNC:    status = -5; break;
 		default:           status = room ? -3 : -5; break;                           // LZD_BADSIG
 		}
-		(void)n;
 	}
-	if (lane == 0) {
+	if (tid == 0) {
+		const bool any = s_wirr[0] | s_wirr[1] | s_wirr[2] | s_wirr[3];
 		d_status[u] = status; d_out_len[u] = status == 0 ? pos : 0;
-		irregular[u] = irr ? 1u : 0u;
-		if (irr) { atomicOr(&irregular[bt.n_units], 1u); }
+		irregular[u] = any ? 1u : 0u;
+		if (any) { atomicOr(&irregular[bt.n_units], 1u); }
 	}
 }
 
 __global__ void lzd_clear_kernel(uint32_t* p) { *p = 0; }
 
-void launch_lzd_scan(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const LzdBufs& b)
+void launch_lzd_segments(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const LzdBufs& b)
 {
 	if (bt.n_units == 0) { return; }
 	static bool attr_set = false;
-	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lzd_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZD_SCAN_LDS); attr_set = true; }
+	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lzd_seg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZD_LDS); attr_set = true; }
 	hipLaunchKernelGGL(lzd_clear_kernel, dim3(1), dim3(1), 0, st, b.irregular + bt.n_units);
-	hipLaunchKernelGGL(lzd_scan_kernel, dim3(bt.n_units), dim3(LZD_SCAN_THREADS), LZD_SCAN_LDS, st, d_in, bt, b.cin, b.cnt, b.stop);
+	hipLaunchKernelGGL(lzd_seg_kernel, dim3(bt.n_chunks), dim3(LZD_THREADS), LZD_LDS, st, d_in, bt, b.cin, b.segL, b.segE, b.segcnt, b.segstop, b.segoff);
+}
+void launch_lzd_verify(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const LzdBufs& b)
+{
+	if (bt.n_units == 0) { return; }
+	hipLaunchKernelGGL(lzd_verify_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, b.cin, b.segL, b.segE, b.segcnt, b.segstop, b.segoff, b.selcnt, b.seloff, b.stop);
 }
 void launch_lzd_chunks(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const LzdBufs& b, uint8_t* d_out, int exact)
 {
 	if (bt.n_units == 0) { return; }
-	const uint32_t grid = bt.n_chunks < 16384u ? (bt.n_chunks ? bt.n_chunks : 1u) : 16384u;
-	if (exact) { hipLaunchKernelGGL(lzd_chunk_kernel<true>, dim3(grid), dim3(64), 0, st, d_in, bt, b.cin, b.start, b.csize, b.irregular, d_out); }
-	else       { hipLaunchKernelGGL(lzd_chunk_kernel<false>, dim3(grid), dim3(64), 0, st, d_in, bt, b.cin, b.start, b.csize, b.irregular, d_out); }
+	const u64 est = (u64)bt.n_chunks * (LZD_SEG / 2048u);            // the count lives on the device; typical chunks are 2-4 KiB
+	const uint32_t grid = est < 16384u ? (uint32_t)est : 16384u;
+	if (exact) { hipLaunchKernelGGL(lzd_chunk_kernel<true>, dim3(grid), dim3(64), 0, st, d_in, bt, b.cin, b.seloff, b.flat, b.csize, b.irregular, d_out); }
+	else       { hipLaunchKernelGGL(lzd_chunk_kernel<false>, dim3(grid), dim3(64), 0, st, d_in, bt, b.cin, b.seloff, b.flat, b.csize, b.irregular, d_out); }
 }
 void launch_lzd_finalize(hipStream_t st, const BatchTables& bt, const LzdBufs& b, u64* d_out_len, int32_t* d_status)
 {
 	if (bt.n_units == 0) { return; }
-	hipLaunchKernelGGL(lzd_finalize_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, b.cnt, b.stop, b.csize, b.irregular, d_out_len, d_status);
+	hipLaunchKernelGGL(lzd_finalize_kernel, dim3(bt.n_units), dim3(256), 0, st, bt, b.flat, b.stop, b.csize, b.irregular, d_out_len, d_status);
 }
 
 } // namespace msc

@@ -36,10 +36,19 @@ void launch_xh_encode(hipStream_t st, const uint8_t* d_in, const BatchTables& bt
                       const u64* tokbits, const uint8_t* lens, const uint16_t* codes, const uint32_t* fbflag, const u64* prefix, uint8_t* d_out);
 
 // ---- decompressors (decompress.hip) ----
-// LZNT1: chunk_prefix[u] = first of the in_len/3+1 chunk slots of unit u. cin: header offset per slot (u32), csize: decoded size or
-// 0x8000 (u16), cnt / stop (2 x u32) / irregular (+1 global flag) per unit, start: u64 exclusive scan of cnt (n_units+1).
-struct LzdBufs { uint32_t* cin; uint16_t* csize; uint32_t* cnt; uint32_t* stop; uint32_t* irregular; u64* start; };
-void launch_lzd_scan(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const LzdBufs& b);
+// LZNT1: the compressed input of a unit is cut into segments of LZD_SEG bytes (chunk_prefix[u] = first segment of unit u, n_chunks =
+// segments of the batch). cin: header offsets, LZD_SLOTS per segment (u32); segL / segE / segcnt / segstop / segoff per speculated
+// chain; selcnt / seloff per segment (the true chain); flat: u64 exclusive scan of selcnt (n_chunks + 1) = number of the first chunk of a segment; csize: decoded size or 0x8000 per
+// chunk number (u16); stop / irregular (+1 global flag) per unit.
+#define LZD_SEG   49152u
+#define LZD_HEAD  12288u
+#define LZD_SLOTS (LZD_SEG / 3u + 2u)
+#define LZD_K     4u         // speculated chains kept per segment
+struct LzdBufs { uint32_t* cin; uint16_t* csize; uint32_t* segL; uint32_t* segE; uint32_t* segcnt; uint32_t* segstop; uint32_t* segoff;   /* LZD_K per segment */
+                 uint32_t* selcnt; uint32_t* seloff; uint32_t* stop; uint32_t* irregular; u64* flat; };
+void launch_lzd_segments(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const LzdBufs& b);
+uint32_t lzd_read_walked();
+void launch_lzd_verify(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const LzdBufs& b);
 void launch_lzd_chunks(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const LzdBufs& b, uint8_t* d_out, int exact);
 void launch_lzd_finalize(hipStream_t st, const BatchTables& bt, const LzdBufs& b, u64* d_out_len, int32_t* d_status);
 

@@ -32,10 +32,15 @@ def run(units, label):
     ctx.profile_enable(True)
     for _ in range(5): q.execute(d_c, d_back, d_len2, d_st2)
     prof = ctx.profile_read(); ctx.profile_enable(False)
+    ctx.lib.mscomp_amd_debug_lzd_walked(ctx._h); q.execute(d_c, d_back, d_len2, d_st2)
+    print("   walked segments:", ctx.lib.mscomp_amd_debug_lzd_walked(ctx._h), "of", sum((c + 49151) // 49152 for c in clens))
     print(label, "ok" if ok else "MISMATCH", "%.3f ms/pass" % (dt * 1e3), "%.1f GB/s out" % (sum(lens) / dt / 1e9), "comp %d" % sum(clens))
     for k, (ms, c) in prof.items(): print("   %-24s %.4f ms" % (k, ms / c))
     q.close(); ctx.close()
 
+if len(sys.argv) > 1 and sys.argv[1] == "files":
+    for i in range(12): run([corpus.file_bytes(i)], corpus.NAMES[i])
+    sys.exit(0)
 moz = corpus.file_bytes(corpus.NAMES.index("mozilla"), 51_220_480)
 run([moz], "mozilla x1 unit")
 run([corpus.file_bytes(i) for i in range(12)], "silesia 12 units")
