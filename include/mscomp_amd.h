@@ -56,9 +56,11 @@ size_t       xpress_huff_max_compressed_size(size_t in_len);
  * bytes produced on MSCOMP_OK; MSCOMP_BUF_ERROR when the output (or what is left of the input) does not fit,
  * MSCOMP_DATA_ERROR for a malformed stream.
  *   ms_decompress      include/mscomp.h:79,   src/mscomp.cpp:119-134               -> ms_decompress
- *   lznt1_decompress   include/lznt1.h:51,    src/lznt1_decompress.cpp:293 (the inflate wrapper, internal.h:616-630) -> lznt1_decompress */
+ *   lznt1_decompress   include/lznt1.h:51,    src/lznt1_decompress.cpp:293 (the inflate wrapper, internal.h:616-630) -> lznt1_decompress
+ *   xpress_decompress  include/xpress.h:50,   src/xpress_decompress.cpp:405                -> xpress_decompress */
 MSCompStatus ms_decompress(MSCompFormat format, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
 MSCompStatus lznt1_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
+MSCompStatus xpress_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
 
 /* ================= Part 2: batch interface (device pointers) ================= */
 typedef struct mscomp_amd_ctx  mscomp_amd_ctx;    /* one per (device, stream); owns scratch in HBM  */

@@ -486,4 +486,159 @@ void launch_lzd_finalize(hipStream_t st, const BatchTables& bt, const LzdBufs& b
 	hipLaunchKernelGGL(lzd_finalize_kernel, dim3(bt.n_units), dim3(256), 0, st, bt, b.flat, b.stop, b.csize, b.irregular, d_out_len, d_status);
 }
 
+// ===================================================================================================================
+// Xpress: one wave per stream
+// ===================================================================================================================
+// xpress_decompress (/root/reference/src/xpress_decompress.cpp:405-462, READ_SYMBOL :62-107): a stream is one chain of tokens - where
+// a token starts depends on every token before it (32-bit flag words, 1 / 2 / 3 / 4 / 6 / 10-byte tokens, a length nibble shared
+// by two matches) - so a stream is decoded by one wave, streams in parallel. All lanes run the token walk (it is uniform);
+// the input is staged through an 8 KiB LDS ring (the next 4 KiB block is in flight in registers), the output through a 16 KiB
+// ring from which matches are copied (offsets reach 8192 bytes back) and which is written to HBM in 8 KiB halves; a literal
+// run and a match are moved by the lanes together.
+#define XPD_INB 4096u
+struct XpdLds { __attribute__((aligned(16))) uint8_t in[2u * XPD_INB]; __attribute__((aligned(16))) uint8_t out[16384]; };
+
+__global__ __launch_bounds__(64) void xpd_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, uint8_t* __restrict__ d_out,
+                                                u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
+{
+	__shared__ XpdLds S;
+	const uint32_t lane = threadIdx.x, u = blockIdx.x;
+	const uint32_t n = (uint32_t)bt.in_len[u];
+	const u64 cap = bt.out_cap[u];
+	const uint8_t* src = d_in + bt.in_off[u];
+	uint8_t* dst = d_out + bt.out_off[u];
+	int32_t status = -3; u64 op = 0;
+	if (n < 5u) {                                                        // :414-418
+		bool ok = n == 0;
+		if (n == 4u) { ok = ((uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24)) != 0xFFFFFFFFu; }
+		if (lane == 0) { d_status[u] = ok ? 0 : -3; d_out_len[u] = 0; }
+		return;
+	}
+	// ---- input ring: q = offset from the 16-byte aligned base; block b = q in [4096 b, 4096 (b+1)) lives at in[(b & 1) * 4096] ----
+	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
+	const uint8_t* ab = src - a0;
+	const u64 endq = (u64)a0 + n;
+	uint4 pf[4];
+	u64 loaded = 0;                                                      // blocks stored so far; block `loaded` is in pf
+	#define XPD_FETCH(b) { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { const u64 q_ = (u64)(b) * XPD_INB + ((uint32_t)i_ * 64u + lane) * 16u; \
+		pf[i_] = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } }
+	#define XPD_STORE(b) { uint8_t* b_ = S.in + ((uint32_t)(b) & 1u) * XPD_INB; \
+		_Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { *reinterpret_cast<uint4*>(b_ + ((uint32_t)i_ * 64u + lane) * 16u) = pf[i_]; } }
+	XPD_FETCH(0) XPD_STORE(0) XPD_FETCH(1) XPD_STORE(1) XPD_FETCH(2)
+	loaded = 2;
+	__syncthreads();
+	auto rb = [&](u64 q) -> uint32_t { return S.in[(uint32_t)q & (2u * XPD_INB - 1u)]; };
+	// ---- output ring: r = output offset + d0 (d0 = alignment of the destination): halves of 8192 are 16-byte aligned in HBM ----
+	const uint32_t d0 = (uint32_t)((uintptr_t)dst & 15u);
+	uint8_t* db = dst - d0;
+	u64 flushed = 0;                                                     // ring coordinate up to which the output is in HBM (multiple of 8192)
+	#define XPD_FLUSH_HALF() { const uint8_t* h_ = S.out + ((uint32_t)flushed & 16383u); \
+		for (uint32_t i_ = lane; i_ < 512u; i_ += 64u) { const u64 r_ = flushed + (u64)i_ * 16u; \
+			if (r_ >= d0) { *reinterpret_cast<uint4*>(db + r_) = *reinterpret_cast<const uint4*>(h_ + i_ * 16u); } \
+			else { for (uint32_t k_ = d0; k_ < 16u; ++k_) { db[r_ + k_] = h_[i_ * 16u + k_]; } } } \
+		flushed += 8192u; }
+	u64 ip = a0;                                                         // in q coordinates
+	uint32_t half = 0; bool have_half = false;
+	bool done = false;
+	while (!done) {
+		if (ip + 4u > endq) { status = -3; break; }                     // :461 the input ended at a flag word
+		while (loaded * XPD_INB < ip + 352u && loaded * XPD_INB < endq) {   // a flag word and its 32 tokens take at most 4 + 32 * 10 bytes
+			__syncthreads();
+			XPD_STORE(loaded) ++loaded; XPD_FETCH(loaded)
+			__syncthreads();
+		}
+		uint32_t flags = rb(ip) | (rb(ip + 1) << 8) | (rb(ip + 2) << 16) | (rb(ip + 3) << 24);
+		uint32_t flagged = flags >> 31;
+		flags = (flags << 1) | 1u; ip += 4u;
+		do {
+			if (ip == endq) {                                            // :433-438
+				uint32_t x = ~flags;
+				status = (flagged && !((x + 1u) & x)) ? 0 : -3; done = true; break;
+			}
+			if (flagged) {
+				if (ip + 2u > endq) { status = -3; done = true; break; }
+				const uint32_t sym = rb(ip) | (rb(ip + 1) << 8); ip += 2u;
+				const uint32_t off = (sym >> 3) + 1u; uint32_t len = sym & 7u;
+				if (len == 7u) {
+					if (have_half) { len = half >> 4; have_half = false; }
+					else if (ip == endq) { status = -3; done = true; break; }
+					else { half = rb(ip); ip += 1u; have_half = true; len = half & 0xFu; }
+					if (len == 0xFu) {
+						if (ip == endq) { status = -3; done = true; break; }
+						len = rb(ip); ip += 1u;
+						if (len == 0xFFu) {
+							if (ip + 2u > endq) { status = -3; done = true; break; }
+							len = rb(ip) | (rb(ip + 1) << 8); ip += 2u;
+							if (len == 0) {
+								if (ip + 4u > endq) { status = -3; done = true; break; }
+								len = rb(ip) | (rb(ip + 1) << 8) | (rb(ip + 2) << 16) | (rb(ip + 3) << 24); ip += 4u;
+							}
+							if (len < 0xFu + 0x7u) { status = -3; done = true; break; }
+							len -= 0xFu + 0x7u;
+						}
+						len += 0xFu;
+					}
+					len += 0x7u;
+				}
+				len += 0x3u;
+				if (off > op) { status = -3; done = true; break; }       // :442
+				if (len > cap - op) { status = -5; done = true; break; } // :443
+				// copy: the source is at most 8192 bytes back, inside the ring
+				u64 r = op + d0;
+				if (off >= 64u) {
+					uint32_t left = len;
+					while (left) {
+						const uint32_t step = left < 64u ? left : 64u;
+						if (lane < step) { S.out[(uint32_t)(r + lane) & 16383u] = S.out[(uint32_t)(r + lane - off) & 16383u]; }
+						r += step; left -= step;
+						if (r >= flushed + 8192u) { __syncthreads(); XPD_FLUSH_HALF() }
+					}
+				} else {
+					const float ro = __builtin_amdgcn_rcpf((float)off);  // off < 64: (x + 0.5) / off is never within 1e-3 of an integer
+					const uint32_t span = (uint32_t)(64.5f * ro) * off;  // whole periods per step
+					const uint32_t lm = lane - (uint32_t)(((float)lane + 0.5f) * ro) * off;
+					const uint32_t v = S.out[(uint32_t)(r - off + lm) & 16383u];
+					uint32_t left = len;
+					while (left) {
+						const uint32_t step = left < span ? left : span;
+						if (lane < step) { S.out[(uint32_t)(r + lane) & 16383u] = (uint8_t)v; }
+						r += step; left -= step;
+						if (r >= flushed + 8192u) { __syncthreads(); XPD_FLUSH_HALF() }
+					}
+				}
+				op += len;
+				flagged = flags >> 31; flags <<= 1;
+			} else {
+				// a run of literals: this token and the zero flags behind it, as far as input and room reach
+				uint32_t run = (uint32_t)__builtin_clz(flags) + 1u;
+				if (op == cap) { status = -5; done = true; break; }      // :455
+				if ((u64)run > endq - ip) { run = (uint32_t)(endq - ip); }
+				if ((u64)run > cap - op) { run = (uint32_t)(cap - op); }
+				const u64 r = op + d0;
+				if (lane < run) { S.out[(uint32_t)(r + lane) & 16383u] = (uint8_t)rb(ip + lane); }
+				op += run; ip += run;
+				if (r + run >= flushed + 8192u) { __syncthreads(); XPD_FLUSH_HALF() }
+				flagged = (uint32_t)(((u64)flags << (run - 1u)) >> 31) & 1u;
+				flags = (uint32_t)((u64)flags << run);
+			}
+		} while (flags);
+	}
+	#undef XPD_FETCH
+	#undef XPD_STORE
+	// the rest of the ring
+	__syncthreads();
+	if (status == 0) {
+		const u64 rend = op + d0;
+		for (u64 r = flushed + lane; r < rend; r += 64u) { if (r >= d0) { db[r] = S.out[(uint32_t)r & 16383u]; } }
+	}
+	#undef XPD_FLUSH_HALF
+	if (lane == 0) { d_status[u] = status; d_out_len[u] = status == 0 ? op : 0; }
+}
+
+void launch_xpress_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* d_out, u64* d_out_len, int32_t* d_status)
+{
+	if (bt.n_units == 0) { return; }
+	hipLaunchKernelGGL(xpd_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, d_out, d_out_len, d_status);
+}
+
 } // namespace msc

@@ -315,43 +315,57 @@ static int xpress_compress_o(const uint8_t* d, size_t n, uint8_t* out, size_t* o
 	return ORC_OK;
 }
 
-/* Xpress decoder (format only; used for round trips). */
+/* Xpress decoder with the semantics of the reference's one-shot xpress_decompress (xpress_decompress.cpp:405-462, the
+ * MSCOMP_WITH_OPT_DECOMPRESS build that config.h:47-48 selects; READ_SYMBOL :62-107). Its fast loop (:148-196) differs from
+ * the checked loop only by what it may skip, not by what it decides, so the checked loop is restated for every token. */
+static int xp_set_bits_are_highest(uint32_t x) { x = ~x; return !((x + 1) & x); }                 /* :41 */
 static int xpress_decompress_o(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)
 {
 	const size_t cap = *out_len;
 	size_t ip = 0, op = 0, half = 0; int have_half = 0;
-	while (ip + 4 <= n) {
-		uint32_t flags = get32(in + ip); ip += 4;
-		for (unsigned i = 0; i < 32; ++i, flags <<= 1) {
-			if (ip >= n) { goto done; }
-			if (!(flags & 0x80000000u)) { if (op >= cap) { return ORC_BUF_ERROR; } out[op++] = in[ip++]; continue; }
-			if (ip + 2 > n) { return ORC_DATA_ERROR; }
-			const uint32_t s = get16(in + ip); ip += 2;
-			const size_t off = (s >> 3) + 1; size_t len = s & 7;
-			if (len == 7) {
-				uint32_t nib;
-				if (have_half) { nib = in[half] >> 4; have_half = 0; }
-				else { if (ip >= n) { return ORC_DATA_ERROR; } half = ip; have_half = 1; nib = in[ip++] & 0xF; }
-				len += nib;
-				if (nib == 15) {
-					if (ip >= n) { return ORC_DATA_ERROR; }
-					const uint32_t b = in[ip++]; len += b;
-					if (b == 255) {
-						if (ip + 2 > n) { return ORC_DATA_ERROR; }
-						len = get16(in + ip); ip += 2;
-						if (len == 0) { if (ip + 4 > n) { return ORC_DATA_ERROR; } len = get32(in + ip); ip += 4; }
-					}
-				}
-			}
-			len += 3;
-			if (off > op) { return ORC_DATA_ERROR; }
-			if (op + len > cap) { return ORC_BUF_ERROR; }
-			while (len--) { out[op] = out[op - off]; ++op; }
-		}
+	if (n < 5) {                                                                                   /* :414-418 */
+		if (n == 0 || (n == 4 && get32(in) != 0xFFFFFFFFu)) { *out_len = 0; return ORC_OK; }
+		return ORC_DATA_ERROR;
 	}
-done:
-	*out_len = op;
-	return ORC_OK;
+	while (ip + 4 <= n) {                                                                          /* :425 */
+		uint32_t flags = get32(in + ip), flagged = flags & 0x80000000u;
+		flags = (flags << 1) | 1; ip += 4;
+		do {
+			if (ip == n) {                                                                         /* :433-438 */
+				if (!flagged || !xp_set_bits_are_highest(flags)) { return ORC_DATA_ERROR; }
+				*out_len = op; return ORC_OK;
+			} else if (flagged) {
+				uint32_t len;                                                                      /* uint32_t like the reference: the sums below wrap */
+				if (ip + 2 > n) { return ORC_DATA_ERROR; }                                         /* :82 */
+				const uint32_t sym = get16(in + ip); ip += 2;
+				const size_t off = (sym >> 3) + 1; len = sym & 7;
+				if (len == 7) {
+					if (have_half) { len = in[half] >> 4; have_half = 0; }                         /* :89 */
+					else if (ip == n) { return ORC_DATA_ERROR; }
+					else { half = ip; have_half = 1; len = in[ip++] & 0xF; }
+					if (len == 0xF) {
+						if (ip == n) { return ORC_DATA_ERROR; }                                    /* :94 */
+						if ((len = in[ip++]) == 0xFF) {
+							if (ip + 2 > n) { return ORC_DATA_ERROR; }
+							len = get16(in + ip); ip += 2;
+							if (len == 0) { if (ip + 4 > n) { return ORC_DATA_ERROR; } len = get32(in + ip); ip += 4; }
+							if (len < 0xF + 0x7) { return ORC_DATA_ERROR; }                        /* :104 */
+							len -= 0xF + 0x7;
+						}
+						len += 0xF;
+					}
+					len += 0x7;
+				}
+				len += 0x3;
+				if (off > op) { return ORC_DATA_ERROR; }                                           /* :442 */
+				if (len > cap - op) { return ORC_BUF_ERROR; }                                      /* :443 */
+				for (uint32_t i = 0; i < len; ++i) { out[op] = out[op - off]; ++op; }
+			} else if (op == cap) { return ORC_BUF_ERROR; }                                        /* :455 */
+			else { out[op++] = in[ip++]; }
+			flagged = flags & 0x80000000u; flags <<= 1;
+		} while (flags);
+	}
+	return ORC_DATA_ERROR;                                                                         /* :461 */
 }
 
 /* ===================================================================================================

@@ -7,7 +7,7 @@ import pytest
 import cases
 
 pytestmark = pytest.mark.gpu
-FMTS = {"lznt1": 2}
+FMTS = {"lznt1": 2, "xpress": 3}
 
 
 @pytest.mark.parametrize("fmt", list(FMTS))
@@ -37,8 +37,11 @@ def test_round_trip_on_device(oracle, gpu_ctx, fmt):
     comp, st = m.compress_units(f, units, ctx=gpu_ctx)
     assert all(s == 0 for s in st)
     back, st2 = m.decompress_units(f, comp, [len(u) for u in units], ctx=gpu_ctx)
-    assert st2 == [0] * len(units)
-    assert back == units
+    for u, b, s2 in zip(units, back, st2):
+        if f == 3 and len(u) == 0:                      # the reference's Xpress decoder rejects what its encoder writes for no input
+            assert s2 == -3
+        else:
+            assert s2 == 0 and b == u, len(u)
 
 
 @pytest.mark.parametrize("fmt", list(FMTS))
@@ -52,13 +55,14 @@ def test_one_shot_decompress_host_pointers(oracle, gpu_ctx, fmt):
     with pytest.raises(m.MSCompError) as e:
         m.decompress(f, comp, len(data) - 1)
     assert e.value.status == m.MSCOMP_BUF_ERROR
-    bad = comp[:1] + bytes([comp[1] ^ 0x40]) + comp[2:]           # first chunk header: wrong signature
+    bad = comp[:1] + bytes([comp[1] ^ 0x40]) + comp[2:] if f == 2 else comp[:-1]    # LZNT1: wrong signature in the first header; Xpress: cut short
     want = oracle.oracle_decompress_ex(f, bad, len(data))[0]
     assert want != 0
     with pytest.raises(m.MSCompError) as e:
         m.decompress(f, bad, len(data))
     assert e.value.status == want
     assert m.decompress(f, b"", 10) == b""
+    assert e.value.status == oracle.ref_decompress(f, bad, len(data))[0] if oracle.load_ref() else True
 
 
 def test_round_trip_full_size_lznt1(oracle, gpu_ctx):

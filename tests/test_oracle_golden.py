@@ -74,7 +74,10 @@ def test_edge_families_golden(oracle, fmt):
         assert st == 0
         h.update(len(out).to_bytes(8, "little")); h.update(out); tot += len(out)
         st, back = oracle.oracle_decompress(FMTS[fmt], out, len(u))
-        assert st == 0 and back == u, (fmt, len(u))
+        if fmt == "xpress" and len(u) == 0:      # the reference's Xpress decoder rejects the 4-byte stream its encoder writes for no input
+            assert st == -3                      # (xpress_decompress.cpp:414-418)
+        else:
+            assert st == 0 and back == u, (fmt, len(u))
     assert tot == g["total_len"] and h.hexdigest() == g["sha256"]
 
 
