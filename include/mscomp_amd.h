@@ -57,10 +57,12 @@ size_t       xpress_huff_max_compressed_size(size_t in_len);
  * MSCOMP_DATA_ERROR for a malformed stream.
  *   ms_decompress      include/mscomp.h:79,   src/mscomp.cpp:119-134               -> ms_decompress
  *   lznt1_decompress   include/lznt1.h:51,    src/lznt1_decompress.cpp:293 (the inflate wrapper, internal.h:616-630) -> lznt1_decompress
- *   xpress_decompress  include/xpress.h:50,   src/xpress_decompress.cpp:405                -> xpress_decompress */
+ *   xpress_decompress  include/xpress.h:50,   src/xpress_decompress.cpp:405                -> xpress_decompress
+ *   xpress_huff_decompress include/xpress_huff.h:49, src/xpress_huff_decompress.cpp:130      -> xpress_huff_decompress */
 MSCompStatus ms_decompress(MSCompFormat format, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
 MSCompStatus lznt1_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
 MSCompStatus xpress_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
+MSCompStatus xpress_huff_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
 
 /* ================= Part 2: batch interface (device pointers) ================= */
 typedef struct mscomp_amd_ctx  mscomp_amd_ctx;    /* one per (device, stream); owns scratch in HBM  */

@@ -313,6 +313,10 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 			KernelTimer t(c, "xpd_kernel"); launch_xpress_decompress(st, d_in, p->bt, d_out, d_out_len, d_status);
 			return MSCOMP_OK;
 		}
+		case MSCOMP_XPRESS_HUFF: {
+			KernelTimer t(c, "xhd_kernel"); launch_xpress_huff_decompress(st, d_in, p->bt, d_out, d_out_len, d_status);
+			return MSCOMP_OK;
+		}
 		default:
 			return MSCOMP_ARG_ERROR;
 		}
@@ -502,12 +506,13 @@ MSCompStatus xpress_huff_compress(const uint8_t* in, size_t n, uint8_t* out, siz
 // the decompressors (lznt1_decompress.cpp:293 via internal.h:616-630, ...): same staging, the decoding happens on the GPU
 MSCompStatus lznt1_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)       { return one_shot(MSCOMP_LZNT1, true, in, n, out, out_len); }
 MSCompStatus xpress_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)      { return one_shot(MSCOMP_XPRESS, true, in, n, out, out_len); }
+MSCompStatus xpress_huff_decompress(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len) { return one_shot(MSCOMP_XPRESS_HUFF, true, in, n, out, out_len); }
 
 #ifndef MSCOMP_AMD_NO_FACADE
 MSCompStatus ms_decompress(MSCompFormat format, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len)
 {
 	switch ((int)format) {
-	case MSCOMP_LZNT1: case MSCOMP_XPRESS: return one_shot(format, true, in, in_len, out, out_len);
+	case MSCOMP_LZNT1: case MSCOMP_XPRESS: case MSCOMP_XPRESS_HUFF: return one_shot(format, true, in, in_len, out, out_len);
 	case MSCOMP_NONE:                                               // mscomp.cpp:26-32
 		if (!out_len || in_len > *out_len) { return out_len ? MSCOMP_BUF_ERROR : MSCOMP_ARG_ERROR; }
 		if (in_len) { memcpy(out, in, in_len); }

@@ -641,4 +641,206 @@ void launch_xpress_decompress(hipStream_t st, const uint8_t* d_in, const BatchTa
 	hipLaunchKernelGGL(xpd_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, d_out, d_out_len, d_status);
 }
 
+// ===================================================================================================================
+// Xpress+Huffman: one wave per buffer
+// ===================================================================================================================
+// xpress_huff_decompress (/root/reference/src/xpress_huff_decompress.cpp:130-162, chunk loop :39-129; InputBitstream Bitstream.h:34-106;
+// HuffmanDecoder<15,512> HuffmanDecoder.h:28-114). Where a chunk's 256-byte table starts is only known when the chunk before it
+// has been decoded (no sizes are stored), and inside a chunk every symbol starts where the previous one ends, so a buffer is
+// decoded by one wave, buffers in parallel. The wave builds the decoding tables of a chunk together (counts and canonical ranks
+// by ballots), then all lanes walk the symbols; codes of up to 9 bits resolve with one LDS read (symbol << 4 | length). Matches
+// reach 65535 bytes back: the output ring holds 9 x 8 KiB and goes to HBM in 8 KiB pieces.
+#define XHD_INB  2048u
+#define XHD_RING 73728u
+struct XhdLds {
+	__attribute__((aligned(16))) uint8_t in[2u * XHD_INB];
+	__attribute__((aligned(16))) uint8_t out[XHD_RING];
+	uint16_t fast[512];                 // 9-bit prefix -> symbol << 4 | length (0: longer code)
+	uint16_t syms[512];                 // symbols in canonical order
+	uint32_t lims[16], poss[16];
+};
+
+__global__ __launch_bounds__(64) void xhd_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, uint8_t* __restrict__ d_out,
+                                                u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
+{
+	__shared__ XhdLds S;
+	const uint32_t lane = threadIdx.x, u = blockIdx.x;
+	const uint32_t n = (uint32_t)bt.in_len[u];
+	const u64 cap = bt.out_cap[u];
+	const uint8_t* src = d_in + bt.in_off[u];
+	uint8_t* dst = d_out + bt.out_off[u];
+	int32_t status = 1; u64 op = 0;                                      // 1 = running
+	// ---- input ring (see xpd_kernel) ----
+	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
+	const uint8_t* ab = src - a0;
+	const u64 endq = (u64)a0 + n;
+	uint4 pf[2];
+	u64 loaded = 0;
+	#define XHD_FETCH(b) { _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) { const u64 q_ = (u64)(b) * XHD_INB + ((uint32_t)i_ * 64u + lane) * 16u; \
+		pf[i_] = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } }
+	#define XHD_STORE(b) { uint8_t* b_ = S.in + ((uint32_t)(b) & 1u) * XHD_INB; \
+		_Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) { *reinterpret_cast<uint4*>(b_ + ((uint32_t)i_ * 64u + lane) * 16u) = pf[i_]; } }
+	#define XHD_NEED(q, margin) while (loaded * XHD_INB < (q) + (margin) && loaded * XHD_INB < endq) { __syncthreads(); XHD_STORE(loaded) ++loaded; XHD_FETCH(loaded) __syncthreads(); }
+	XHD_FETCH(0) XHD_STORE(0) XHD_FETCH(1) XHD_STORE(1) XHD_FETCH(2)
+	loaded = 2;
+	__syncthreads();
+	auto rb = [&](u64 q) -> uint32_t { return S.in[(uint32_t)q & (2u * XHD_INB - 1u)]; };
+	// ---- output ring: coordinate r = output offset + d0; wi = r mod XHD_RING ----
+	const uint32_t d0 = (uint32_t)((uintptr_t)dst & 15u);
+	uint8_t* db = dst - d0;
+	u64 flushed = 0;
+	#define XHD_FLUSH() { const uint8_t* h_ = S.out + (uint32_t)(flushed % XHD_RING); \
+		for (uint32_t i_ = lane; i_ < 512u; i_ += 64u) { const u64 r_ = flushed + (u64)i_ * 16u; \
+			if (r_ >= d0) { *reinterpret_cast<uint4*>(db + r_) = *reinterpret_cast<const uint4*>(h_ + i_ * 16u); } \
+			else { for (uint32_t k_ = d0; k_ < 16u; ++k_) { db[r_ + k_] = h_[i_ * 16u + k_]; } } } \
+		flushed += 8192u; }
+	auto wrap = [](uint32_t x) -> uint32_t { return x >= XHD_RING ? x - XHD_RING : x; };
+	uint32_t wi = d0;                                                    // ring index of output offset op
+	u64 ip = a0;
+	while (status == 1) {
+		// ---- a chunk: 256 bytes of code lengths, then its bit stream (:137-152) ----
+		if (endq - ip < 260u) { status = (ip != endq) ? -3 : 0; break; } // :140-144
+		XHD_NEED(ip, 320u)
+		uint32_t cl[8];
+		{
+			const uint32_t w = rb(ip + 4u * lane) | (rb(ip + 4u * lane + 1u) << 8) | (rb(ip + 4u * lane + 2u) << 16) | (rb(ip + 4u * lane + 3u) << 24);
+			#pragma unroll
+			for (int k = 0; k < 8; ++k) { cl[k] = (w >> (4 * k)) & 0xFu; }   // symbols 8 lane .. 8 lane + 7
+		}
+		ip += 256u;
+		__syncthreads();
+		// SetCodeLengths (HuffmanDecoder.h:42-90): counts, limits, positions, canonical order
+		uint32_t last = 0, pos_acc = 0, prevcnt = 0; bool bad = false;
+		for (uint32_t i = lane; i < 512u; i += 64u) { S.syms[i] = 0xFFFFu; }
+		if (lane == 0) { S.lims[0] = 0; S.poss[0] = 0; }
+		for (uint32_t L = 1; L <= 15u; ++L) {
+			u64 m[8]; uint32_t cnt = 0, before = 0;
+			#pragma unroll
+			for (int k = 0; k < 8; ++k) { m[k] = __ballot(cl[k] == L); cnt += (uint32_t)__builtin_popcountll(m[k]); before += popc_below(m[k]); }
+			pos_acc += prevcnt; prevcnt = cnt;                           // poss[L] = poss[L-1] + cnts[L-1], cnts[0] = 0
+			if (L < 15u) { const uint32_t inc = cnt << (15u - L); if (last + inc > 32768u) { bad = true; } last += inc; }
+			else if (last + cnt > 32768u) { bad = true; }
+			if (lane == 0) { S.lims[L] = L < 15u ? last : 32768u; S.poss[L] = pos_acc; }
+			uint32_t mine = 0;
+			#pragma unroll
+			for (int k = 0; k < 8; ++k) { if (cl[k] == L) { const uint32_t at = pos_acc + before + mine; if (at < 512u) { S.syms[at] = (uint16_t)(lane * 8u + k); } ++mine; } }
+		}
+		if (bad) { status = -3; break; }                                 // :149
+		__syncthreads();
+		const uint32_t lims9 = S.lims[9];
+		for (uint32_t i = lane; i < 512u; i += 64u) {
+			uint32_t e = 0;
+			const uint32_t x = i << 6;
+			if (x < lims9) {
+				uint32_t L = 1;
+				while (x >= S.lims[L]) { ++L; }
+				const uint32_t sidx = S.poss[L] + ((x - S.lims[L - 1u]) >> (15u - L));
+				const uint32_t sym = sidx < 512u ? S.syms[sidx] : 0xFFFFu;
+				e = sym == 0xFFFFu ? 0u : ((sym << 4) | L);
+			}
+			S.fast[i] = (uint16_t)e;
+		}
+		__syncthreads();
+		// ---- the chunk's symbols (:87-127) ----
+		XHD_NEED(ip, 320u)
+		uint32_t mask = (rb(ip) << 16) | (rb(ip + 1) << 24) | rb(ip + 2) | (rb(ip + 3) << 8);   // Bitstream.h:44
+		uint32_t bits = 32; ip += 4u;
+		const u64 chunk_end = op + 65536u;
+		bool stream_end = false;
+		#define XHD_SKIP(k) { mask <<= (k); bits -= (k); if (bits < 16u && ip + 2u <= endq) { mask |= (rb(ip) | (rb(ip + 1) << 8)) << (16u - bits); bits |= 16u; ip += 2u; } }
+		#define XHD_MASK_ZERO() (bits == 0 || (mask >> (32u - bits)) == 0)
+		#define XHD_DECODE(sym) { const uint32_t r_ = bits; const uint32_t x_ = r_ < 15u ? (((mask >> 16) >> (16u - r_)) << (15u - r_)) : (mask >> 17); \
+			const uint32_t f_ = S.fast[x_ >> 6]; uint32_t n_; \
+			if (f_) { n_ = f_ & 0xFu; sym = f_ >> 4; if (n_ > r_) { sym = 0xFFFFu; } else { XHD_SKIP(n_) } } \
+			else { n_ = 1; while (x_ >= S.lims[n_]) { ++n_; } \
+				if (n_ > r_) { sym = 0xFFFFu; } else { XHD_SKIP(n_) const uint32_t s_ = S.poss[n_] + ((x_ - S.lims[n_ - 1u]) >> (15u - n_)); sym = s_ >= 512u ? 0xFFFFu : S.syms[s_]; } } }
+		while (op < chunk_end || !XHD_MASK_ZERO()) {
+			XHD_NEED(ip, 64u)
+			uint32_t sym;
+			XHD_DECODE(sym)
+			if (sym == 0xFFFFu) { status = -3; break; }
+			if (sym == 0x100u && ip == endq && XHD_MASK_ZERO()) { stream_end = true; break; }   // :91
+			if (sym < 0x100u) {
+				if (op == cap) { status = -5; break; }
+				if (lane == 0) { S.out[wi] = (uint8_t)sym; }
+				++op; wi = wrap(wi + 1u);
+				if (op + d0 >= flushed + 8192u) { __syncthreads(); XHD_FLUSH() }
+			} else {
+				uint32_t len = sym & 0xFu;
+				if (len == 0xFu) {
+					if (endq - ip < 1u) { status = -3; break; }
+					len = rb(ip); ip += 1u;
+					if (len == 0xFFu) {
+						if (endq - ip < 2u) { status = -3; break; }
+						len = rb(ip) | (rb(ip + 1) << 8); ip += 2u;
+						if (len == 0) {
+							if (endq - ip < 4u) { status = -3; break; }
+							len = rb(ip) | (rb(ip + 1) << 8) | (rb(ip + 2) << 16) | (rb(ip + 3) << 24); ip += 4u;
+						}
+						if (len < 0xFu) { status = -3; break; }
+						len -= 0xFu;
+					}
+					len += 0xFu;
+				}
+				len += 3u;
+				const uint32_t ob = (sym >> 4) & 0xFu;
+				if (ob > bits) { status = -3; break; }                   // :117
+				const uint32_t off = ((mask >> 16) >> (16u - ob)) + (1u << ob);
+				XHD_SKIP(ob)
+				if (off > op) { status = -3; break; }                    // :120
+				if (len > cap - op) { status = -5; break; }              // :121
+				uint32_t left = len;
+				if (off >= 64u) {
+					uint32_t si = wi >= off ? wi - off : wi + XHD_RING - off;
+					while (left) {
+						const uint32_t step = left < 64u ? left : 64u;
+						if (lane < step) { S.out[wrap(wi + lane)] = S.out[wrap(si + lane)]; }
+						wi = wrap(wi + step); si = wrap(si + step); op += step; left -= step;
+						if (op + d0 >= flushed + 8192u) { __syncthreads(); XHD_FLUSH() }
+					}
+				} else {
+					const float ro = __builtin_amdgcn_rcpf((float)off);
+					const uint32_t span = (uint32_t)(64.5f * ro) * off;
+					const uint32_t lm = lane - (uint32_t)(((float)lane + 0.5f) * ro) * off;
+					const uint32_t s0 = wi >= off ? wi - off : wi + XHD_RING - off;
+					const uint32_t v = S.out[wrap(s0 + lm)];
+					while (left) {
+						const uint32_t step = left < span ? left : span;
+						if (lane < step) { S.out[wrap(wi + lane)] = (uint8_t)v; }
+						wi = wrap(wi + step); op += step; left -= step;
+						if (op + d0 >= flushed + 8192u) { __syncthreads(); XHD_FLUSH() }
+					}
+				}
+			}
+		}
+		if (status != 1) { break; }
+		if (!stream_end) {                                               // :128-134: is the next symbol the end of the stream?
+			const u64 ip_keep = ip;
+			uint32_t sym;
+			XHD_DECODE(sym)
+			if (sym == 0x100u && ip == endq && XHD_MASK_ZERO()) { stream_end = true; } else { ip = ip_keep; }
+		}
+		if (stream_end) { status = 0; }
+	}
+	#undef XHD_FETCH
+	#undef XHD_STORE
+	#undef XHD_NEED
+	#undef XHD_SKIP
+	#undef XHD_MASK_ZERO
+	#undef XHD_DECODE
+	__syncthreads();
+	if (status == 0) {
+		const u64 rend = op + d0;
+		for (u64 r = flushed + lane; r < rend; r += 64u) { if (r >= d0) { db[r] = S.out[(uint32_t)(r % XHD_RING)]; } }
+	}
+	#undef XHD_FLUSH
+	if (lane == 0) { d_status[u] = status; d_out_len[u] = status == 0 ? op : 0; }
+}
+
+void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* d_out, u64* d_out_len, int32_t* d_status)
+{
+	if (bt.n_units == 0) { return; }
+	hipLaunchKernelGGL(xhd_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, d_out, d_out_len, d_status);
+}
+
 } // namespace msc

@@ -55,6 +55,9 @@ void launch_lzd_finalize(hipStream_t st, const BatchTables& bt, const LzdBufs& b
 // Xpress: one wave per stream
 void launch_xpress_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* d_out, u64* d_out_len, int32_t* d_status);
 
+// Xpress+Huffman: one wave per buffer
+void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* d_out, u64* d_out_len, int32_t* d_status);
+
 // ---- utilities (util.hip) ----
 // prefix[0..n] = exclusive scan of sizes[0..n) as u64 (prefix[n] = total). block_sums: scratch of ceil(n/1024)+1 u64.
 void launch_scan_sizes(hipStream_t st, const uint32_t* sizes, u64* prefix, uint32_t n, u64* block_sums);

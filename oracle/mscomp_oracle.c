@@ -576,70 +576,121 @@ static int xpress_huff_compress_o(const uint8_t* d, size_t n, uint8_t* out, size
 	return ORC_OK;
 }
 
-/* Xpress-Huffman decoder (format only; used for round trips). */
+/* Xpress-Huffman decoder with the semantics of the reference's xpress_huff_decompress (xpress_huff_decompress.cpp:130-162) and
+ * its chunk loop (:39-129). The fast loop (:50-84) decides nothing differently from the checked loop (:87-127) while it runs
+ * (>= 13 input bytes and >= 16 output bytes away from the ends), so the checked loop is restated for every symbol.
+ * InputBitstream: Bitstream.h:34-106; HuffmanDecoder<15,512>: HuffmanDecoder.h:28-114. */
+typedef struct { const uint8_t* in; const uint8_t* end; uint32_t mask; unsigned bits; } xh_ibs;
+static inline uint32_t xh_peek(const xh_ibs* b, unsigned n) { return (b->mask >> 16) >> (16 - n); }              /* Bitstream.h:55 */
+static inline int xh_mask_is_zero(const xh_ibs* b) { return b->bits == 0 || (b->mask >> (32 - b->bits)) == 0; } /* :58 */
+static inline void xh_skip(xh_ibs* b, unsigned n)                                                                /* :63-74 */
+{
+	b->mask <<= n; b->bits -= n;
+	if (b->bits < 16 && b->in + 2 <= b->end) { b->mask |= get16(b->in) << (16 - b->bits); b->bits |= 0x10; b->in += 2; }
+}
+typedef struct { uint32_t lims[16], poss[16]; uint16_t syms[512]; uint8_t lens[512]; } xh_dec;
+static int xh_set_code_lengths(xh_dec* d, const uint8_t cl[512])                                                  /* HuffmanDecoder.h:42-90 */
+{
+	uint32_t cnts[16] = { 0 }, last = 0, index = 0;
+	memset(d->syms, 0xFF, sizeof d->syms);
+	for (unsigned s = 0; s < 512; ++s) { ++cnts[cl[s]]; }
+	cnts[0] = 0;
+	d->lims[0] = 0; d->lims[15] = 32768;
+	for (unsigned len = 1; len <= 9; ++len) {
+		const uint32_t inc = cnts[len] << (15 - len);
+		if (last + inc > 32768) { return 0; }
+		d->lims[len] = (last += inc);
+		const uint32_t limit = last >> 6;
+		memset(d->lens + index, (int)len, limit - index); index = limit;
+	}
+	for (unsigned len = 10; len < 15; ++len) {
+		const uint32_t inc = cnts[len] << (15 - len);
+		if (last + inc > 32768) { return 0; }
+		d->lims[len] = (last += inc);
+	}
+	if (last + cnts[15] > 32768) { return 0; }
+	d->poss[0] = 0;
+	for (unsigned len = 1; len <= 15; ++len) { d->poss[len] = d->poss[len - 1] + cnts[len - 1]; }
+	memcpy(cnts, d->poss, sizeof cnts);
+	for (unsigned s = 0; s < 512; ++s) { if (cl[s]) { d->syms[cnts[cl[s]]++] = (uint16_t)s; } }
+	return 1;
+}
+#define XH_INVALID 0xFFFFu
+static unsigned xh_decode_symbol(const xh_dec* d, xh_ibs* b)                                                      /* HuffmanDecoder.h:92-102 */
+{
+	unsigned n; const unsigned r = b->bits;
+	const uint32_t x = r < 15 ? (xh_peek(b, r) << (15 - r)) : xh_peek(b, 15);
+	if (x < d->lims[9]) { n = d->lens[x >> 6]; } else { for (n = 10; x >= d->lims[n]; ++n) { } }
+	if (n > r) { return XH_INVALID; }
+	xh_skip(b, n);
+	const uint32_t s = d->poss[n] + ((x - d->lims[n - 1]) >> (15 - n));
+	return s >= 512 ? XH_INVALID : d->syms[s];
+}
+/* xpress_huff_decompress_chunk: 0 = chunk done, 1 = stream end, < 0 = error. */
+static int xh_decompress_chunk_o(const uint8_t** pin, const uint8_t* in_end, uint8_t* out_base, size_t* pop, size_t cap, const xh_dec* d)
+{
+	xh_ibs b = { *pin + 4, in_end, (get16(*pin) << 16) | get16(*pin + 2), 32 };                                   /* Bitstream.h:44 */
+	size_t op = *pop;
+	const size_t chunk_end = op + 65536;
+	while (op < chunk_end || !xh_mask_is_zero(&b)) {                                                              /* :87 */
+		const unsigned sym = xh_decode_symbol(d, &b);
+		if (sym == XH_INVALID) { return ORC_DATA_ERROR; }
+		if (sym == 0x100 && b.in == b.end && xh_mask_is_zero(&b)) { *pin = b.in; *pop = op; return 1; }           /* :91 */
+		if (sym < 0x100) {
+			if (op == cap) { return ORC_BUF_ERROR; }
+			out_base[op++] = (uint8_t)sym;
+		} else {
+			uint32_t len = sym & 0xF, off;
+			if (len == 0xF) {
+				if (b.end - b.in < 1) { return ORC_DATA_ERROR; }
+				if ((len = *b.in++) == 0xFF) {
+					if (b.end - b.in < 2) { return ORC_DATA_ERROR; }
+					len = get16(b.in); b.in += 2;
+					if (len == 0) {
+						if (b.end - b.in < 4) { return ORC_DATA_ERROR; }
+						len = get32(b.in); b.in += 4;
+					}
+					if (len < 0xF) { return ORC_DATA_ERROR; }
+					len -= 0xF;
+				}
+				len += 0xF;
+			}
+			len += 3;
+			{
+				const unsigned off_bits = (sym >> 4) & 0xF;
+				if (off_bits > b.bits) { return ORC_DATA_ERROR; }                                                 /* :117 */
+				off = xh_peek(&b, off_bits) + (1u << off_bits); xh_skip(&b, off_bits);
+			}
+			if (off > op) { return ORC_DATA_ERROR; }                                                              /* :120 */
+			if (len > cap - op) { return ORC_BUF_ERROR; }                                                         /* :121 */
+			for (uint32_t i = 0; i < len; ++i) { out_base[op] = out_base[op - off]; ++op; }
+		}
+	}
+	*pop = op; *pin = b.in;
+	if (xh_decode_symbol(d, &b) == 0x100 && b.in == b.end && xh_mask_is_zero(&b)) { *pin = b.in; return 1; }     /* :130-134 */
+	return 0;
+}
 static int xpress_huff_decompress_o(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)
 {
 	const size_t cap = *out_len;
-	size_t ip = 0, op = 0;
-	uint16_t* tab = (uint16_t*)malloc(32768 * sizeof(uint16_t));   /* 15-bit prefix -> (sym<<4)|len */
-	if (!tab) { return ORC_MEM_ERROR; }
-	while (ip < n) {
-		uint8_t lens[512]; uint16_t codes[512];
-		if (n - ip < 260) { free(tab); return ORC_DATA_ERROR; }
-		for (unsigned i = 0; i < 256; ++i) { lens[2 * i] = in[ip + i] & 0xF; lens[2 * i + 1] = in[ip + i] >> 4; }
+	const uint8_t* ip = in; const uint8_t* in_end = in + n;
+	size_t op = 0;
+	int status;
+	xh_dec* d = (xh_dec*)malloc(sizeof *d);
+	if (!d) { return ORC_MEM_ERROR; }
+	do {
+		uint8_t cl[512];
+		if (in_end - ip < 260) {                                                                                  /* :140-144 */
+			if (ip != in_end) { free(d); return ORC_DATA_ERROR; }
+			break;
+		}
+		for (unsigned i = 0; i < 256; ++i) { cl[2 * i] = ip[i] & 0xF; cl[2 * i + 1] = ip[i] >> 4; }
 		ip += 256;
-		canonical_codes(lens, codes);
-		memset(tab, 0, 32768 * sizeof(uint16_t));
-		for (unsigned s = 0; s < 512; ++s) {
-			if (!lens[s]) { continue; }
-			const unsigned lo = (unsigned)codes[s] << (15 - lens[s]), cnt = 1u << (15 - lens[s]);
-			if (lo + cnt > 32768) { free(tab); return ORC_DATA_ERROR; }
-			for (unsigned k = 0; k < cnt; ++k) { tab[lo + k] = (uint16_t)((s << 4) | lens[s]); }
-		}
-		uint32_t bits = (get16(in + ip) << 16) | get16(in + ip + 2);
-		int extra = 16;
-		const size_t chunk_end = op + 65536;
-		ip += 4;
-#define XH_CONSUME(k) do { bits <<= (k); extra -= (int)(k); if (extra < 0) { if (ip + 2 > n) { free(tab); return ORC_DATA_ERROR; } \
-	bits |= get16(in + ip) << (-extra); ip += 2; extra += 16; } } while (0)
-		for (;;) {
-			if (op >= chunk_end) { break; }
-			const unsigned e = tab[bits >> 17];
-			if (!e) { free(tab); return ORC_DATA_ERROR; }
-			const unsigned s = e >> 4;
-			XH_CONSUME(e & 0xF);
-			if (s < 0x100) { if (op >= cap) { free(tab); return ORC_BUF_ERROR; } out[op++] = (uint8_t)s; continue; }
-			/* EOS: all input consumed. (Ambiguous with a real off=1,len=3 match when the EOS code is all
-			 * zero bits -- the reference decoder has the same ambiguity -- so callers of this test helper
-			 * pass cap == original length and we keep decoding while output is still owed.) */
-			if (s == 0x100 && ip >= n && bits == 0 && op >= cap) { goto done; }
-			size_t len = s & 0xF; const unsigned ob = (s >> 4) & 0xF;
-			if (len == 15) {
-				if (ip >= n) { free(tab); return ORC_DATA_ERROR; }
-				len = in[ip++];
-				if (len == 255) {
-					if (ip + 2 > n) { free(tab); return ORC_DATA_ERROR; }
-					len = get16(in + ip); ip += 2;
-					if (len == 0) { if (ip + 4 > n) { free(tab); return ORC_DATA_ERROR; } len = get32(in + ip); ip += 4; }
-					if (len < 15) { free(tab); return ORC_DATA_ERROR; }
-					len -= 15;
-				}
-				len += 15;
-			}
-			len += 3;
-			const size_t off = (ob ? (bits >> (32 - ob)) : 0) + ((size_t)1 << ob);
-			XH_CONSUME(ob);
-			if (off > op) { free(tab); return ORC_DATA_ERROR; }
-			if (op + len > cap) { free(tab); return ORC_BUF_ERROR; }
-			while (len--) { out[op] = out[op - off]; ++op; }
-		}
-#undef XH_CONSUME
-		/* a full 64 KiB chunk was produced. A following chunk needs >= 256+4 bytes; anything shorter is the
-		 * EOS tail of a final chunk that held exactly 64 KiB (its EOS code is still in `bits`). */
-		if (n - ip < 260) { break; }
-	}
-done:
-	free(tab);
+		if (!xh_set_code_lengths(d, cl)) { free(d); return ORC_DATA_ERROR; }
+		status = xh_decompress_chunk_o(&ip, in_end, out, &op, cap, d);
+		if (status < 0) { free(d); return status; }
+	} while (status != 1);
+	free(d);
 	*out_len = op;
 	return ORC_OK;
 }

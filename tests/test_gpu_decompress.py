@@ -7,7 +7,7 @@ import pytest
 import cases
 
 pytestmark = pytest.mark.gpu
-FMTS = {"lznt1": 2, "xpress": 3}
+FMTS = {"lznt1": 2, "xpress": 3, "xpress_huff": 4}
 
 
 @pytest.mark.parametrize("fmt", list(FMTS))

@@ -80,7 +80,7 @@ def test_huffman_builders(oracle, ref):
         assert lens.tolist() == _huff_ref("slow", counts), "CreateCodesSlow case %d" % case
 
 
-@pytest.mark.parametrize("fmt", [2, 3])
+@pytest.mark.parametrize("fmt", [2, 3, 4])
 def test_decompress_semantics(oracle, ref, fmt):
     """The restated decoders return the reference's status and bytes on valid, truncated, concatenated and corrupted
     streams, for exact / larger / smaller capacities (streams on which the reference is undefined are not put to it)."""
