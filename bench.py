@@ -84,6 +84,33 @@ class Job:
         self.plan.close()
 
 
+def decompress_leg(m, ctx, fmt, blob, in_off, in_len, desc, steps, sharding):
+    """decode on the GPU what the GPU compressor wrote for this workload, check that the input comes back,
+    report decompressed MB/s (HBM-resident, like `value`)."""
+    import torch
+    job = Job(m, ctx, fmt, blob, in_off, in_len)
+    job.step(); torch.cuda.synchronize()
+    comp_len = job.d_len.cpu().numpy().astype(np.uint64)
+    assert bool((job.d_st == 0).all().item())
+    d_back = torch.zeros(len(blob) + 16, dtype=torch.uint8, device=job.d_in.device)
+    caps = [m.max_compressed_size(fmt, int(x)) + 2 for x in in_len]
+    comp_off, _ = m.pack_offsets(caps)
+    plan = m.Plan(ctx, fmt, comp_off, comp_len, in_off, in_len, decompress=True)
+
+    class D:
+        pass
+    d = D(); d.ctx = ctx
+    d.step = lambda: plan.execute(job.d_out, d_back, job.d_len2, job.d_st2)
+    job.d_len2 = torch.zeros_like(job.d_len); job.d_st2 = torch.full_like(job.d_st, -9)
+    dt, prof = timed(d, steps, 1, sharding)
+    ok = bool((job.d_st2 == 0).all().item()) and bool(torch.equal(job.d_len2.cpu(), torch.from_numpy(in_len.astype(np.int64)))) \
+        and bool(torch.equal(d_back[: len(blob)], job.d_in[: len(blob)]))
+    res = {"MB_per_s": round(job.in_bytes * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3), "workload": desc,
+           "round_trip_ok": ok, "kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
+    plan.close(); job.close()
+    return res
+
+
 def timed(job, steps, warmup, sharding):
     import torch
     for _ in range(warmup):
@@ -221,6 +248,12 @@ def main():
             extra[codec] = {"MB_per_s": round(j2.in_bytes * steps2 / t2 / 1e6, 1), "ms_per_step": round(t2 / steps2 * 1e3, 3),
                             "workload": d2, "compression_ratio": round(ob / j2.in_bytes, 4), "roofline": roofline(f2, p2, j2.in_bytes, ob)}
             j2.close()
+        dec = {}
+        for codec, wl in (("lznt1", "mozilla"), ("xpress", "silesia_units64k"), ("xpress_huff", "silesia_units64k")):
+            f2 = m.FORMATS[codec]
+            b2, o2, l2, d2 = build_workload(m, corpus, f2, wl)
+            dec[codec] = decompress_leg(m, ctx, f2, b2, o2, l2, d2, 3, sharding)
+        extra["decompress"] = dec
         res["extra"] = extra
     if rank == 0:
         print(json.dumps(res))

@@ -166,28 +166,70 @@ __global__ __launch_bounds__(64) void lzd_verify_kernel(const uint8_t* __restric
 	uint32_t pos = 0, stopk = 0, last = 0;
 	bool ended = false;
 	for (uint32_t s0 = 0; s0 < S; s0 += 64u) {
-		// lane t holds the LZD_K chains of segment s0 + t
+		// lane t holds the LZD_K chains of segment s0 + t (an unrecorded chain cannot be used), and the landings of the segment behind it
 		const uint32_t sl = s0 + lane;
-		uint32_t cl[LZD_K], ce[LZD_K];
+		uint32_t cl[LZD_K], ce[LZD_K], nl[LZD_K];
 		#pragma unroll
 		for (uint32_t k = 0; k < LZD_K; ++k) {
 			const size_t r = (size_t)(g0 + (sl < S ? sl : S - 1u)) * LZD_K + k;
-			cl[k] = segL[r]; ce[k] = (segoff[r] == LZD_NONE) ? LZD_NONE : segE[r];     // an unrecorded chain cannot be used
+			const bool usable = sl < S && segoff[r] != LZD_NONE;
+			cl[k] = usable ? segL[r] : LZD_NONE; ce[k] = usable ? segE[r] : LZD_NONE;
+			nl[k] = (sl + 1u < S && segoff[r + LZD_K] != LZD_NONE) ? segL[r + LZD_K] : LZD_NONE;
 		}
 		uint32_t mycnt = 0, mysel = LZD_K + 1u;                          // what lane t learns about its segment (LZD_K + 1: not reached, LZD_K: walked here)
 		const uint32_t tiles = S - s0 < 64u ? S - s0 : 64u;
+		if (ended) { if (sl < S) { selcnt[g0 + sl] = 0; seloff[g0 + sl] = 0; } continue; }
+		// ---- all 64 segments at once: chain k of a segment continues as chain map[k] of the next (0xE: the stream ends in it, 0xF: nowhere) ----
+		uint32_t map = 0;
+		#pragma unroll
+		for (uint32_t k = 0; k < LZD_K; ++k) {
+			uint32_t to = 0xFu;
+			if (ce[k] == LZD_ENDED) { to = 0xEu; }
+			else if (ce[k] != LZD_NONE) {
+				#pragma unroll
+				for (uint32_t q = LZD_K; q-- > 0;) { if (nl[q] == ce[k]) { to = q; } }
+			}
+			map |= to << (4u * k);
+		}
+		auto compose = [](uint32_t a, uint32_t b) -> uint32_t {          // chain k -> a[b[k]]
+			uint32_t r = 0;
+			#pragma unroll
+			for (uint32_t k = 0; k < LZD_K; ++k) { const uint32_t bk = (b >> (4u * k)) & 0xFu; r |= (bk < LZD_K ? (a >> (4u * bk)) & 0xFu : bk) << (4u * k); }
+			return r;
+		};
+		uint32_t P = map;
+		#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)P, d, 64); if ((int)lane >= d) { P = compose(P, t); } }
+		uint32_t carry = 0xFu;                                           // the chain of the tile's first segment that starts at pos
+		#pragma unroll
+		for (uint32_t k = LZD_K; k-- > 0;) { if ((uint32_t)__builtin_amdgcn_readlane((int)cl[k], 0) == pos) { carry = k; } }
+		const uint32_t Pprev = (uint32_t)__shfl_up((int)P, 1, 64);
+		const uint32_t sel = carry >= LZD_K ? 0xFu : (lane == 0 ? carry : (Pprev >> (4u * carry)) & 0xFu);
+		const u64 fail = __ballot(sl < S && sel == 0xFu);
+		if (!fail) {
+			uint32_t nxt = 0xFu, e = LZD_NONE;
+			#pragma unroll
+			for (uint32_t k = 0; k < LZD_K; ++k) { if (sel == k) { nxt = (map >> (4u * k)) & 0xFu; e = ce[k]; } }
+			if (sl < S && sel < LZD_K) { mysel = sel; }
+			const u64 endm = __ballot(sl < S && sel < LZD_K && nxt == 0xEu);   // the segment in which the stream ends
+			if (endm) {
+				const uint32_t le = ctz64(endm);
+				stopk = segstop[(size_t)(g0 + s0 + le) * LZD_K + (uint32_t)__builtin_amdgcn_readlane((int)sel, (int)le)];
+				ended = true;
+			} else { pos = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)(tiles - 1u)); }
+		} else {
 		for (uint32_t t = 0; t < tiles; ++t) {
 			if (ended) { break; }
-			uint32_t sel = LZD_K, e = LZD_NONE;
+			uint32_t sel1 = LZD_K, e = LZD_NONE;
 			#pragma unroll
 			for (uint32_t k = 0; k < LZD_K; ++k) {
 				const uint32_t lk = (uint32_t)__builtin_amdgcn_readlane((int)cl[k], (int)t), ek = (uint32_t)__builtin_amdgcn_readlane((int)ce[k], (int)t);
-				if (sel == LZD_K && lk == pos && ek != LZD_NONE) { sel = k; e = ek; }
+				if (sel1 == LZD_K && lk == pos && ek != LZD_NONE) { sel1 = k; e = ek; }
 			}
 			const uint32_t g = g0 + s0 + t;
-			if (sel < LZD_K) {
-				if (lane == t) { mysel = sel; }
-				if (e == LZD_ENDED) { stopk = segstop[(size_t)g * LZD_K + sel]; ended = true; } else { pos = e; }
+			if (sel1 < LZD_K) {
+				if (lane == t) { mysel = sel1; }
+				if (e == LZD_ENDED) { stopk = segstop[(size_t)g * LZD_K + sel1]; ended = true; } else { pos = e; }
 			} else {                                                     // no recorded chain starts here: walk the segment now
 				uint32_t count = 0;
 				uint32_t* __restrict__ my = cin + (size_t)g * LZD_SLOTS;
@@ -203,6 +245,7 @@ __global__ __launch_bounds__(64) void lzd_verify_kernel(const uint8_t* __restric
 				if (lane == t) { mycnt = count; mysel = LZD_K; }
 				if (lane == 0) { atomicAdd(&g_lzd_walked, 1u); }
 			}
+		}
 		}
 		if (sl < S) {
 			uint32_t myoff = 0;

@@ -43,7 +43,7 @@ void launch_xh_encode(hipStream_t st, const uint8_t* d_in, const BatchTables& bt
 #define LZD_SEG   49152u
 #define LZD_HEAD  12288u
 #define LZD_SLOTS (LZD_SEG / 3u + 2u)
-#define LZD_K     4u         // speculated chains kept per segment
+#define LZD_K     8u         // speculated chains kept per segment
 struct LzdBufs { uint32_t* cin; uint16_t* csize; uint32_t* segL; uint32_t* segE; uint32_t* segcnt; uint32_t* segstop; uint32_t* segoff;   /* LZD_K per segment */
                  uint32_t* selcnt; uint32_t* seloff; uint32_t* stop; uint32_t* irregular; u64* flat; };
 void launch_lzd_segments(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const LzdBufs& b);

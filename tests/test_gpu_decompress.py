@@ -87,3 +87,26 @@ def test_round_trip_full_size_lznt1(oracle, gpu_ctx):
         assert int(d_st[0]) == 0 and int(d_len[0]) == n
         assert torch.equal(d_back[:n], d_in)
     q.close()
+
+
+def test_lznt1_header_walk_falls_back_when_speculation_cannot_decide(oracle, gpu_ctx):
+    """Stored chunks full of 0x33 bytes: every offset of such a stream looks like a chunk header (0x3333: signature 011, 822
+    bytes), so the speculated chains of a segment do not agree on one landing and the verify kernel walks those segments itself.
+    The result must not change; a mixed stream (compressed text, then the hostile part, then text) exercises the hand-over."""
+    import ms_compress_amd as m
+    hostile = b"".join(b"\xff\x3f" + b"\x33" * 4096 for _ in range(60))           # 60 stored chunks = 245 880 B of input
+    text = cases.mixed_buffer()[:200000]
+    ctext = oracle.oracle_compress(2, text)[1]
+    streams = [hostile, ctext + hostile + ctext, hostile + ctext]
+    plain = [b"\x33" * (4096 * 60), text + b"\x33" * (4096 * 60) + text, b"\x33" * (4096 * 60) + text]
+    gpu_ctx.lib.mscomp_amd_debug_lzd_walked(gpu_ctx._h)
+    outs, sts = m.decompress_units(2, streams, [len(p) for p in plain], ctx=gpu_ctx)
+    walked = gpu_ctx.lib.mscomp_amd_debug_lzd_walked(gpu_ctx._h)
+    assert sts == [0, 0, 0] and outs == plain
+    assert walked >= 3, walked
+    for s, p in zip(streams, plain):
+        assert oracle.oracle_decompress_ex(2, s, len(p))[:2] == (0, p)
+    # and the ordinary corpus needs no fallback
+    comp, _ = m.compress_units(2, [cases.mixed_buffer()], ctx=gpu_ctx)
+    m.decompress_units(2, comp, [len(cases.mixed_buffer())], ctx=gpu_ctx)
+    assert gpu_ctx.lib.mscomp_amd_debug_lzd_walked(gpu_ctx._h) == 0
