@@ -534,12 +534,15 @@ void launch_lzd_finalize(hipStream_t st, const BatchTables& bt, const LzdBufs& b
 // ===================================================================================================================
 // xpress_decompress (/root/reference/src/xpress_decompress.cpp:405-462, READ_SYMBOL :62-107): a stream is one chain of tokens - where
 // a token starts depends on every token before it (32-bit flag words, 1 / 2 / 3 / 4 / 6 / 10-byte tokens, a length nibble shared
-// by two matches) - so a stream is decoded by one wave, streams in parallel. All lanes run the token walk (it is uniform);
-// the input is staged through an 8 KiB LDS ring (the next 4 KiB block is in flight in registers), the output through a 16 KiB
-// ring from which matches are copied (offsets reach 8192 bytes back) and which is written to HBM in 8 KiB halves; a literal
-// run and a match are moved by the lanes together.
-#define XPD_INB 4096u
-struct XpdLds { __attribute__((aligned(16))) uint8_t in[2u * XPD_INB]; __attribute__((aligned(16))) uint8_t out[16384]; };
+// by two matches) - so a stream is decoded by one wave, streams in parallel. All lanes run the token walk (it is uniform).
+// The input is staged through a 2 KiB LDS ring (the next 1 KiB block is in flight in registers), the output through a 10 KiB ring
+// from which matches are copied (offsets reach 8192 bytes back) and which goes to HBM in 2 KiB pieces: 12.3 KiB of LDS, 13
+// streams per CU. A literal run and a match are moved by the lanes together. The 8 bytes at the next token are fetched (3
+// aligned dword reads) before the current token's bytes are moved, so a token costs about one LDS round trip.
+#define XPD_INB  1024u
+#define XPD_RING 10240u
+#define XPD_PIECE 2048u
+struct XpdLds { __attribute__((aligned(16))) uint8_t in[2u * XPD_INB]; __attribute__((aligned(16))) uint8_t out[XPD_RING]; };
 
 __global__ __launch_bounds__(64) void xpd_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, uint8_t* __restrict__ d_out,
                                                 u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
@@ -557,64 +560,76 @@ __global__ __launch_bounds__(64) void xpd_kernel(const uint8_t* __restrict__ d_i
 		if (lane == 0) { d_status[u] = ok ? 0 : -3; d_out_len[u] = 0; }
 		return;
 	}
-	// ---- input ring: q = offset from the 16-byte aligned base; block b = q in [4096 b, 4096 (b+1)) lives at in[(b & 1) * 4096] ----
+	// ---- input ring: q = offset from the 16-byte aligned base (32 bits: units are below 4 GiB - 256); block b = q in [1024 b, 1024 (b+1)) ----
 	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
 	const uint8_t* ab = src - a0;
-	const u64 endq = (u64)a0 + n;
-	uint4 pf[4];
-	u64 loaded = 0;                                                      // blocks stored so far; block `loaded` is in pf
-	#define XPD_FETCH(b) { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { const u64 q_ = (u64)(b) * XPD_INB + ((uint32_t)i_ * 64u + lane) * 16u; \
-		pf[i_] = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } }
-	#define XPD_STORE(b) { uint8_t* b_ = S.in + ((uint32_t)(b) & 1u) * XPD_INB; \
-		_Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { *reinterpret_cast<uint4*>(b_ + ((uint32_t)i_ * 64u + lane) * 16u) = pf[i_]; } }
+	const uint32_t endq = a0 + n;
+	uint4 pf;
+	uint32_t loaded = 0;                                                 // blocks stored so far; block `loaded` is in pf
+	#define XPD_FETCH(b) { const u64 q_ = (u64)(b) * XPD_INB + lane * 16u; pf = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); }
+	#define XPD_STORE(b) { *reinterpret_cast<uint4*>(S.in + ((uint32_t)(b) & 1u) * XPD_INB + lane * 16u) = pf; }
 	XPD_FETCH(0) XPD_STORE(0) XPD_FETCH(1) XPD_STORE(1) XPD_FETCH(2)
 	loaded = 2;
 	__syncthreads();
-	auto rb = [&](u64 q) -> uint32_t { return S.in[(uint32_t)q & (2u * XPD_INB - 1u)]; };
-	// ---- output ring: r = output offset + d0 (d0 = alignment of the destination): halves of 8192 are 16-byte aligned in HBM ----
+	auto rb = [&](uint32_t q) -> uint32_t { return S.in[q & (2u * XPD_INB - 1u)]; };
+	const uint32_t* in32 = reinterpret_cast<const uint32_t*>(S.in);
+	// bytes q .. q+7 as two dwords
+	#define XPD_FETCH8(q, lo, hi) { const uint32_t i_ = ((q) >> 2) & (2u * XPD_INB / 4u - 1u), sh_ = (q) & 3u; \
+		const uint32_t w0_ = in32[i_], w1_ = in32[(i_ + 1u) & (2u * XPD_INB / 4u - 1u)], w2_ = in32[(i_ + 2u) & (2u * XPD_INB / 4u - 1u)]; \
+		lo = __builtin_amdgcn_alignbyte(w1_, w0_, sh_); hi = __builtin_amdgcn_alignbyte(w2_, w1_, sh_); }
+	// ---- output ring: coordinate r = output offset + d0 (d0 = alignment of the destination): pieces of 2048 are 16-byte aligned in HBM ----
 	const uint32_t d0 = (uint32_t)((uintptr_t)dst & 15u);
 	uint8_t* db = dst - d0;
-	u64 flushed = 0;                                                     // ring coordinate up to which the output is in HBM (multiple of 8192)
-	#define XPD_FLUSH_HALF() { const uint8_t* h_ = S.out + ((uint32_t)flushed & 16383u); \
-		for (uint32_t i_ = lane; i_ < 512u; i_ += 64u) { const u64 r_ = flushed + (u64)i_ * 16u; \
-			if (r_ >= d0) { *reinterpret_cast<uint4*>(db + r_) = *reinterpret_cast<const uint4*>(h_ + i_ * 16u); } \
-			else { for (uint32_t k_ = d0; k_ < 16u; ++k_) { db[r_ + k_] = h_[i_ * 16u + k_]; } } } \
-		flushed += 8192u; }
-	u64 ip = a0;                                                         // in q coordinates
+	u64 flushed = 0;                                                     // ring coordinate up to which the output is in HBM (multiple of XPD_PIECE)
+	uint32_t fi = 0;                                                     // flushed mod XPD_RING
+	#define XPD_FLUSH() { _Pragma("unroll") for (uint32_t i_ = 0; i_ < 2u; ++i_) { const uint32_t o_ = (i_ * 64u + lane) * 16u; const u64 r_ = flushed + o_; \
+			if (r_ >= d0) { *reinterpret_cast<uint4*>(db + r_) = *reinterpret_cast<const uint4*>(S.out + fi + o_); } \
+			else { for (uint32_t k_ = d0; k_ < 16u; ++k_) { db[r_ + k_] = S.out[fi + o_ + k_]; } } } \
+		flushed += XPD_PIECE; fi += XPD_PIECE; if (fi == XPD_RING) { fi = 0; } }
+	auto wrap = [](uint32_t x) -> uint32_t { return x >= XPD_RING ? x - XPD_RING : x; };
+	uint32_t wi = d0;                                                    // ring index of output offset op
+	u64 nextflush = XPD_PIECE - d0;                                      // output offset at which the next piece is complete
+	uint32_t ip = a0;
 	uint32_t half = 0; bool have_half = false;
 	bool done = false;
+	uint32_t lo = 0, hi = 0;
+	XPD_FETCH8(ip, lo, hi)
 	while (!done) {
 		if (ip + 4u > endq) { status = -3; break; }                     // :461 the input ended at a flag word
-		while (loaded * XPD_INB < ip + 352u && loaded * XPD_INB < endq) {   // a flag word and its 32 tokens take at most 4 + 32 * 10 bytes
+		while (loaded * XPD_INB < ip + 352u && (u64)loaded * XPD_INB < endq) {   // a flag word and its 32 tokens take at most 4 + 32 * 10 bytes
 			__syncthreads();
 			XPD_STORE(loaded) ++loaded; XPD_FETCH(loaded)
 			__syncthreads();
+			XPD_FETCH8(ip, lo, hi)
 		}
-		uint32_t flags = rb(ip) | (rb(ip + 1) << 8) | (rb(ip + 2) << 16) | (rb(ip + 3) << 24);
+		uint32_t flags = lo;
 		uint32_t flagged = flags >> 31;
 		flags = (flags << 1) | 1u; ip += 4u;
+		lo = hi; XPD_FETCH8(ip, lo, hi)
 		do {
 			if (ip == endq) {                                            // :433-438
-				uint32_t x = ~flags;
+				const uint32_t x = ~flags;
 				status = (flagged && !((x + 1u) & x)) ? 0 : -3; done = true; break;
 			}
 			if (flagged) {
 				if (ip + 2u > endq) { status = -3; done = true; break; }
-				const uint32_t sym = rb(ip) | (rb(ip + 1) << 8); ip += 2u;
+				const uint32_t sym = lo & 0xFFFFu;
+				uint32_t used = 2u;                                      // bytes of this token; byte k of the token is (k < 4 ? lo : hi) >> 8 (k & 3)
 				const uint32_t off = (sym >> 3) + 1u; uint32_t len = sym & 7u;
 				if (len == 7u) {
 					if (have_half) { len = half >> 4; have_half = false; }
-					else if (ip == endq) { status = -3; done = true; break; }
-					else { half = rb(ip); ip += 1u; have_half = true; len = half & 0xFu; }
+					else if (ip + used == endq) { status = -3; done = true; break; }
+					else { half = (lo >> 16) & 0xFFu; used = 3u; have_half = true; len = half & 0xFu; }
 					if (len == 0xFu) {
-						if (ip == endq) { status = -3; done = true; break; }
-						len = rb(ip); ip += 1u;
+						if (ip + used == endq) { status = -3; done = true; break; }
+						len = used == 2u ? (lo >> 16) & 0xFFu : lo >> 24; ++used;
 						if (len == 0xFFu) {
-							if (ip + 2u > endq) { status = -3; done = true; break; }
-							len = rb(ip) | (rb(ip + 1) << 8); ip += 2u;
+							if (ip + used + 2u > endq) { status = -3; done = true; break; }
+							len = used == 3u ? ((lo >> 24) | ((hi & 0xFFu) << 8)) : (hi & 0xFFFFu); used += 2u;
 							if (len == 0) {
-								if (ip + 4u > endq) { status = -3; done = true; break; }
-								len = rb(ip) | (rb(ip + 1) << 8) | (rb(ip + 2) << 16) | (rb(ip + 3) << 24); ip += 4u;
+								if (ip + used + 4u > endq) { status = -3; done = true; break; }
+								const uint32_t q4 = ip + used;
+								len = rb(q4) | (rb(q4 + 1u) << 8) | (rb(q4 + 2u) << 16) | (rb(q4 + 3u) << 24); used += 4u;
 							}
 							if (len < 0xFu + 0x7u) { status = -3; done = true; break; }
 							len -= 0xFu + 0x7u;
@@ -624,43 +639,43 @@ __global__ __launch_bounds__(64) void xpd_kernel(const uint8_t* __restrict__ d_i
 					len += 0x7u;
 				}
 				len += 0x3u;
+				ip += used;
+				XPD_FETCH8(ip, lo, hi)                                  // the next token's bytes travel while this one is copied
 				if (off > op) { status = -3; done = true; break; }       // :442
 				if (len > cap - op) { status = -5; done = true; break; } // :443
-				// copy: the source is at most 8192 bytes back, inside the ring
-				u64 r = op + d0;
+				uint32_t left = len;
 				if (off >= 64u) {
-					uint32_t left = len;
+					uint32_t si = wi >= off ? wi - off : wi + XPD_RING - off;
 					while (left) {
 						const uint32_t step = left < 64u ? left : 64u;
-						if (lane < step) { S.out[(uint32_t)(r + lane) & 16383u] = S.out[(uint32_t)(r + lane - off) & 16383u]; }
-						r += step; left -= step;
-						if (r >= flushed + 8192u) { __syncthreads(); XPD_FLUSH_HALF() }
+						if (lane < step) { S.out[wrap(wi + lane)] = S.out[wrap(si + lane)]; }
+						wi = wrap(wi + step); si = wrap(si + step); op += step; left -= step;
+						if (op >= nextflush) { __syncthreads(); XPD_FLUSH() nextflush += XPD_PIECE; }
 					}
 				} else {
 					const float ro = __builtin_amdgcn_rcpf((float)off);  // off < 64: (x + 0.5) / off is never within 1e-3 of an integer
 					const uint32_t span = (uint32_t)(64.5f * ro) * off;  // whole periods per step
 					const uint32_t lm = lane - (uint32_t)(((float)lane + 0.5f) * ro) * off;
-					const uint32_t v = S.out[(uint32_t)(r - off + lm) & 16383u];
-					uint32_t left = len;
+					const uint32_t s0 = wi >= off ? wi - off : wi + XPD_RING - off;
+					const uint32_t v = S.out[wrap(s0 + lm)];
 					while (left) {
 						const uint32_t step = left < span ? left : span;
-						if (lane < step) { S.out[(uint32_t)(r + lane) & 16383u] = (uint8_t)v; }
-						r += step; left -= step;
-						if (r >= flushed + 8192u) { __syncthreads(); XPD_FLUSH_HALF() }
+						if (lane < step) { S.out[wrap(wi + lane)] = (uint8_t)v; }
+						wi = wrap(wi + step); op += step; left -= step;
+						if (op >= nextflush) { __syncthreads(); XPD_FLUSH() nextflush += XPD_PIECE; }
 					}
 				}
-				op += len;
 				flagged = flags >> 31; flags <<= 1;
 			} else {
 				// a run of literals: this token and the zero flags behind it, as far as input and room reach
 				uint32_t run = (uint32_t)__builtin_clz(flags) + 1u;
 				if (op == cap) { status = -5; done = true; break; }      // :455
-				if ((u64)run > endq - ip) { run = (uint32_t)(endq - ip); }
+				if (run > endq - ip) { run = endq - ip; }
 				if ((u64)run > cap - op) { run = (uint32_t)(cap - op); }
-				const u64 r = op + d0;
-				if (lane < run) { S.out[(uint32_t)(r + lane) & 16383u] = (uint8_t)rb(ip + lane); }
-				op += run; ip += run;
-				if (r + run >= flushed + 8192u) { __syncthreads(); XPD_FLUSH_HALF() }
+				if (lane < run) { S.out[wrap(wi + lane)] = (uint8_t)rb(ip + lane); }
+				op += run; ip += run; wi = wrap(wi + run);
+				XPD_FETCH8(ip, lo, hi)
+				if (op >= nextflush) { __syncthreads(); XPD_FLUSH() nextflush += XPD_PIECE; }
 				flagged = (uint32_t)(((u64)flags << (run - 1u)) >> 31) & 1u;
 				flags = (uint32_t)((u64)flags << run);
 			}
@@ -668,13 +683,14 @@ __global__ __launch_bounds__(64) void xpd_kernel(const uint8_t* __restrict__ d_i
 	}
 	#undef XPD_FETCH
 	#undef XPD_STORE
+	#undef XPD_FETCH8
 	// the rest of the ring
 	__syncthreads();
 	if (status == 0) {
 		const u64 rend = op + d0;
-		for (u64 r = flushed + lane; r < rend; r += 64u) { if (r >= d0) { db[r] = S.out[(uint32_t)r & 16383u]; } }
+		for (u64 r = flushed + lane; r < rend; r += 64u) { if (r >= d0) { db[r] = S.out[wrap(fi + (uint32_t)(r - flushed))]; } }
 	}
-	#undef XPD_FLUSH_HALF
+	#undef XPD_FLUSH
 	if (lane == 0) { d_status[u] = status; d_out_len[u] = status == 0 ? op : 0; }
 }
 
