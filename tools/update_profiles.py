@@ -21,9 +21,13 @@ for k, v in out.items():
     v["hbm_bytes_per_launch_corrected"] = int(v.get("FETCH_SIZE_KB_per_launch", 0) * 1024 * 2 + v.get("WRITE_SIZE_KB_per_launch", 0) * 1024)
 doc = {"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --steps 3 --warmup 1 --no-cpu ; "
               "counters are KB; FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE uncalibrated",
-       "workloads": "lznt1: mozilla 51220480 B; xpress: 3239 x 64 KiB units (211938580 B); xpress_huff: 12 files (211938580 B)", "kernels": out}
+       "workloads": "lznt1: mozilla 51220480 B; xpress: 3239 x 64 KiB units (211938580 B); xpress_huff: 12 files (211938580 B); decompression (lzd_* / xpd / xhd kernels): what the compressor wrote for mozilla (lznt1) and for the 3239 units (xpress, xpress_huff)", "kernels": out}
 json.dump(doc, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
 r = json.load(open("profiles/%s_bench.json" % tag))
 print(r["value"], r["roofline"]["frac"], r["roofline"]["traffic"], r["cpu_baseline"]["value"])
 for k, v in r["extra"].items():
-    print(k, v["MB_per_s"], v["roofline"]["frac"], v["roofline"]["kernels_ms_per_step"])
+    if k == "decompress":
+        for c, d in v.items():
+            print("decompress", c, d["MB_per_s"], d["round_trip_ok"], d["kernels_ms_per_step"])
+    else:
+        print(k, v["MB_per_s"], v["roofline"]["frac"], v["roofline"]["kernels_ms_per_step"])
