@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void xh_parse_kernel(const uint8_t* __restrict
 // Huffman lengths (heap), size, canonical codes
 // ===================================================================================================================
 struct HuffLds {
-	__attribute__((aligned(16))) u64 heap[516];   // entry = (weight << 16) | node ; weight = (count<<8)|depth ; heap[0] = 0 sentinel
+	__attribute__((aligned(16))) uint2 heap[516]; // entry = {weight, node}; weight = (count<<8)|depth; heap[0] = {0,0}; every entry behind the last one is {0xFFFFFFFF,0}
 	uint32_t wleaf[512];   // leaf weights (kept for the >15-bit rescale loop)
 	uint16_t parent[1024];
 	uint32_t cnt[512];
@@ -293,31 +293,33 @@ struct HuffLds {
 
 // HEAP_PUSH / HEAP_POP (HuffmanEncoder.h:31-55), executed by ONE lane. Keys are compared on the weight only, exactly
 // like the reference (`weights[x] < weights[heap[j>>1]]`); carrying the weight inside the heap entry makes every sift
-// level a single LDS read (the two children of a node are one aligned 16-byte read).
-__device__ __forceinline__ void hh_push(HuffLds& h, uint32_t& hl, u64 e)
+// level a single LDS read (the two children of a node are one aligned 16-byte read). Entries behind the last one hold the
+// largest weight, so "no child" / "no right child" need no index test: such a child never wins and always stops the sift
+// (the child index is clamped to the pair 514/515, which is never occupied).
+#define HH_SENT 0xFFFFFFFFu
+__device__ __forceinline__ void hh_push(HuffLds& h, uint32_t& hl, uint2 e)
 {
 	uint32_t j = ++hl;
-	const uint32_t we = (uint32_t)(e >> 16);
 	for (;;) {
-		const u64 par = h.heap[j >> 1];
-		if (!(we < (uint32_t)(par >> 16))) { break; }
+		const uint2 par = h.heap[j >> 1];
+		if (!(e.x < par.x)) { break; }
 		h.heap[j] = par; j >>= 1;
 	}
 	h.heap[j] = e;
 }
-__device__ __forceinline__ u64 hh_pop(HuffLds& h, uint32_t& hl)
+__device__ __forceinline__ uint2 hh_pop(HuffLds& h, uint32_t& hl)
 {
-	const u64 top = h.heap[1], t = h.heap[hl--];
-	const uint32_t wt = (uint32_t)(t >> 16);
+	const uint2 top = h.heap[1], t = h.heap[hl];
+	h.heap[hl] = make_uint2(HH_SENT, 0); --hl;
 	uint32_t i = 1;
 	for (;;) {
 		uint32_t j = i << 1;
-		if (j > hl) { break; }
-		const ulonglong2 ch = *reinterpret_cast<const ulonglong2*>(&h.heap[j]);   // children j and j+1 (j is even: 16 B aligned)
-		u64 c = ch.x;
-		if (j < hl && (uint32_t)(ch.y >> 16) < (uint32_t)(c >> 16)) { ++j; c = ch.y; }
-		if (wt < (uint32_t)(c >> 16)) { break; }
-		h.heap[i] = c; i = j;
+		j = j < 514u ? j : 514u;
+		const uint4 ch = *reinterpret_cast<const uint4*>(&h.heap[j]);    // children j and j+1 (j is even: 16 B aligned)
+		const bool right = ch.z < ch.x;
+		const uint32_t cw = right ? ch.z : ch.x, cn = right ? ch.w : ch.y;
+		if (t.x < cw) { break; }
+		h.heap[i] = make_uint2(cw, cn); i = j + (right ? 1u : 0u);
 	}
 	h.heap[i] = t;
 	return top;
@@ -330,18 +332,19 @@ __device__ void huff_lengths_fast(HuffLds& h, uint32_t lane)
 	__syncthreads();
 	for (;;) {
 		for (uint32_t i = lane; i < 1024u; i += 64u) { h.parent[i] = 0; }
+		for (uint32_t i = lane; i < 516u; i += 64u) { h.heap[i] = i ? make_uint2(HH_SENT, 0) : make_uint2(0, 0); }
 		__syncthreads();
 		if (lane == 0) {
-			uint32_t hl = 0; h.heap[0] = 0;
-			for (uint32_t i = 1; i <= 512u; ++i) { hh_push(h, hl, ((u64)h.wleaf[i - 1u] << 16) | i); }
+			uint32_t hl = 0;
+			for (uint32_t i = 1; i <= 512u; ++i) { hh_push(h, hl, make_uint2(h.wleaf[i - 1u], i)); }
 			uint32_t nn = 512;
 			while (hl > 1) {
-				const u64 ea = hh_pop(h, hl), eb = hh_pop(h, hl);
-				const uint32_t wa = (uint32_t)(ea >> 16), wb = (uint32_t)(eb >> 16);
+				const uint2 ea = hh_pop(h, hl), eb = hh_pop(h, hl);
+				const uint32_t wa = ea.x, wb = eb.x;
 				const uint32_t da = wa & 0xFFu, db = wb & 0xFFu;
-				++nn; h.parent[ea & 0xFFFFu] = (uint16_t)nn; h.parent[eb & 0xFFFFu] = (uint16_t)nn;
+				++nn; h.parent[ea.y] = (uint16_t)nn; h.parent[eb.y] = (uint16_t)nn;
 				const uint32_t wn = ((wa & ~0xFFu) + (wb & ~0xFFu)) | (1u + (da > db ? da : db));
-				hh_push(h, hl, ((u64)wn << 16) | nn);
+				hh_push(h, hl, make_uint2(wn, nn));
 			}
 		}
 		__syncthreads();
