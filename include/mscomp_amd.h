@@ -64,6 +64,34 @@ MSCompStatus lznt1_decompress(const uint8_t* in, size_t in_len, uint8_t* out, si
 MSCompStatus xpress_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
 MSCompStatus xpress_huff_decompress(const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len);
 
+/* Streaming compression: the reference's stream object and its LZNT1 streaming compressor -- the only format
+ * whose ms_deflate works in the reference. Layout of mscomp_stream = include/mscomp/general.h:95-121 in the default build
+ * (MSCOMP_WITH_ERROR_MESSAGES and MSCOMP_WITH_WARNING_MESSAGES, include/mscomp/config.h:54-63). Same call protocol and statuses
+ * (include/mscomp.h:102-158); the bytes are those of the reference for every way of slicing the input and the output windows.
+ *   ms_deflate_init / ms_deflate / ms_deflate_end          include/mscomp.h:114,143,158, src/mscomp.cpp:136-165 (MSCOMP_NONE, MSCOMP_LZNT1)
+ *   lznt1_deflate_init / lznt1_deflate / lznt1_deflate_end include/lznt1.h:55-57,       src/lznt1_compress.cpp:132-231 */
+typedef enum _MSCompFlush { MSCOMP_NO_FLUSH = 0, MSCOMP_FLUSH = 2, MSCOMP_FINISH = 4 } MSCompFlush;
+typedef struct _mscomp_internal_state mscomp_internal_state;
+typedef struct _mscomp_stream {
+	MSCompFormat format;
+#ifdef __cplusplus
+	bool compressing;
+#else
+	int compressing;
+#endif
+	const uint8_t* in;  size_t in_avail,  in_total;
+	uint8_t*       out; size_t out_avail, out_total;
+	char error[256];
+	char warning[256];
+	mscomp_internal_state* state;
+} mscomp_stream;
+MSCompStatus ms_deflate_init(MSCompFormat format, mscomp_stream* stream);
+MSCompStatus ms_deflate(mscomp_stream* stream, MSCompFlush flush);
+MSCompStatus ms_deflate_end(mscomp_stream* stream);
+MSCompStatus lznt1_deflate_init(mscomp_stream* stream);
+MSCompStatus lznt1_deflate(mscomp_stream* stream, MSCompFlush flush);
+MSCompStatus lznt1_deflate_end(mscomp_stream* stream);
+
 /* ================= Part 2: batch interface (device pointers) ================= */
 typedef struct mscomp_amd_ctx  mscomp_amd_ctx;    /* one per (device, stream); owns scratch in HBM  */
 typedef struct mscomp_amd_plan mscomp_amd_plan;   /* unit layout of one batch, uploaded once        */

@@ -1,0 +1,194 @@
+// stream.hip -- the reference's streaming compression entry points for LZNT1, host side.
+//
+// ms_deflate_init / ms_deflate / ms_deflate_end (/root/reference/src/mscomp.cpp:136-165) and lznt1_deflate_init / lznt1_deflate /
+// lznt1_deflate_end (/root/reference/src/lznt1_compress.cpp:132-231, chunk writer :95-131, stream macros
+// /root/reference/include/mscomp/internal.h:473-533). LZNT1 is the only format whose streaming compressor works in the reference
+// (Xpress: xpress_compress.cpp:52-73,219-221 return errors; Xpress+Huffman: none, mscomp.cpp:141).
+//
+// The stream object is a host-side state machine over independent 4 KiB chunks: what is buffered when, when a short chunk is cut
+// (MSCOMP_FLUSH / MSCOMP_FINISH), how a chunk that does not fit the caller's output window is handed out piecewise. That logic is
+// restated here; every chunk image (header + payload) is produced by the HIP compressor: all full chunks that are certain to fit the
+// output window go to the GPU as ONE batch (a unit of k x 4096 bytes is exactly the concatenation of its k chunk images).
+#include "../../include/mscomp_amd.h"
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+namespace {
+
+const size_t CHUNK = 4096;
+
+struct DeflateState {                       // what lznt1_compress.cpp:32-40 keeps: one partial input chunk, one pending output chunk
+	bool finished = false;
+	uint8_t in[CHUNK];
+	size_t in_needed = 0, in_avail = 0;
+	uint8_t out[CHUNK + 2];
+	size_t out_pos = 0, out_avail = 0;
+	uint8_t* scratch = nullptr; size_t scratch_cap = 0;      // host staging of a batch's output
+};
+
+bool stream_ok(const mscomp_stream* s, MSCompFormat f)     // CHECK_STREAM (internal.h:481)
+{
+	return s && s->format == f && s->compressing && !(s->in == nullptr && s->in_avail != 0) && !(s->out == nullptr && s->out_avail != 0);
+}
+void take_in(mscomp_stream* s, size_t n)  { s->in += n;  s->in_total += n;  s->in_avail -= n; }
+void give_out(mscomp_stream* s, size_t n) { s->out += n; s->out_total += n; s->out_avail -= n; }
+
+// k full chunks (or one short chunk) -> their images, back to back, compressed on the GPU
+MSCompStatus gpu_images(DeflateState* st, const uint8_t* in, size_t n, uint8_t** img, size_t* img_len)
+{
+	const size_t cap = lznt1_max_compressed_size(n);
+	if (st->scratch_cap < cap) {
+		free(st->scratch);
+		st->scratch = static_cast<uint8_t*>(malloc(cap + 64)); st->scratch_cap = st->scratch ? cap : 0;
+		if (!st->scratch) { return MSCOMP_MEM_ERROR; }
+	}
+	size_t len = cap;
+	const MSCompStatus r = lznt1_compress(in, n, st->scratch, &len);
+	if (r != MSCOMP_OK) { return r; }
+	*img = st->scratch; *img_len = len;
+	return MSCOMP_OK;
+}
+
+// lznt1_compress_chunk_write (:95-131): one chunk of n <= 4096 bytes; goes to the caller's window when header + n bytes are sure to
+// fit, else through the state's buffer
+MSCompStatus write_chunk(mscomp_stream* s, DeflateState* st, const uint8_t* in, size_t n)
+{
+	uint8_t* img; size_t len;
+	const MSCompStatus r = gpu_images(st, in, n, &img, &len);
+	if (r != MSCOMP_OK) { return r; }
+	if (s->out_avail >= n + 2) { memcpy(s->out, img, len); give_out(s, len); return MSCOMP_OK; }
+	memcpy(st->out, img, len);
+	const size_t copy = len < s->out_avail ? len : s->out_avail;
+	memcpy(s->out, st->out, copy);
+	give_out(s, copy);
+	st->out_pos = copy; st->out_avail = len - copy;
+	return MSCOMP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+MSCompStatus lznt1_deflate_init(mscomp_stream* s)
+{
+	if (!s) { return MSCOMP_ARG_ERROR; }                     // INIT_STREAM (internal.h:473-480)
+	s->format = MSCOMP_LZNT1; s->compressing = true;
+	s->in = nullptr; s->out = nullptr; s->in_avail = 0; s->out_avail = 0; s->in_total = 0; s->out_total = 0;
+	s->error[0] = 0; s->warning[0] = 0; s->state = nullptr;
+	DeflateState* st = new (std::nothrow) DeflateState();
+	if (!st) { return MSCOMP_MEM_ERROR; }
+	s->state = reinterpret_cast<mscomp_internal_state*>(st);
+	return MSCOMP_OK;
+}
+
+MSCompStatus lznt1_deflate(mscomp_stream* s, MSCompFlush flush)
+{
+	DeflateState* st = s ? reinterpret_cast<DeflateState*>(s->state) : nullptr;
+	if (!stream_ok(s, MSCOMP_LZNT1) || !st || st->finished) { return MSCOMP_ARG_ERROR; }     // :149
+	MSCompStatus r;
+	// output of an earlier call that did not fit then (DUMP_OUT, internal.h:493-513)
+	if (st->out_avail) {
+		const size_t k = st->out_avail < s->out_avail ? st->out_avail : s->out_avail;
+		memcpy(s->out, st->out + st->out_pos, k);
+		s->out += k; s->out_total += k;
+		if (st->out_avail == k) { s->out_avail -= k; st->out_avail = 0; }
+		else { s->out_avail = 0; st->out_pos += k; st->out_avail -= k; return MSCOMP_OK; }
+	}
+	// a partial chunk kept from an earlier call (APPEND_IN, internal.h:517-533, with the body of :152-170)
+	if (st->in_avail) {
+		const size_t k = st->in_needed < s->in_avail ? st->in_needed : s->in_avail;
+		if (k) { memcpy(st->in + st->in_avail, s->in, k); st->in_avail += k; st->in_needed -= k; take_in(s, k); }
+		if (st->in_needed) {
+			if (flush != MSCOMP_NO_FLUSH) {                  // cut a short chunk here
+				if ((r = write_chunk(s, st, st->in, st->in_avail)) != MSCOMP_OK) { return r; }
+				st->in_avail = 0; st->in_needed = 0;
+				if (flush == MSCOMP_FINISH && !st->out_avail) { goto stream_end; }
+			}
+			return MSCOMP_OK;                                // still not a whole chunk
+		}
+		if ((r = write_chunk(s, st, st->in, CHUNK)) != MSCOMP_OK) { return r; }
+		st->in_avail = 0;
+	}
+	// whole chunks while there is room (:173-177). As many as are CERTAIN to land in the window unbuffered (4098 bytes each at most)
+	// are one GPU batch; the reference would have written the same bytes chunk by chunk.
+	while (s->out_avail && s->in_avail >= CHUNK) {
+		size_t k = s->in_avail / CHUNK;
+		const size_t sure = s->out_avail / (CHUNK + 2);
+		if (sure < k) { k = sure; }
+		if (k == 0) {
+			if ((r = write_chunk(s, st, s->in, CHUNK)) != MSCOMP_OK) { return r; }
+			take_in(s, CHUNK);
+			continue;
+		}
+		uint8_t* img; size_t len;
+		if ((r = gpu_images(st, s->in, k * CHUNK, &img, &len)) != MSCOMP_OK) { return r; }
+		memcpy(s->out, img, len); give_out(s, len); take_in(s, k * CHUNK);
+	}
+	// the rest: less than a chunk of input, or no room (:180-195)
+	if (s->out_avail && s->in_avail) {
+		if (flush != MSCOMP_NO_FLUSH) {
+			if ((r = write_chunk(s, st, s->in, s->in_avail)) != MSCOMP_OK) { return r; }
+		} else {
+			memcpy(st->in, s->in, s->in_avail);
+			st->in_avail = s->in_avail; st->in_needed = CHUNK - st->in_avail;
+		}
+		take_in(s, s->in_avail);
+	}
+	if (flush == MSCOMP_FINISH && !s->in_avail && !st->in_avail && !st->out_avail) {
+stream_end:
+		st->finished = true;
+		if (s->out_avail >= 2) { s->out[0] = 0; s->out[1] = 0; }     // End_of_buffer, not counted (:202-204)
+		return MSCOMP_STREAM_END;
+	}
+	return MSCOMP_OK;
+}
+
+MSCompStatus lznt1_deflate_end(mscomp_stream* s)
+{
+	DeflateState* st = s ? reinterpret_cast<DeflateState*>(s->state) : nullptr;
+	if (!stream_ok(s, MSCOMP_LZNT1) || !st) { return MSCOMP_ARG_ERROR; }                     // :211
+	const MSCompStatus r = (!st->finished || s->in_avail || st->in_avail || st->out_avail) ? MSCOMP_DATA_ERROR : MSCOMP_OK;   // :216
+	free(st->scratch);
+	delete st;
+	s->state = nullptr;
+	return r;
+}
+
+#ifndef MSCOMP_AMD_NO_FACADE
+// mscomp.cpp:136-165 with its "copy" codec (:33-47,:60) for MSCOMP_NONE
+MSCompStatus ms_deflate_init(MSCompFormat format, mscomp_stream* s)
+{
+	if (format == MSCOMP_LZNT1) { return lznt1_deflate_init(s); }
+	if (format == MSCOMP_NONE) {
+		if (!s) { return MSCOMP_ARG_ERROR; }
+		s->format = MSCOMP_NONE; s->compressing = true;
+		s->in = nullptr; s->out = nullptr; s->in_avail = 0; s->out_avail = 0; s->in_total = 0; s->out_total = 0;
+		s->error[0] = 0; s->warning[0] = 0; s->state = nullptr;
+		return MSCOMP_OK;
+	}
+	return MSCOMP_ARG_ERROR;                                  // Xpress: the reference's streaming compressor only returns errors; Xpress+Huffman: none
+}
+MSCompStatus ms_deflate(mscomp_stream* s, MSCompFlush flush)
+{
+	if (!s) { return MSCOMP_ARG_ERROR; }
+	if (s->format == MSCOMP_LZNT1) { return lznt1_deflate(s, flush); }
+	if (s->format == MSCOMP_NONE) {
+		if (!stream_ok(s, MSCOMP_NONE)) { return MSCOMP_ARG_ERROR; }
+		const size_t n = s->in_avail < s->out_avail ? s->in_avail : s->out_avail;
+		if (n) { memcpy(s->out, s->in, n); }
+		give_out(s, n); take_in(s, n);
+		return (flush == MSCOMP_FINISH && !s->in_avail) ? MSCOMP_STREAM_END : MSCOMP_OK;
+	}
+	return MSCOMP_ARG_ERROR;
+}
+MSCompStatus ms_deflate_end(mscomp_stream* s)
+{
+	if (!s) { return MSCOMP_ARG_ERROR; }
+	if (s->format == MSCOMP_LZNT1) { return lznt1_deflate_end(s); }
+	if (s->format == MSCOMP_NONE) { return stream_ok(s, MSCOMP_NONE) ? MSCOMP_OK : MSCOMP_ARG_ERROR; }
+	return MSCOMP_ARG_ERROR;
+}
+#endif
+
+} // extern "C"

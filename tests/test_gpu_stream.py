@@ -1,0 +1,103 @@
+"""GPU: the LZNT1 streaming compressor (ms_deflate_init / ms_deflate / ms_deflate_end) against the compiled
+reference's streaming compressor, call by call: same status, same bytes consumed and produced by every call, same output, for
+random ways of slicing the input and the output windows and random MSCOMP_FLUSH points."""
+import ctypes as C
+import random
+
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+NO_FLUSH, FLUSH, FINISH = 0, 2, 4
+
+
+class Stream(C.Structure):                      # include/mscomp/general.h:95-121 (default build: error + warning texts)
+    _fields_ = [("format", C.c_int), ("compressing", C.c_bool), ("in_", C.c_void_p), ("in_avail", C.c_size_t), ("in_total", C.c_size_t),
+                ("out", C.c_void_p), ("out_avail", C.c_size_t), ("out_total", C.c_size_t), ("error", C.c_char * 256),
+                ("warning", C.c_char * 256), ("state", C.c_void_p)]
+
+
+def drive(lib, fmt, data, steps, tail_window):
+    """steps: (bytes offered, output window, flush). Afterwards MSCOMP_FINISH with `tail_window` until MSCOMP_STREAM_END."""
+    for f in (lib.ms_deflate_init, lib.ms_deflate, lib.ms_deflate_end):
+        f.restype = C.c_int
+    lib.ms_deflate_init.argtypes = [C.c_int, C.POINTER(Stream)]
+    lib.ms_deflate.argtypes = [C.POINTER(Stream), C.c_int]
+    lib.ms_deflate_end.argtypes = [C.POINTER(Stream)]
+    s = Stream()
+    assert lib.ms_deflate_init(fmt, C.byref(s)) == 0
+    inbuf = C.create_string_buffer(bytes(data), max(1, len(data)))
+    outbuf = C.create_string_buffer(len(data) + len(data) // 1000 + 70000)
+    ipos = opos = 0
+    trace = []
+
+    def call(offer, window, flush):
+        nonlocal ipos, opos
+        offer = min(offer, len(data) - ipos)
+        s.in_ = C.addressof(inbuf) + ipos; s.in_avail = offer
+        s.out = C.addressof(outbuf) + opos; s.out_avail = window
+        st = lib.ms_deflate(C.byref(s), flush)
+        took, gave = offer - s.in_avail, window - s.out_avail
+        ipos += took; opos += gave
+        trace.append((st, took, gave, s.in_total, s.out_total))
+        return st
+
+    for offer, window, flush in steps:
+        if call(offer, window, flush) < 0:
+            break
+    for _ in range(100000):
+        if call(len(data) - ipos, tail_window, FINISH) != 0:
+            break
+    end = lib.ms_deflate_end(C.byref(s))
+    return outbuf.raw[:opos], trace, end
+
+
+def plans(rnd, n):
+    yield [], 1 << 30                                              # everything in one MSCOMP_FINISH call
+    yield [(n, 1 << 30, NO_FLUSH)], 1 << 30
+    yield [(4096, 5000, NO_FLUSH)] * (n // 4096 + 2), 4098
+    yield [(1000, 700, NO_FLUSH)] * (n // 1000 + 2), 100            # output windows smaller than a chunk
+    for _ in range(6):
+        steps = []
+        for _ in range(rnd.randint(1, 60)):
+            steps.append((rnd.choice((1, 17, 4095, 4096, 4097, 10000, 50000, rnd.randint(1, 70000))),
+                          rnd.choice((0, 1, 2, 100, 4097, 4098, 4099, 9000, 1 << 20)), rnd.choice((NO_FLUSH, NO_FLUSH, NO_FLUSH, FLUSH))))
+        yield steps, rnd.choice((1, 3, 4098, 1 << 20))
+
+
+def test_lznt1_deflate_matches_reference_call_by_call(oracle, gpu_ctx):
+    import ms_compress_amd as m
+    ref = oracle.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    mine = m.load_library()
+    rnd = random.Random(9)
+    datas = [b"", b"x", cases.family("words", 4096, rnd), cases.family("lz", 12289, rnd), cases.family("random", 9000, rnd),
+             cases.mixed_buffer()[95000:95000 + 180000]]
+    n_cmp = 0
+    for data in datas:
+        for steps, tail in plans(rnd, len(data)):
+            want = drive(ref, 2, data, steps, tail)
+            got = drive(mine, 2, data, steps, tail)
+            assert got[1] == want[1], (len(data), steps[:4], tail)
+            assert got[0] == want[0] and got[2] == want[2]
+            n_cmp += 1
+    assert n_cmp >= 50
+    # without MSCOMP_FLUSH the stream is the one-shot output
+    data = datas[-1]
+    out, _, end = drive(mine, 2, data, [(7000, 3000, NO_FLUSH)] * 40, 5000)
+    assert end == 0 and out == oracle.oracle_compress(2, data)[1]
+
+
+def test_copy_codec_and_argument_errors(gpu_ctx):
+    import ms_compress_amd as m
+    mine = m.load_library()
+    out, trace, end = drive(mine, 0, b"hello world" * 10, [(50, 20, NO_FLUSH)] * 3, 1000)
+    assert out == b"hello world" * 10 and trace[-1][0] == 1 and end == 0
+    s = Stream()
+    mine.ms_deflate_init.argtypes = [C.c_int, C.POINTER(Stream)]
+    assert mine.ms_deflate_init(3, C.byref(s)) == -2 and mine.ms_deflate_init(4, C.byref(s)) == -2 and mine.ms_deflate_init(9, C.byref(s)) == -2
+    assert mine.ms_deflate_init(2, C.byref(s)) == 0
+    assert mine.ms_deflate_end(C.byref(s)) == -3                     # ended before MSCOMP_FINISH was answered with MSCOMP_STREAM_END
+    assert mine.ms_deflate(C.byref(s), NO_FLUSH) == -2               # no state any more
