@@ -51,6 +51,10 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    try:                      # PyTorch bundles its own libamdhip64; this library links /opt/rocm's. Both live in one process, and the
+        import torch  # noqa: F401   device is only visible to both when torch's runtime was loaded first (seen on the MI355X box).
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     one_shot = [C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
     lib.ms_compress.argtypes = [C.c_int] + one_shot

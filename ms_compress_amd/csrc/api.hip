@@ -102,7 +102,7 @@ uint32_t chunks_of(MSCompFormat f, bool decompress, uint64_t n)
 
 extern "C" {
 
-const char* mscomp_amd_version(void) { return "mscomp_amd 0.1 (gfx950, HIP; LZNT1/Xpress/Xpress+Huffman one-shot compressors)"; }
+const char* mscomp_amd_version(void) { return "mscomp_amd 0.2 (gfx950, HIP; LZNT1 / Xpress / Xpress+Huffman compressors and decompressors, LZNT1 streaming compressor)"; }
 
 size_t lznt1_max_compressed_size(size_t n)       { return n + 3 + 2 * ((n + 4095) / 4096); }
 size_t xpress_max_compressed_size(size_t n)      { return n + 4 + 4 * (n / 32); }
