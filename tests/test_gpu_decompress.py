@@ -110,3 +110,34 @@ def test_lznt1_header_walk_falls_back_when_speculation_cannot_decide(oracle, gpu
     comp, _ = m.compress_units(2, [cases.mixed_buffer()], ctx=gpu_ctx)
     m.decompress_units(2, comp, [len(cases.mixed_buffer())], ctx=gpu_ctx)
     assert gpu_ctx.lib.mscomp_amd_debug_lzd_walked(gpu_ctx._h) == 0
+
+
+@pytest.mark.parametrize("fmt", ["xpress", "xpress_huff"])
+def test_round_trip_full_size_units(oracle, gpu_ctx, fmt):
+    """BASELINE configs[2]/[3] sizes: the 212 MB corpus as 3 239 units of 64 KiB, GPU compress -> GPU decompress gives the
+    input back (one wave per stream decodes; every status MSCOMP_OK, every length right)."""
+    import torch
+    import ms_compress_amd as m
+    from ms_compress_amd import corpus
+    f = FMTS[fmt]
+    files = [corpus.file_bytes(i) for i in range(12)]
+    blob = np.concatenate(files)
+    offs, lens = [], []
+    pos = 0
+    for fl in files:
+        s = np.arange(0, len(fl), 65536, dtype=np.uint64)
+        offs.append(s + np.uint64(pos)); lens.append(np.minimum(65536, len(fl) - s).astype(np.uint64)); pos += len(fl)
+    in_off, in_len = np.concatenate(offs), np.concatenate(lens)
+    caps = [m.max_compressed_size(f, int(x)) + 2 for x in in_len]
+    c_off, c_total = m.pack_offsets(caps)
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(blob).to(dev); d_c = torch.zeros(c_total + 16, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(len(in_len), dtype=torch.int64, device=dev); d_st = torch.zeros(len(in_len), dtype=torch.int32, device=dev)
+    p = m.Plan(gpu_ctx, f, in_off, in_len, c_off, caps); p.execute(d_in, d_c, d_len, d_st); torch.cuda.synchronize(); p.close()
+    assert bool((d_st == 0).all())
+    clen = d_len.cpu().numpy().astype(np.uint64)
+    d_back = torch.zeros(len(blob) + 16, dtype=torch.uint8, device=dev)
+    d_len2 = torch.zeros_like(d_len); d_st2 = torch.full_like(d_st, -9)
+    q = m.Plan(gpu_ctx, f, c_off, clen, in_off, in_len, decompress=True); q.execute(d_c, d_back, d_len2, d_st2); torch.cuda.synchronize(); q.close()
+    assert bool((d_st2 == 0).all()) and torch.equal(d_len2.cpu(), torch.from_numpy(in_len.astype(np.int64)))
+    assert torch.equal(d_back[: len(blob)], d_in)
