@@ -46,6 +46,7 @@ struct mscomp_amd_ctx {
 	DevBuf wrec, sbrec;                                // ... state / counts / prefixes per window (6 x u32), per super-block (tot 4 x u32, pre 3 x u64, seams)
 	DevBuf tokbits, counts, extra, lens, codes, fb_list, fbflag;   // Xpress+Huffman per-chunk scratch
 	DevBuf dz_cin, dz_csize, dz_unit;                  // LZNT1 decompression: header offset / decoded size per chunk slot, per-unit records
+	DevBuf dz_tok, dz_ntok;                            // Xpress+Huffman decompression: 32-bit tokens of every unit, token counts
 	DevBuf one_in, one_out, one_meta;                  // staging of the host-pointer one-shot path
 	bool profiling = false;
 	std::vector<ProfRec> recs;
@@ -59,6 +60,7 @@ struct mscomp_amd_plan {
 	uint32_t n_units = 0, n_chunks = 0;
 	uint64_t total_in = 0;
 	DevBuf tables;                                     // in_off | out_off | chunk_prefix
+	DevBuf tokpre;                                     // decompression by tokens: first token slot of every unit (u64, n_units + 1)
 	BatchTables bt{};
 	// the launch sequence of plan_execute as a hipGraph: captured on the plan's second execution, replayed while the
 	// arguments and the scratch buffers stay where they were
@@ -146,7 +148,7 @@ void mscomp_amd_ctx_destroy(mscomp_amd_ctx* c)
 	c->wtok.release(); c->wmat.release(); c->wfar.release(); c->wrec.release(); c->sbrec.release();
 	c->tokbits.release(); c->counts.release(); c->extra.release(); c->lens.release(); c->codes.release();
 	c->fb_list.release(); c->fbflag.release();
-	c->dz_cin.release(); c->dz_csize.release(); c->dz_unit.release();
+	c->dz_cin.release(); c->dz_csize.release(); c->dz_unit.release(); c->dz_tok.release(); c->dz_ntok.release();
 	delete c;
 }
 
@@ -215,7 +217,21 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 			okd = c->dz_cin.reserve((size_t)p->n_chunks * LZD_SLOTS * 4 + 64) && c->dz_csize.reserve((size_t)p->n_chunks * LZD_SLOTS * 2 + 64) &&
 			      c->dz_unit.reserve(((size_t)p->n_chunks * (5 * LZD_K + 2) + (size_t)n_units * 2 + 8) * 4);
 		}
-		if (!okd) { p->tables.release(); delete p; return MSCOMP_MEM_ERROR; }
+		if (okd && format == MSCOMP_XPRESS_HUFF) {
+			// a symbol gives one token, a match one more per 32766 bytes; no token without an output byte
+			std::vector<uint64_t> tp(n_units + 1);
+			uint64_t slots = 0;
+			for (size_t i = 0; i < n_units; ++i) {
+				tp[i] = slots;
+				const uint64_t by_in = 8 * in_len[i] + out_cap[i] / 32766u + 1, cnt = out_cap[i] < by_in ? out_cap[i] : by_in;
+				slots += cnt + 64;
+			}
+			tp[n_units] = slots;
+			okd = p->tokpre.reserve(tp.size() * 8) && c->dz_tok.reserve(slots * 4 + 256) && c->dz_ntok.reserve((n_units + 1) * 8);
+			if (okd && (hipMemcpyAsync(p->tokpre.p, tp.data(), tp.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+			            hipStreamSynchronize(c->stream) != hipSuccess)) { p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_ERRNO; }
+		}
+		if (!okd) { p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_MEM_ERROR; }
 		*out = p;
 		return MSCOMP_OK;
 	}
@@ -262,7 +278,7 @@ void mscomp_amd_plan_destroy(mscomp_amd_plan* p)
 	DeviceGuard g(p->ctx->device);
 	(void)hipStreamSynchronize(p->ctx->stream);
 	if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); }
-	p->tables.release();
+	p->tables.release(); p->tokpre.release();
 	delete p;
 }
 
@@ -314,7 +330,9 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 			return MSCOMP_OK;
 		}
 		case MSCOMP_XPRESS_HUFF: {
-			KernelTimer t(c, "xhd_kernel"); launch_xpress_huff_decompress(st, d_in, p->bt, d_out, d_out_len, d_status);
+			const u64* tp = static_cast<const u64*>(p->tokpre.p); uint32_t* tok = static_cast<uint32_t*>(c->dz_tok.p); u64* ntok = static_cast<u64*>(c->dz_ntok.p);
+			{ KernelTimer t(c, "xhd_parse_kernel"); launch_xpress_huff_decompress(st, d_in, p->bt, tp, tok, ntok, d_out, d_out_len, d_status, 0); }
+			{ KernelTimer t(c, "lz_copy_kernel"); launch_xpress_huff_decompress(st, d_in, p->bt, tp, tok, ntok, d_out, d_out_len, d_status, 1); }
 			return MSCOMP_OK;
 		}
 		default:

@@ -705,29 +705,38 @@ void launch_xpress_decompress(hipStream_t st, const uint8_t* d_in, const BatchTa
 // ===================================================================================================================
 // xpress_huff_decompress (/root/reference/src/xpress_huff_decompress.cpp:130-162, chunk loop :39-129; InputBitstream Bitstream.h:34-106;
 // HuffmanDecoder<15,512> HuffmanDecoder.h:28-114). Where a chunk's 256-byte table starts is only known when the chunk before it
-// has been decoded (no sizes are stored), and inside a chunk every symbol starts where the previous one ends, so a buffer is
-// decoded by one wave, buffers in parallel. The wave builds the decoding tables of a chunk together (counts and canonical ranks
-// by ballots), then all lanes walk the symbols; codes of up to 9 bits resolve with one LDS read (symbol << 4 | length). Matches
-// reach 65535 bytes back: the output ring holds 9 x 8 KiB and goes to HBM in 8 KiB pieces.
+// has been decoded (no sizes are stored), and inside a chunk every symbol starts where the previous one ends, so the SYMBOLS of
+// a buffer are walked by one wave, buffers in parallel (xhd_parse_kernel). The wave builds the decoding tables of a chunk
+// together (counts and canonical ranks by ballots), then all lanes walk the symbols; codes of up to 9 bits resolve with one LDS
+// read (symbol << 4 | length). The walk needs the output only as a running length, so it writes 32-bit tokens (a literal, or
+// offset | length << 16; a match longer than 32766 is cut into matches with the same offset, which copy the same bytes) and
+// keeps 7 KiB of LDS: 23 buffers per CU instead of the 2 that a 64 KiB output window allows. The bytes are produced afterwards
+// by lz_copy_kernel, in parallel.
 #define XHD_INB  2048u
-#define XHD_RING 73728u
+#define LZT_MAXLEN 32766u
 struct XhdLds {
 	__attribute__((aligned(16))) uint8_t in[2u * XHD_INB];
-	__attribute__((aligned(16))) uint8_t out[XHD_RING];
+	uint32_t stage[64];                 // tokens on their way to HBM
 	uint16_t fast[512];                 // 9-bit prefix -> symbol << 4 | length (0: longer code)
 	uint16_t syms[512];                 // symbols in canonical order
 	uint32_t lims[16], poss[16];
 };
 
-__global__ __launch_bounds__(64) void xhd_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, uint8_t* __restrict__ d_out,
-                                                u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
+// tokens of unit u: tok[tok_prefix[u] ...], ntok[u]; d_out_len / d_status as the caller sees them (the bytes follow in lz_copy_kernel)
+__global__ __launch_bounds__(64) void xhd_parse_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, const u64* __restrict__ tok_prefix,
+                                                      uint32_t* __restrict__ tok, u64* __restrict__ ntok,
+                                                      u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
 {
 	__shared__ XhdLds S;
 	const uint32_t lane = threadIdx.x, u = blockIdx.x;
 	const uint32_t n = (uint32_t)bt.in_len[u];
 	const u64 cap = bt.out_cap[u];
 	const uint8_t* src = d_in + bt.in_off[u];
-	uint8_t* dst = d_out + bt.out_off[u];
+	uint32_t* __restrict__ mytok = tok + tok_prefix[u];
+	u64 nt = 0; uint32_t ns = 0;                                         // tokens in HBM, tokens staged
+	#define XHD_EMIT(w) { if (lane == 0) { S.stage[ns] = (w); } ++ns; \
+		if (ns == 64u) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); mytok[nt + lane] = S.stage[lane]; nt += 64u; ns = 0; \
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } }
 	int32_t status = 1; u64 op = 0;                                      // 1 = running
 	// ---- input ring (see xpd_kernel) ----
 	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
@@ -744,17 +753,6 @@ __global__ __launch_bounds__(64) void xhd_kernel(const uint8_t* __restrict__ d_i
 	loaded = 2;
 	__syncthreads();
 	auto rb = [&](u64 q) -> uint32_t { return S.in[(uint32_t)q & (2u * XHD_INB - 1u)]; };
-	// ---- output ring: coordinate r = output offset + d0; wi = r mod XHD_RING ----
-	const uint32_t d0 = (uint32_t)((uintptr_t)dst & 15u);
-	uint8_t* db = dst - d0;
-	u64 flushed = 0;
-	#define XHD_FLUSH() { const uint8_t* h_ = S.out + (uint32_t)(flushed % XHD_RING); \
-		for (uint32_t i_ = lane; i_ < 512u; i_ += 64u) { const u64 r_ = flushed + (u64)i_ * 16u; \
-			if (r_ >= d0) { *reinterpret_cast<uint4*>(db + r_) = *reinterpret_cast<const uint4*>(h_ + i_ * 16u); } \
-			else { for (uint32_t k_ = d0; k_ < 16u; ++k_) { db[r_ + k_] = h_[i_ * 16u + k_]; } } } \
-		flushed += 8192u; }
-	auto wrap = [](uint32_t x) -> uint32_t { return x >= XHD_RING ? x - XHD_RING : x; };
-	uint32_t wi = d0;                                                    // ring index of output offset op
 	u64 ip = a0;
 	while (status == 1) {
 		// ---- a chunk: 256 bytes of code lengths, then its bit stream (:137-152) ----
@@ -821,9 +819,8 @@ __global__ __launch_bounds__(64) void xhd_kernel(const uint8_t* __restrict__ d_i
 			if (sym == 0x100u && ip == endq && XHD_MASK_ZERO()) { stream_end = true; break; }   // :91
 			if (sym < 0x100u) {
 				if (op == cap) { status = -5; break; }
-				if (lane == 0) { S.out[wi] = (uint8_t)sym; }
-				++op; wi = wrap(wi + 1u);
-				if (op + d0 >= flushed + 8192u) { __syncthreads(); XHD_FLUSH() }
+				XHD_EMIT(0x80000000u | sym)
+				++op;
 			} else {
 				uint32_t len = sym & 0xFu;
 				if (len == 0xFu) {
@@ -848,28 +845,9 @@ __global__ __launch_bounds__(64) void xhd_kernel(const uint8_t* __restrict__ d_i
 				XHD_SKIP(ob)
 				if (off > op) { status = -3; break; }                    // :120
 				if (len > cap - op) { status = -5; break; }              // :121
-				uint32_t left = len;
-				if (off >= 64u) {
-					uint32_t si = wi >= off ? wi - off : wi + XHD_RING - off;
-					while (left) {
-						const uint32_t step = left < 64u ? left : 64u;
-						if (lane < step) { S.out[wrap(wi + lane)] = S.out[wrap(si + lane)]; }
-						wi = wrap(wi + step); si = wrap(si + step); op += step; left -= step;
-						if (op + d0 >= flushed + 8192u) { __syncthreads(); XHD_FLUSH() }
-					}
-				} else {
-					const float ro = __builtin_amdgcn_rcpf((float)off);
-					const uint32_t span = (uint32_t)(64.5f * ro) * off;
-					const uint32_t lm = lane - (uint32_t)(((float)lane + 0.5f) * ro) * off;
-					const uint32_t s0 = wi >= off ? wi - off : wi + XHD_RING - off;
-					const uint32_t v = S.out[wrap(s0 + lm)];
-					while (left) {
-						const uint32_t step = left < span ? left : span;
-						if (lane < step) { S.out[wrap(wi + lane)] = (uint8_t)v; }
-						wi = wrap(wi + step); op += step; left -= step;
-						if (op + d0 >= flushed + 8192u) { __syncthreads(); XHD_FLUSH() }
-					}
-				}
+				op += len;
+				while (len > LZT_MAXLEN) { XHD_EMIT(off | (LZT_MAXLEN << 16)) len -= LZT_MAXLEN; }
+				XHD_EMIT(off | (len << 16))
 			}
 		}
 		if (status != 1) { break; }
@@ -887,19 +865,107 @@ __global__ __launch_bounds__(64) void xhd_kernel(const uint8_t* __restrict__ d_i
 	#undef XHD_SKIP
 	#undef XHD_MASK_ZERO
 	#undef XHD_DECODE
-	__syncthreads();
-	if (status == 0) {
-		const u64 rend = op + d0;
-		for (u64 r = flushed + lane; r < rend; r += 64u) { if (r >= d0) { db[r] = S.out[(uint32_t)(r % XHD_RING)]; } }
-	}
-	#undef XHD_FLUSH
-	if (lane == 0) { d_status[u] = status; d_out_len[u] = status == 0 ? op : 0; }
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+	if (lane < ns) { mytok[nt + lane] = S.stage[lane]; }
+	#undef XHD_EMIT
+	if (lane == 0) { d_status[u] = status; d_out_len[u] = status == 0 ? op : 0; ntok[u] = status == 0 ? nt + ns : 0; }
 }
 
-void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* d_out, u64* d_out_len, int32_t* d_status)
+// ===================================================================================================================
+// tokens -> bytes (one wave per unit)
+// ===================================================================================================================
+// The output of a unit is produced 2048 bytes at a time. The tokens that start in the window set a bit per start and leave their
+// word at that position; then 64 bytes at a time find their token (highest start at or below them; the token running when the
+// row begins is carried in registers), hence their source: a literal, or byte (i - s) mod off of the match's first period. A
+// source in an earlier window is read back from HBM, one in an earlier row of the window from LDS, one in the same row is chased
+// with ds_bpermute pointer jumping (as in the LZNT1 chunk kernel).
+#define LZC_W 2048u
+struct LzcLds { __attribute__((aligned(16))) uint8_t win[LZC_W + 64]; uint32_t info[LZC_W]; u64 bm[LZC_W / 64u]; };
+
+__global__ __launch_bounds__(64) void lz_copy_kernel(BatchTables bt, const u64* __restrict__ tok_prefix, const uint32_t* __restrict__ tok,
+                                                    const u64* __restrict__ ntok, const u64* __restrict__ d_out_len, const int32_t* __restrict__ d_status,
+                                                    uint8_t* __restrict__ d_out)
+{
+	__shared__ LzcLds L;
+	const uint32_t lane = threadIdx.x, u = blockIdx.x;
+	if (d_status[u] != 0) { return; }
+	const u64 total = d_out_len[u], nt = ntok[u];
+	const uint32_t* __restrict__ mytok = tok + tok_prefix[u];
+	uint8_t* dst = d_out + bt.out_off[u];
+	u64 t = 0, tpos = 0;                                                 // next token to place, its output offset
+	u64 cur_s = 0; uint32_t cur_w = 0x80000000u;                         // the token running at the current position
+	for (u64 w0 = 0; w0 < total; w0 += LZC_W) {
+		const uint32_t wlen = total - w0 < LZC_W ? (uint32_t)(total - w0) : LZC_W;
+		if (lane < LZC_W / 64u) { L.bm[lane] = 0; }
+		__syncthreads();
+		// ---- the tokens that start in this window ----
+		while (t < nt && tpos < w0 + wlen) {
+			const u64 ti = t + lane;
+			const uint32_t w = ti < nt ? mytok[ti] : 0x80000000u;
+			const uint32_t len = ti < nt ? ((w & 0x80000000u) ? 1u : (w >> 16) & 0x7FFFu) : 0u;
+			const uint32_t incl = wave_incl_scan_add_u32(len);
+			const u64 p = tpos + incl - len;
+			const bool in = ti < nt && p < w0 + wlen;
+			if (in) {
+				const uint32_t q = (uint32_t)(p - w0);
+				L.info[q] = w;
+				atomicOr(reinterpret_cast<uint32_t*>(L.bm) + (q >> 5), 1u << (q & 31u));
+			}
+			const uint32_t k = (uint32_t)__builtin_popcountll(__ballot(in));     // a prefix of the lanes
+			t += k;
+			tpos += k == 64u ? (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) : (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(k ? k - 1u : 0u)) * (k ? 1u : 0u);
+			if (k < 64u) { break; }
+		}
+		__syncthreads();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");               // earlier windows of this unit are read back from HBM
+		// ---- bytes ----
+		for (uint32_t rowbase = 0; rowbase < wlen; rowbase += 64u) {
+			const u64 word = L.bm[rowbase >> 6];
+			const u64 i = w0 + rowbase + lane;
+			const u64 mine = word & ((2ull << lane) - 1ull);
+			const u64 s = mine ? w0 + rowbase + 63u - (uint32_t)__builtin_clzll(mine) : cur_s;
+			const uint32_t inf = mine ? L.info[(uint32_t)(s - w0)] : cur_w;
+			if (word) { cur_s = w0 + rowbase + 63u - (uint32_t)__builtin_clzll(word); cur_w = L.info[(uint32_t)(cur_s - w0)]; }
+			const bool lit = (inf & 0x80000000u) != 0;
+			uint32_t val = inf & 0xFFu;
+			const uint32_t rowend = rowbase + 64u < wlen ? 64u : wlen - rowbase;
+			bool resolved = lit || lane >= rowend;
+			uint32_t ptr = lane;                                         // in-row source lane while unresolved
+			if (!resolved) {
+				const uint32_t off = inf & 0xFFFFu, dd = (uint32_t)(i - s);
+				uint32_t rem = dd;
+				if (dd >= off) {
+					const uint32_t q = (uint32_t)((float)dd * __builtin_amdgcn_rcpf((float)off));
+					int32_t rr = (int32_t)dd - (int32_t)(q * off);
+					if (rr < 0) { rr += (int32_t)off; } else if (rr >= (int32_t)off) { rr -= (int32_t)off; }
+					rem = (uint32_t)rr;
+				}
+				const u64 sp = s - off + rem;                            // absolute source position, < s
+				if (sp >= w0 + rowbase) { ptr = (uint32_t)(sp - (w0 + rowbase)); }
+				else if (sp >= w0) { val = L.win[(uint32_t)(sp - w0)]; resolved = true; }
+				else { val = dst[sp]; resolved = true; }
+			}
+			while (__ballot(!resolved)) {
+				const uint32_t tl = resolved ? lane : ptr;
+				const uint32_t tv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(tl << 2), (int)(val | (resolved ? 0x100u : 0u)));
+				const uint32_t tp = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(tl << 2), (int)ptr);
+				if (!resolved) { if (tv & 0x100u) { val = tv & 0xFFu; resolved = true; } else { ptr = tp; } }
+			}
+			L.win[rowbase + lane] = (uint8_t)val;
+			__syncthreads();
+		}
+		lzd_store(dst + w0, L.win, wlen, lane);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		__syncthreads();
+	}
+}
+
+void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
+                                   uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase)
 {
 	if (bt.n_units == 0) { return; }
-	hipLaunchKernelGGL(xhd_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, d_out, d_out_len, d_status);
+	if (phase == 0) { hipLaunchKernelGGL(xhd_parse_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, tok_prefix, tok, ntok, d_out_len, d_status); }
+	else            { hipLaunchKernelGGL(lz_copy_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out); }
 }
 
 } // namespace msc

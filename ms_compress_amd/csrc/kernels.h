@@ -55,8 +55,10 @@ void launch_lzd_finalize(hipStream_t st, const BatchTables& bt, const LzdBufs& b
 // Xpress: one wave per stream
 void launch_xpress_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* d_out, u64* d_out_len, int32_t* d_status);
 
-// Xpress+Huffman: one wave per buffer
-void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* d_out, u64* d_out_len, int32_t* d_status);
+// Xpress+Huffman: phase 0 = one wave per buffer walks the symbols and writes 32-bit tokens (tok_prefix[u] = first slot of unit u, ntok[u]),
+// status and length; phase 1 = the tokens become bytes
+void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
+                                   uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase);
 
 // ---- utilities (util.hip) ----
 // prefix[0..n] = exclusive scan of sizes[0..n) as u64 (prefix[n] = total). block_sums: scratch of ceil(n/1024)+1 u64.
