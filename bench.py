@@ -189,6 +189,42 @@ def cpu_baseline(fmt, blob, budget_s=12.0):
             "sample": "%d passes over the first %d B of the batch, %d threads x %d B independent ms_compress calls" % (passes, sample, len(slices), piece)}
 
 
+def cpu_decompress_baseline(fmt, blob, budget_s=3.0):
+    """The reference's CPU decoder beside the GPU decompression leg: the same kind of bounded sample as cpu_baseline (64 KiB units
+    for the Xpress formats, 4 MiB pieces for LZNT1; compressed by the reference, untimed), all host cores, output MB/s."""
+    from oracle import loader
+    ref = loader.load_ref()
+    kind = "reference" if ref is not None else "port"
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    unit = (4 << 20) if fmt == 2 else 65536
+    per_thread = 4 << 20
+    sample = min(len(blob), per_thread * cores) // unit * unit
+    data = blob[:sample].tobytes()
+    comp = loader.ref_compress if ref is not None else loader.oracle_compress
+    dec = loader.ref_decompress if ref is not None else loader.oracle_decompress
+    units = [data[o:o + unit] for o in range(0, sample, unit)]
+    pool = [[] for _ in range(min(cores, len(units)))]
+    for i, u in enumerate(units):
+        pool[i % len(pool)].append((comp(fmt, u)[1], len(u)))
+
+    def work(items):
+        for c, n in items:
+            dec(fmt, c, n)
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        th = [threading.Thread(target=work, args=(it,)) for it in pool]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        passes += 1
+        if time.perf_counter() - t0 > budget_s or passes >= 20:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(sample * passes / dt / 1e6, 1), "unit": "MB/s (output)", "cores": len(pool), "kind": kind,
+            "sample": "%d passes over the first %d B of the batch as %d independent ms_decompress calls of %d B" % (passes, sample, len(units), unit)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,6 +289,8 @@ def main():
             f2 = m.FORMATS[codec]
             b2, o2, l2, d2 = build_workload(m, corpus, f2, wl)
             dec[codec] = decompress_leg(m, ctx, f2, b2, o2, l2, d2, 3, sharding)
+            if rank == 0 and not args.no_cpu:
+                dec[codec]["cpu_baseline"] = cpu_decompress_baseline(f2, b2)
         extra["decompress"] = dec
         res["extra"] = extra
     if rank == 0:

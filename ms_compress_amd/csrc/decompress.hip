@@ -564,13 +564,11 @@ __global__ __launch_bounds__(64) void xpd_kernel(const uint8_t* __restrict__ d_i
 	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
 	const uint8_t* ab = src - a0;
 	const uint32_t endq = a0 + n;
-	uint4 pf;
-	uint32_t loaded = 0;                                                 // blocks stored so far; block `loaded` is in pf
-	#define XPD_FETCH(b) { const u64 q_ = (u64)(b) * XPD_INB + lane * 16u; pf = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); }
-	#define XPD_STORE(b) { *reinterpret_cast<uint4*>(S.in + ((uint32_t)(b) & 1u) * XPD_INB + lane * 16u) = pf; }
-	XPD_FETCH(0) XPD_STORE(0) XPD_FETCH(1) XPD_STORE(1) XPD_FETCH(2)
-	loaded = 2;
-	__syncthreads();
+	uint32_t loaded = 0;                                                 // blocks of 1024 input bytes brought to LDS so far (the last two are resident)
+	#define XPD_BLOCK() { __syncthreads(); { const u64 q_ = (u64)loaded * XPD_INB + lane * 16u; \
+			*reinterpret_cast<uint4*>(S.in + (loaded & 1u) * XPD_INB + lane * 16u) = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } \
+		++loaded; __syncthreads(); }
+	XPD_BLOCK() XPD_BLOCK()
 	auto rb = [&](uint32_t q) -> uint32_t { return S.in[q & (2u * XPD_INB - 1u)]; };
 	const uint32_t* in32 = reinterpret_cast<const uint32_t*>(S.in);
 	// bytes q .. q+7 as two dwords
@@ -596,10 +594,8 @@ __global__ __launch_bounds__(64) void xpd_kernel(const uint8_t* __restrict__ d_i
 	XPD_FETCH8(ip, lo, hi)
 	while (!done) {
 		if (ip + 4u > endq) { status = -3; break; }                     // :461 the input ended at a flag word
-		while (loaded * XPD_INB < ip + 352u && (u64)loaded * XPD_INB < endq) {   // a flag word and its 32 tokens take at most 4 + 32 * 10 bytes
-			__syncthreads();
-			XPD_STORE(loaded) ++loaded; XPD_FETCH(loaded)
-			__syncthreads();
+		while ((u64)loaded * XPD_INB < (u64)ip + 352u && (u64)loaded * XPD_INB < endq) {   // a flag word and its 32 tokens take at most 4 + 32 * 10 bytes
+			XPD_BLOCK()
 			XPD_FETCH8(ip, lo, hi)
 		}
 		uint32_t flags = lo;
@@ -681,8 +677,7 @@ __global__ __launch_bounds__(64) void xpd_kernel(const uint8_t* __restrict__ d_i
 			}
 		} while (flags);
 	}
-	#undef XPD_FETCH
-	#undef XPD_STORE
+	#undef XPD_BLOCK
 	#undef XPD_FETCH8
 	// the rest of the ring
 	__syncthreads();
@@ -716,7 +711,6 @@ void launch_xpress_decompress(hipStream_t st, const uint8_t* d_in, const BatchTa
 #define LZT_MAXLEN 32766u
 struct XhdLds {
 	__attribute__((aligned(16))) uint8_t in[2u * XHD_INB];
-	uint32_t stage[64];                 // tokens on their way to HBM
 	uint16_t fast[512];                 // 9-bit prefix -> symbol << 4 | length (0: longer code)
 	uint16_t syms[512];                 // symbols in canonical order
 	uint32_t lims[16], poss[16];
@@ -733,27 +727,24 @@ __global__ __launch_bounds__(64) void xhd_parse_kernel(const uint8_t* __restrict
 	const u64 cap = bt.out_cap[u];
 	const uint8_t* src = d_in + bt.in_off[u];
 	uint32_t* __restrict__ mytok = tok + tok_prefix[u];
-	u64 nt = 0; uint32_t ns = 0;                                         // tokens in HBM, tokens staged
-	#define XHD_EMIT(w) { if (lane == 0) { S.stage[ns] = (w); } ++ns; \
-		if (ns == 64u) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); mytok[nt + lane] = S.stage[lane]; nt += 64u; ns = 0; \
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } }
+	u64 nt = 0; uint32_t ns = 0, treg = 0;                               // tokens in HBM; tokens staged: token k of the batch waits in lane k
+	#define XHD_EMIT(w) { treg = lane == ns ? (w) : treg; ++ns; if (ns == 64u) { mytok[nt + lane] = treg; nt += 64u; ns = 0; } }
 	int32_t status = 1; u64 op = 0;                                      // 1 = running
 	// ---- input ring (see xpd_kernel) ----
 	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
 	const uint8_t* ab = src - a0;
-	const u64 endq = (u64)a0 + n;
-	uint4 pf[2];
-	u64 loaded = 0;
-	#define XHD_FETCH(b) { _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) { const u64 q_ = (u64)(b) * XHD_INB + ((uint32_t)i_ * 64u + lane) * 16u; \
-		pf[i_] = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } }
-	#define XHD_STORE(b) { uint8_t* b_ = S.in + ((uint32_t)(b) & 1u) * XHD_INB; \
-		_Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) { *reinterpret_cast<uint4*>(b_ + ((uint32_t)i_ * 64u + lane) * 16u) = pf[i_]; } }
-	#define XHD_NEED(q, margin) while (loaded * XHD_INB < (q) + (margin) && loaded * XHD_INB < endq) { __syncthreads(); XHD_STORE(loaded) ++loaded; XHD_FETCH(loaded) __syncthreads(); }
-	XHD_FETCH(0) XHD_STORE(0) XHD_FETCH(1) XHD_STORE(1) XHD_FETCH(2)
-	loaded = 2;
-	__syncthreads();
-	auto rb = [&](u64 q) -> uint32_t { return S.in[(uint32_t)q & (2u * XHD_INB - 1u)]; };
-	u64 ip = a0;
+	const uint32_t endq = a0 + n;                                        // units are below 4 GiB - 256
+	uint32_t loaded = 0;                                                 // blocks of 2048 input bytes brought to LDS so far (the last two are resident)
+	// a block is loaded when the walk gets there (one HBM round trip per 2 KiB of input: nothing next to ~5000 symbols); values that
+	// live across the walk in registers (a prefetched block) made the compiler wait for memory and shuffle them on every symbol
+	#define XHD_BLOCK() { uint8_t* b_ = S.in + (loaded & 1u) * XHD_INB; __syncthreads(); \
+		_Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) { const u64 q_ = (u64)loaded * XHD_INB + ((uint32_t)i_ * 64u + lane) * 16u; \
+			*reinterpret_cast<uint4*>(b_ + ((uint32_t)i_ * 64u + lane) * 16u) = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } \
+		++loaded; __syncthreads(); }
+	#define XHD_NEED(q, margin) while ((u64)loaded * XHD_INB < (u64)(q) + (margin) && (u64)loaded * XHD_INB < endq) { XHD_BLOCK() }
+	XHD_BLOCK() XHD_BLOCK()
+	auto rb = [&](uint32_t q) -> uint32_t { return S.in[q & (2u * XHD_INB - 1u)]; };
+	uint32_t ip = a0;
 	while (status == 1) {
 		// ---- a chunk: 256 bytes of code lengths, then its bit stream (:137-152) ----
 		if (endq - ip < 260u) { status = (ip != endq) ? -3 : 0; break; } // :140-144
@@ -804,7 +795,7 @@ __global__ __launch_bounds__(64) void xhd_parse_kernel(const uint8_t* __restrict
 		uint32_t bits = 32; ip += 4u;
 		const u64 chunk_end = op + 65536u;
 		bool stream_end = false;
-		#define XHD_SKIP(k) { mask <<= (k); bits -= (k); if (bits < 16u && ip + 2u <= endq) { mask |= (rb(ip) | (rb(ip + 1) << 8)) << (16u - bits); bits |= 16u; ip += 2u; } }
+		#define XHD_SKIP(k) { mask <<= (k); bits -= (k); if (bits < 16u && ip + 2u <= endq) { XHD_NEED(ip, 2u) mask |= (rb(ip) | (rb(ip + 1) << 8)) << (16u - bits); bits |= 16u; ip += 2u; } }
 		#define XHD_MASK_ZERO() (bits == 0 || (mask >> (32u - bits)) == 0)
 		#define XHD_DECODE(sym) { const uint32_t r_ = bits; const uint32_t x_ = r_ < 15u ? (((mask >> 16) >> (16u - r_)) << (15u - r_)) : (mask >> 17); \
 			const uint32_t f_ = S.fast[x_ >> 6]; uint32_t n_; \
@@ -812,18 +803,18 @@ __global__ __launch_bounds__(64) void xhd_parse_kernel(const uint8_t* __restrict
 			else { n_ = 1; while (x_ >= S.lims[n_]) { ++n_; } \
 				if (n_ > r_) { sym = 0xFFFFu; } else { XHD_SKIP(n_) const uint32_t s_ = S.poss[n_] + ((x_ - S.lims[n_ - 1u]) >> (15u - n_)); sym = s_ >= 512u ? 0xFFFFu : S.syms[s_]; } } }
 		while (op < chunk_end || !XHD_MASK_ZERO()) {
-			XHD_NEED(ip, 64u)
 			uint32_t sym;
 			XHD_DECODE(sym)
-			if (sym == 0xFFFFu) { status = -3; break; }
-			if (sym == 0x100u && ip == endq && XHD_MASK_ZERO()) { stream_end = true; break; }   // :91
 			if (sym < 0x100u) {
 				if (op == cap) { status = -5; break; }
 				XHD_EMIT(0x80000000u | sym)
 				++op;
 			} else {
+				if (sym == 0xFFFFu) { status = -3; break; }
+				if (sym == 0x100u && ip == endq && XHD_MASK_ZERO()) { stream_end = true; break; }   // :91
 				uint32_t len = sym & 0xFu;
 				if (len == 0xFu) {
+					XHD_NEED(ip, 8u)
 					if (endq - ip < 1u) { status = -3; break; }
 					len = rb(ip); ip += 1u;
 					if (len == 0xFFu) {
@@ -852,21 +843,19 @@ __global__ __launch_bounds__(64) void xhd_parse_kernel(const uint8_t* __restrict
 		}
 		if (status != 1) { break; }
 		if (!stream_end) {                                               // :128-134: is the next symbol the end of the stream?
-			const u64 ip_keep = ip;
+			const uint32_t ip_keep = ip;
 			uint32_t sym;
 			XHD_DECODE(sym)
 			if (sym == 0x100u && ip == endq && XHD_MASK_ZERO()) { stream_end = true; } else { ip = ip_keep; }
 		}
 		if (stream_end) { status = 0; }
 	}
-	#undef XHD_FETCH
-	#undef XHD_STORE
+	#undef XHD_BLOCK
 	#undef XHD_NEED
 	#undef XHD_SKIP
 	#undef XHD_MASK_ZERO
 	#undef XHD_DECODE
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
-	if (lane < ns) { mytok[nt + lane] = S.stage[lane]; }
+	if (lane < ns) { mytok[nt + lane] = treg; }
 	#undef XHD_EMIT
 	if (lane == 0) { d_status[u] = status; d_out_len[u] = status == 0 ? op : 0; ntok[u] = status == 0 ? nt + ns : 0; }
 }

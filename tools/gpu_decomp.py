@@ -41,9 +41,10 @@ u64k = []
 for f in files: u64k += [f[k:k + 65536] for k in range(0, len(f), 65536)]
 moz = corpus.file_bytes(corpus.NAMES.index("mozilla"), 51_220_480)
 which = sys.argv[1:] or ["2", "3", "4"]
+nofiles = "nofiles" in which
 if "2" in which:
     run(2, [moz], "mozilla as one unit"); run(2, u64k, "%d units of 64 KiB" % len(u64k))
 if "3" in which:
-    run(3, u64k, "%d units of 64 KiB" % len(u64k)); run(3, files, "12 files, one stream each", reps=1)
+    run(3, u64k, "%d units of 64 KiB" % len(u64k)); (None if nofiles else run(3, files, "12 files, one stream each", reps=1))
 if "4" in which:
-    run(4, u64k, "%d units of 64 KiB" % len(u64k)); run(4, files, "12 files", reps=1)
+    run(4, u64k, "%d units of 64 KiB" % len(u64k)); (None if nofiles else run(4, files, "12 files", reps=1))
