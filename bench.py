@@ -144,20 +144,22 @@ def pmc_traffic(kernel):
     return None
 
 
-def roofline(fmt, prof, in_bytes, out_bytes):
+def roofline(fmt, prof, in_bytes, out_bytes, steps):
     name = DOMINANT[fmt]
     tot_ms = sum(v[0] for v in prof.values())
     dom = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else name
     ms, cnt = prof.get(dom, (0.0, 0))
     per_launch_ms = ms / cnt if cnt else float("nan")
+    launches_per_step = cnt / steps if cnt else 1          # 2 when the batch runs as two halves on two streams
     # algorithmic bytes: 1 B HBM read + CR B HBM write per input byte, for the units one launch processes
-    alg = in_bytes + out_bytes
+    alg = (in_bytes + out_bytes) / launches_per_step
     ach = alg / (per_launch_ms * 1e-3) / 1e9 if cnt else float("nan")
     return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom),
-            "kernel_ms_per_launch": round(per_launch_ms, 4), "kernel_share_of_gpu_time": round(ms / tot_ms, 3) if tot_ms else None,
-            "algorithmic_bytes_per_launch": alg,
-            "kernels_ms_per_step": {k: round(v[0] / v[1], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
+            "kernel_ms_per_launch": round(per_launch_ms, 4), "launches_per_step": launches_per_step,
+            "kernel_share_of_gpu_time": round(ms / tot_ms, 3) if tot_ms else None,
+            "algorithmic_bytes_per_launch": int(alg),
+            "kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
 
 
 def cpu_baseline(fmt, blob, budget_s=12.0):
@@ -265,7 +267,7 @@ def main():
         "config": {"workload": "%s: %s; one %s block per chunk" % (args.codec, desc, {2: "4 KiB", 3: "64 KiB", 4: "64 KiB"}[fmt]),
                    "bytes_per_step_per_gpu": job.in_bytes, "units_per_gpu": int(len(in_len)), "compression_ratio": round(out_bytes / job.in_bytes, 4),
                    "parallelism": "replica-per-gpu x%d (independent units, no collective)" % world, "MiB_per_s": round(job_bytes / job_dt / 2 ** 20, 1)},
-        "roofline": roofline(fmt, prof, job.in_bytes, out_bytes),
+        "roofline": roofline(fmt, prof, job.in_bytes, out_bytes, args.steps),
     }
     job.close()
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -282,7 +284,7 @@ def main():
             ob = j2.out_bytes()
             steps2 = max(3, args.steps // 4)
             extra[codec] = {"MB_per_s": round(j2.in_bytes * steps2 / t2 / 1e6, 1), "ms_per_step": round(t2 / steps2 * 1e3, 3),
-                            "workload": d2, "compression_ratio": round(ob / j2.in_bytes, 4), "roofline": roofline(f2, p2, j2.in_bytes, ob)}
+                            "workload": d2, "compression_ratio": round(ob / j2.in_bytes, 4), "roofline": roofline(f2, p2, j2.in_bytes, ob, steps2)}
             j2.close()
         dec = {}
         for codec, wl in (("lznt1", "mozilla"), ("xpress", "silesia_units64k"), ("xpress_huff", "silesia_units64k")):
