@@ -261,8 +261,10 @@ __global__ __launch_bounds__(64) void lzd_verify_kernel(const uint8_t* __restric
 // ===================================================================================================================
 #define LZD_ERR 0x8000u
 struct LzdLds {
-	__attribute__((aligned(16))) uint8_t in[4128];     // the chunk (header + data) at its 16-byte phase in global memory
-	__attribute__((aligned(16))) uint8_t out[4096 + 64];
+	union {                                            // the input is dead when the first output byte is written (all tokens are placed by then)
+		__attribute__((aligned(16))) uint8_t in[4128];     // the chunk (header + data) at its 16-byte phase in global memory
+		__attribute__((aligned(16))) uint8_t out[4096 + 64];
+	};
 	uint16_t info[4096];                               // at token starts: literal byte, or 0x8000 | (offset - 1)
 	u64      bm[64];                                   // token-start bitmap over the output positions
 	uint16_t gs[464];                                  // start (data offset) of every flag group
