@@ -203,15 +203,21 @@ def cpu_decompress_baseline(fmt, blob, budget_s=3.0):
     sample = min(len(blob), per_thread * cores) // unit * unit
     data = blob[:sample].tobytes()
     comp = loader.ref_compress if ref is not None else loader.oracle_compress
-    dec = loader.ref_decompress if ref is not None else loader.oracle_decompress
     units = [data[o:o + unit] for o in range(0, sample, unit)]
     pool = [[] for _ in range(min(cores, len(units)))]
     for i, u in enumerate(units):
         pool[i % len(pool)].append((comp(fmt, u)[1], len(u)))
 
-    def work(items):
+    import ctypes as C
+    lib = ref if ref is not None else loader.load_oracle()
+    fn = lib.ms_decompress if ref is not None else lib.orc_decompress
+
+    def work(items):                               # one output buffer per thread; the GIL is released inside the C call
+        out = C.create_string_buffer(unit + 64)
+        ln = C.c_size_t(0)
         for c, n in items:
-            dec(fmt, c, n)
+            ln.value = n
+            fn(fmt, c, len(c), out, C.byref(ln))
     passes, t0 = 0, time.perf_counter()
     while True:
         th = [threading.Thread(target=work, args=(it,)) for it in pool]
