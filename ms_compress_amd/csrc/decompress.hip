@@ -261,12 +261,10 @@ __global__ __launch_bounds__(64) void lzd_verify_kernel(const uint8_t* __restric
 // ===================================================================================================================
 #define LZD_ERR 0x8000u
 struct LzdLds {
-	union {                                            // the input is dead when the first output byte is written (all tokens are placed by then)
-		__attribute__((aligned(16))) uint8_t in[4128];     // the chunk (header + data) at its 16-byte phase in global memory
-		__attribute__((aligned(16))) uint8_t out[4096 + 64];
-	};
-	uint16_t info[4096];                               // at token starts: literal byte, or 0x8000 | (offset - 1)
-	u64      bm[64];                                   // token-start bitmap over the output positions
+	__attribute__((aligned(16))) uint8_t in[4128];     // the chunk (header + data) at its 16-byte phase in global memory
+	__attribute__((aligned(16))) uint8_t out[4096 + 64];   // literals at once; a match leaves offset - 1 in its first two bytes until its row is resolved
+	u64      bm[64];                                   // token starts over the output positions
+	u64      mb[64];                                   // ... those that are matches
 	uint16_t gs[464];                                  // start (data offset) of every flag group
 };
 
@@ -278,7 +276,7 @@ __device__ __forceinline__ uint32_t lzd_decode_chunk(LzdLds& L, const uint8_t* _
 	const uint8_t* ab = src - a0;
 	const uint32_t nw = (a0 + in_size + 15u) >> 4;                       // <= 258
 	for (uint32_t i = lane; i < nw; i += 64u) { *reinterpret_cast<uint4*>(L.in + i * 16u) = *reinterpret_cast<const uint4*>(ab + i * 16u); }
-	L.bm[lane] = 0;
+	L.bm[lane] = 0; L.mb[lane] = 0;
 	__syncthreads();
 	const uint8_t* d = L.in + a0 + 2u;                                  // chunk data
 	const uint32_t n = in_size - 2u;                                     // 1..4096
@@ -320,8 +318,9 @@ __device__ __forceinline__ uint32_t lzd_decode_chunk(LzdLds& L, const uint8_t* _
 		if (valid && (is_match ? (off > pos || pos + len > 4096u) : pos >= 4096u)) { err = 1; }   // :104-105; a literal beyond the chunk is our DATA_ERROR
 		if (__ballot(err)) { return LZD_ERR; }
 		if (valid) {
-			L.info[pos] = (uint16_t)(is_match ? (0x8000u | (off - 1u)) : raw);
+			L.out[pos] = (uint8_t)(is_match ? off - 1u : raw);
 			atomicOr(reinterpret_cast<uint32_t*>(L.bm) + (pos >> 5), 1u << (pos & 31u));
+			if (is_match) { L.out[pos + 1u] = (uint8_t)((off - 1u) >> 8); atomicOr(reinterpret_cast<uint32_t*>(L.mb) + (pos >> 5), 1u << (pos & 31u)); }
 		}
 		base_pos = (uint32_t)__builtin_amdgcn_readlane((int)(pos + len), 63);
 		sh = (uint32_t)__builtin_amdgcn_readlane((int)sh, 63);
@@ -329,19 +328,23 @@ __device__ __forceinline__ uint32_t lzd_decode_chunk(LzdLds& L, const uint8_t* _
 	const uint32_t total = base_pos;
 	__syncthreads();
 	// ---- bytes, 64 at a time: every byte finds its token and its source; sources inside the row are chased with bpermute ----
-	uint32_t carry = 0;
+	uint32_t carry = 0, carry_off = 0; bool carry_match = false;         // the token running when a row begins
 	for (uint32_t rowbase = 0; rowbase < total; rowbase += 64u) {
-		const u64 word = L.bm[rowbase >> 6];
+		const u64 word = L.bm[rowbase >> 6], mword = L.mb[rowbase >> 6];
 		const uint32_t i = rowbase + lane;
 		const u64 mine = word & ((2ull << lane) - 1ull);
 		const uint32_t s = mine ? rowbase + 63u - (uint32_t)__builtin_clzll(mine) : carry;
-		if (word) { carry = rowbase + 63u - (uint32_t)__builtin_clzll(word); }
-		const uint32_t inf = L.info[s];
-		const bool lit = !(inf & 0x8000u);
-		uint32_t ptr = i, val = inf & 0xFFu;
-		bool resolved = lit || i >= total;
+		const bool mat = mine ? ((mword >> (s - rowbase)) & 1ull) != 0 : carry_match;
+		const uint32_t offm1 = mine ? ((uint32_t)L.out[s] | ((uint32_t)L.out[s + 1u] << 8)) : carry_off;     // only meaningful for a match
+		uint32_t ptr = i, val = L.out[i];                                 // a literal is in place already
+		if (word) {
+			carry = rowbase + 63u - (uint32_t)__builtin_clzll(word);
+			carry_match = ((mword >> (carry - rowbase)) & 1ull) != 0;
+			carry_off = (uint32_t)L.out[carry] | ((uint32_t)L.out[carry + 1u] << 8);
+		}
+		bool resolved = !mat || i >= total;
 		if (!resolved) {
-			const uint32_t off = (inf & 0xFFFu) + 1u, dd = i - s;
+			const uint32_t off = offm1 + 1u, dd = i - s;
 			uint32_t rem = dd;
 			if (dd >= off) {
 				const uint32_t q = (uint32_t)((float)dd * __builtin_amdgcn_rcpf((float)off));
