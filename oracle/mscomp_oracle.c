@@ -6,7 +6,8 @@
  * Xpress hash chains, an explicit token array for Xpress-Huffman) -- only the observable bytes match.
  *
  * Parity status: PINNED against the compiled reference (oracle/_ref) and the SURVEY 8c KAT table;
- * see tests/test_oracle_vs_ref.py and tests/test_oracle_golden.py.
+ * see tests/test_oracle_vs_ref.py and tests/test_oracle_golden.py. The decoders (with the reference's status codes) are
+ * pinned the same way: test_decompress_semantics and tests/golden/decode_streams.json.
  */
 #include "mscomp_oracle.h"
 #include <stdlib.h>

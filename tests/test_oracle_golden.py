@@ -108,3 +108,21 @@ def test_units_driver_threads(oracle):
         for i, u in enumerate(units):
             exp = oracle.oracle_compress(fmt, u)[1]
             assert status[i] == 0 and bytes(out[int(out_off[i]): int(out_off[i]) + int(out_len[i])]) == exp
+
+
+@pytest.mark.parametrize("fmt", list(FMTS))
+def test_decoders_golden(oracle, fmt):
+    """The restated decoders against the committed digest of the reference's ms_decompress over the decode stream families
+    (status + bytes of ~900 valid / truncated / concatenated / corrupted streams per codec)."""
+    g = json.load(open(os.path.join(G, "decode_streams.json")))[fmt]
+    f = FMTS[fmt]
+    streams = cases.decode_streams(f, lambda d: oracle.oracle_compress(f, d)[1])
+    assert len(streams) == g["streams"]
+    h = hashlib.sha256(); asked = 0
+    for stream, cap in streams:
+        st, out, undefined = oracle.oracle_decompress_ex(f, stream, cap)
+        if undefined:
+            continue
+        h.update(st.to_bytes(4, "little", signed=True)); h.update(len(out).to_bytes(8, "little")); h.update(out)
+        asked += 1
+    assert asked == g["asked"] and h.hexdigest() == g["sha256"]

@@ -63,3 +63,20 @@ for fn, f in FMTS.items():
     fam[fn] = {"units": len(units), "total_len": tot, "sha256": h.hexdigest()}
 json.dump(fam, open(os.path.join(ROOT, "tests/golden/edge_families.json"), "w"), indent=1)
 print("golden fixtures written:", {k: v["len"] for k, v in cor["mozilla"].items() if isinstance(v, dict)})
+
+# 4. decoders: status and output of the REFERENCE's ms_decompress for the stream families of tests/cases.py::decode_streams
+# (valid / terminated / truncated / concatenated / corrupted, several capacities): one digest per codec. Streams on which the
+# reference is undefined (flagged by the restated decoder, oracle/mscomp_oracle.c) are left out and counted.
+dec = {}
+for fn, f in FMTS.items():
+    streams = cases.decode_streams(f, lambda d: loader.ref_compress(f, d)[1])
+    h = hashlib.sha256(); asked = 0; by_status = {}
+    for stream, cap in streams:
+        if loader.oracle_decompress_ex(f, stream, cap)[2]:
+            continue
+        st, out = loader.ref_decompress(f, stream, cap)
+        h.update(st.to_bytes(4, "little", signed=True)); h.update(len(out).to_bytes(8, "little")); h.update(out)
+        asked += 1; by_status[str(st)] = by_status.get(str(st), 0) + 1
+    dec[fn] = {"streams": len(streams), "asked": asked, "by_status": by_status, "sha256": h.hexdigest()}
+json.dump(dec, open(os.path.join(ROOT, "tests/golden/decode_streams.json"), "w"), indent=1)
+print("decoder fixture:", {k: (v["asked"], v["by_status"]) for k, v in dec.items()})
