@@ -138,6 +138,18 @@ MSCompStatus mscomp_amd_decompress_batch(mscomp_amd_ctx* ctx, MSCompFormat forma
                                          uint8_t* d_out, const uint64_t* out_off, const uint64_t* out_cap,
                                          uint64_t* d_out_len, int32_t* d_status);
 
+/* Batch helpers.
+ * Capacity planning: out_cap[i] = what one ms_compress call needs at most for in_len[i] bytes (ms_max_compressed_size, + 2 for the LZNT1
+ * End_of_buffer), out_off[i] = running offset rounded up to `align`; returns the total size of the output buffer ((uint64_t)-1: bad format).
+ * Either output array may be NULL.
+ * Compaction: the outputs of a batch sit at out_off[i] with gaps up to their capacities; this packs them back to back, in unit order,
+ * into d_packed and writes the n_units + 1 offsets (uint64, device memory) to d_packed_off; out_off / out_cap are the host arrays given to
+ * the plan, d_out_len the device array plan_execute filled (units with a status other than MSCOMP_OK have length 0). Enqueued on the ctx
+ * stream after one small synchronous table upload. */
+uint64_t     mscomp_amd_plan_layout(MSCompFormat format, size_t n_units, const uint64_t* in_len, uint64_t align, uint64_t* out_off, uint64_t* out_cap);
+MSCompStatus mscomp_amd_compact_batch(mscomp_amd_ctx* ctx, size_t n_units, const uint8_t* d_out, const uint64_t* out_off, const uint64_t* out_cap,
+                                      const uint64_t* d_out_len, uint8_t* d_packed, uint64_t* d_packed_off);
+
 /* ---- measurement hooks (bench.py / profiles) ---- */
 /* When enabled, every kernel launch of plan_execute is bracketed by hipEvents on the ctx stream. */
 void         mscomp_amd_profile_enable(mscomp_amd_ctx* ctx, int on);

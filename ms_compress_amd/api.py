@@ -28,6 +28,7 @@ EXPORTS = [  # every symbol include/mscomp_amd.h declares (tests check the libra
     "xpress_huff_compress", "xpress_huff_max_compressed_size",
     "mscomp_amd_ctx_create", "mscomp_amd_ctx_destroy", "mscomp_amd_plan_create", "mscomp_amd_plan_destroy",
     "mscomp_amd_plan_execute", "mscomp_amd_compress_batch", "mscomp_amd_profile_enable", "mscomp_amd_profile_read",
+    "mscomp_amd_plan_layout", "mscomp_amd_compact_batch",
     "ms_deflate_init", "ms_deflate", "ms_deflate_end", "lznt1_deflate_init", "lznt1_deflate", "lznt1_deflate_end",
     "ms_decompress", "lznt1_decompress", "xpress_decompress", "xpress_huff_decompress", "mscomp_amd_plan_create_decompress", "mscomp_amd_decompress_batch",
     "mscomp_amd_version", "mscomp_amd_debug_xpress_matches", "mscomp_amd_debug_lds_lane_order", "mscomp_amd_debug_set_xpress_emit", "mscomp_amd_debug_set_lznt1", "mscomp_amd_debug_lzd_walked",
@@ -92,6 +93,10 @@ def load_library():
     lib.mscomp_amd_plan_create_decompress.restype = C.c_int
     lib.mscomp_amd_decompress_batch.argtypes = lib.mscomp_amd_compress_batch.argtypes
     lib.mscomp_amd_decompress_batch.restype = C.c_int
+    lib.mscomp_amd_plan_layout.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.mscomp_amd_plan_layout.restype = C.c_uint64
+    lib.mscomp_amd_compact_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mscomp_amd_compact_batch.restype = C.c_int
     lib.mscomp_amd_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.mscomp_amd_profile_enable.restype = None
     lib.mscomp_amd_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]

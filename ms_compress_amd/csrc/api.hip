@@ -47,6 +47,7 @@ struct mscomp_amd_ctx {
 	DevBuf tokbits, counts, extra, lens, codes, fb_list, fbflag;   // Xpress+Huffman per-chunk scratch
 	DevBuf dz_cin, dz_csize, dz_unit;                  // LZNT1 decompression: header offset / decoded size per chunk slot, per-unit records
 	DevBuf dz_tok, dz_ntok;                            // Xpress+Huffman decompression: 32-bit tokens of every unit, token counts
+	DevBuf cp_tab;                                     // compaction: out_off (u64) | tile_prefix (u32) of the batch being packed
 	DevBuf one_in, one_out, one_meta;                  // staging of the host-pointer one-shot path
 	bool profiling = false;
 	std::vector<ProfRec> recs;
@@ -143,7 +144,7 @@ void mscomp_amd_ctx_destroy(mscomp_amd_ctx* c)
 	for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
 	for (auto e : c->free_events) { (void)hipEventDestroy(e); }
 	c->slots.release(); c->slot_size.release(); c->prefix.release(); c->tile_sums.release();
-	c->one_in.release(); c->one_out.release(); c->one_meta.release();
+	c->one_in.release(); c->one_out.release(); c->one_meta.release(); c->cp_tab.release();
 	c->links.release(); c->lasthead.release(); c->mlen3.release(); c->moff.release();
 	c->wtok.release(); c->wmat.release(); c->wfar.release(); c->wrec.release(); c->sbrec.release();
 	c->tokbits.release(); c->counts.release(); c->extra.release(); c->lens.release(); c->codes.release();
@@ -445,6 +446,51 @@ MSCompStatus mscomp_amd_decompress_batch(mscomp_amd_ctx* c, MSCompFormat format,
 
 // Stage-level test hook: per-position (len-3 capped at 45, offset) of ONE unit as found by the HIP match finder.
 // h_len3/h_off: host arrays of in_len u16. max_off 0x2000 (Xpress) or 0xFFFF (Xpress+Huffman, clip to 64 KiB chunks).
+// ---- batch helpers: capacity planning and device-side compaction ----
+uint64_t mscomp_amd_plan_layout(MSCompFormat format, size_t n_units, const uint64_t* in_len, uint64_t align, uint64_t* out_off, uint64_t* out_cap)
+{
+	if (!align) { align = 1; }
+	uint64_t pos = 0;
+	for (size_t i = 0; i < n_units; ++i) {
+		size_t cap;
+		switch ((int)format) {
+		case MSCOMP_LZNT1:       cap = lznt1_max_compressed_size((size_t)in_len[i]) + 2; break;   // room for the uncounted End_of_buffer
+		case MSCOMP_XPRESS:      cap = xpress_max_compressed_size((size_t)in_len[i]); break;
+		case MSCOMP_XPRESS_HUFF: cap = xpress_huff_max_compressed_size((size_t)in_len[i]); break;
+		case MSCOMP_NONE:        cap = (size_t)in_len[i]; break;
+		default:                 return (uint64_t)-1;
+		}
+		if (out_off) { out_off[i] = pos; }
+		if (out_cap) { out_cap[i] = cap; }
+		pos += (cap + align - 1) / align * align;
+	}
+	return pos;
+}
+
+MSCompStatus mscomp_amd_compact_batch(mscomp_amd_ctx* c, size_t n_units, const uint8_t* d_out, const uint64_t* out_off, const uint64_t* out_cap,
+                                      const uint64_t* d_out_len, uint8_t* d_packed, uint64_t* d_packed_off)
+{
+	if (!c || !d_packed_off || (n_units && (!d_out || !out_off || !out_cap || !d_out_len || !d_packed)) || n_units > 0x7FFFFFF0u) { return MSCOMP_ARG_ERROR; }
+	DeviceGuard g(c->device);
+	if (!g.ok) { return MSCOMP_ERRNO; }
+	if (n_units == 0) { return hipMemsetAsync(d_packed_off, 0, 8, c->stream) == hipSuccess ? MSCOMP_OK : MSCOMP_ERRNO; }
+	std::vector<uint64_t> host(n_units + (n_units + 2) / 2 + 1);
+	uint32_t* tp = reinterpret_cast<uint32_t*>(host.data() + n_units);
+	uint64_t tiles = 0;
+	for (size_t i = 0; i < n_units; ++i) {
+		host[i] = out_off[i]; tp[i] = (uint32_t)tiles;
+		tiles += (out_cap[i] + 65535u) / 65536u;
+		if (tiles > 0x7FFFFFF0u) { return MSCOMP_ARG_ERROR; }
+	}
+	tp[n_units] = (uint32_t)tiles;
+	const size_t bytes = host.size() * sizeof(uint64_t);
+	if (!c->cp_tab.reserve(bytes)) { return MSCOMP_MEM_ERROR; }
+	if (hipMemcpyAsync(c->cp_tab.p, host.data(), bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { return MSCOMP_ERRNO; }
+	const u64* d_off = static_cast<const u64*>(c->cp_tab.p);
+	launch_compact(c->stream, d_out, d_off, reinterpret_cast<const uint32_t*>(d_off + n_units), (uint32_t)n_units, (uint32_t)tiles, d_out_len, d_packed_off, d_packed);
+	return hipGetLastError() == hipSuccess ? MSCOMP_OK : MSCOMP_ERRNO;
+}
+
 MSCompStatus mscomp_amd_debug_xpress_matches(mscomp_amd_ctx* c, const uint8_t* d_in, size_t in_len, uint32_t max_off, int clip,
                                              uint16_t* h_len3, uint16_t* h_off)
 {

@@ -67,6 +67,9 @@ void launch_scan_sizes(hipStream_t st, const uint32_t* sizes, u64* prefix, uint3
 void launch_concat_slots(hipStream_t st, const uint8_t* slots, uint32_t slot_stride, const uint32_t* slot_size,
                          const u64* prefix, const BatchTables& bt, uint8_t* d_out);
 // Per unit: out_len, status (OK / BUF_ERROR); LZNT1 also appends the uncounted 00 00 End_of_buffer when room.
+// outputs of a batch packed back to back: packed_off[0..n] (device), bytes of unit u at d_packed + packed_off[u]
+void launch_compact(hipStream_t st, const uint8_t* d_out, const u64* d_out_off, const uint32_t* d_tile_prefix, uint32_t n_units, uint32_t n_tiles,
+                    const u64* d_out_len, u64* d_packed_off, uint8_t* d_packed);
 uint32_t run_lds_lane_order_check(hipStream_t st, uint32_t seed, uint32_t blocks, uint32_t rounds, uint32_t nkeys, uint32_t* d_bad);
 void launch_finalize_units(hipStream_t st, const u64* prefix, const BatchTables& bt, uint8_t* d_out,
                            u64* d_out_len, int32_t* d_status, int lznt1_eob);

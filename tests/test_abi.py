@@ -82,3 +82,22 @@ def test_pack_offsets():
     assert off.tolist() == [0, 16, 16, 48] and total == 64
     off, total = m.pack_offsets([5, 0, 17], align=1)
     assert off.tolist() == [0, 5, 5] and total == 22
+
+
+def test_plan_layout_is_the_max_compressed_size_layout():
+    """mscomp_amd_plan_layout (host arithmetic, no GPU): capacities from ms_max_compressed_size, aligned running offsets"""
+    import ctypes as C
+    import numpy as np
+    import ms_compress_amd as m
+    lib = m.load_library()
+    lens = np.array([0, 1, 4096, 65536, 70001, 1 << 20], dtype=np.uint64)
+    for fmt in (0, 2, 3, 4):
+        off = np.zeros(len(lens), dtype=np.uint64); cap = np.zeros(len(lens), dtype=np.uint64)
+        total = lib.mscomp_amd_plan_layout(fmt, len(lens), lens.ctypes.data, 16, off.ctypes.data, cap.ctypes.data)
+        pos = 0
+        for i, n in enumerate(lens):
+            want = m.max_compressed_size(fmt, int(n)) + (2 if fmt == 2 else 0)
+            assert int(cap[i]) == want and int(off[i]) == pos and pos % 16 == 0
+            pos += (want + 15) // 16 * 16
+        assert total == pos
+    assert lib.mscomp_amd_plan_layout(7, 1, lens.ctypes.data, 16, None, None) == 2 ** 64 - 1

@@ -257,3 +257,34 @@ def test_plan_reuse_replays_a_graph(oracle, gpu_ctx, fmt):
     m.compress_units(FMTS[fmt], big, ctx=gpu_ctx)
     for _ in range(2): run(plan, units, d_in1, d_out1, caps, out_off)          # re-capture after the scratch moved, replay
     plan.close()
+
+
+def test_compact_batch_packs_outputs_back_to_back(oracle, gpu_ctx):
+    """mscomp_amd_compact_batch: the outputs of a batch, which sit at out_off[i] with gaps, packed on the device"""
+    import ctypes as C
+    import torch
+    import ms_compress_amd as m
+    units = [cases.mixed_buffer()[:300000], b"", b"abc" * 1000, cases.mixed_buffer()[100000:170001], bytes(5)]
+    lens = np.array([len(u) for u in units], dtype=np.uint64)
+    lib = gpu_ctx.lib
+    dev = torch.device("cuda", 0)
+    for fmt in (2, 3, 4):
+        out_off = np.zeros(len(units), dtype=np.uint64); out_cap = np.zeros(len(units), dtype=np.uint64)
+        total = lib.mscomp_amd_plan_layout(fmt, len(units), lens.ctypes.data, 16, out_off.ctypes.data, out_cap.ctypes.data)
+        in_off, in_total = m.pack_offsets([int(x) for x in lens])
+        blob = np.zeros(in_total + 16, dtype=np.uint8)
+        for o, u in zip(in_off, units): blob[int(o): int(o) + len(u)] = np.frombuffer(u, dtype=np.uint8)
+        d_in = torch.from_numpy(blob).to(dev); d_out = torch.zeros(total + 16, dtype=torch.uint8, device=dev)
+        d_len = torch.zeros(len(units), dtype=torch.int64, device=dev); d_st = torch.zeros(len(units), dtype=torch.int32, device=dev)
+        p = m.Plan(gpu_ctx, fmt, in_off, lens, out_off, out_cap); p.execute(d_in, d_out, d_len, d_st); torch.cuda.synchronize(); p.close()
+        d_packed = torch.zeros(total + 16, dtype=torch.uint8, device=dev); d_poff = torch.zeros(len(units) + 1, dtype=torch.int64, device=dev)
+        st = lib.mscomp_amd_compact_batch(gpu_ctx._h, len(units), C.c_void_p(d_out.data_ptr()), out_off.ctypes.data, out_cap.ctypes.data,
+                                          C.c_void_p(d_len.data_ptr()), C.c_void_p(d_packed.data_ptr()), C.c_void_p(d_poff.data_ptr()))
+        assert st == 0
+        torch.cuda.synchronize()
+        want = b"".join(oracle.oracle_compress(fmt, u)[1] for u in units)
+        poff = d_poff.cpu().numpy()
+        assert int(poff[-1]) == len(want) and bytes(d_packed[: len(want)].cpu().numpy()) == want
+        acc = 0
+        for i, u in enumerate(units):
+            assert int(poff[i]) == acc; acc += len(oracle.oracle_compress(fmt, u)[1])
