@@ -281,13 +281,18 @@ __device__ __forceinline__ uint32_t lzd_decode_chunk(LzdLds& L, const uint8_t* _
 	const uint8_t* d = L.in + a0 + 2u;                                  // chunk data
 	const uint32_t n = in_size - 2u;                                     // 1..4096
 	// ---- flag groups: p -> p + 9 + popcount(flags) ----
+	// 64 positions at a time: every lane knows the step that would follow if a group started at its byte; the chain through the
+	// window is then followed with readlane (at most 8 steps of 9..17 bytes), and the visited lanes record themselves.
 	uint32_t G = 0;
 	{
-		uint32_t p = 0;
-		while (p < n) {
-			if (lane == 0) { L.gs[G] = (uint16_t)p; }
-			++G;
-			p += 9u + (uint32_t)__builtin_popcount(d[p]);
+		uint32_t e = 0;                                                  // where the chain enters the window
+		for (uint32_t wbase = 0; wbase < n; wbase += 64u) {
+			const uint32_t J = 9u + (uint32_t)__builtin_popcount(wbase + lane < n ? (uint32_t)d[wbase + lane] : 0u);
+			u64 visited = 0; uint32_t q = e;
+			while (q < 64u && wbase + q < n) { visited |= 1ull << q; q += (uint32_t)__builtin_amdgcn_readlane((int)J, (int)q); }
+			if ((visited >> lane) & 1ull) { L.gs[G + popc_below(visited)] = (uint16_t)(wbase + lane); }
+			G += (uint32_t)__builtin_popcountll(visited);
+			e = q >= 64u ? q - 64u : 0u;
 		}
 	}
 	__syncthreads();
