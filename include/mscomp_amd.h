@@ -91,6 +91,15 @@ MSCompStatus ms_deflate_end(mscomp_stream* stream);
 MSCompStatus lznt1_deflate_init(mscomp_stream* stream);
 MSCompStatus lznt1_deflate(mscomp_stream* stream, MSCompFlush flush);
 MSCompStatus lznt1_deflate_end(mscomp_stream* stream);
+/* ... and its streaming decompressor: ms_inflate_init / ms_inflate / ms_inflate_end (include/mscomp.h:174,198,213, src/mscomp.cpp:167-196;
+ * MSCOMP_NONE and MSCOMP_LZNT1) and lznt1_inflate_init / lznt1_inflate / lznt1_inflate_end (include/lznt1.h:59-61,
+ * src/lznt1_decompress.cpp:210-290). Every chunk is decoded on the GPU; xpress_inflate is not offloaded. */
+MSCompStatus ms_inflate_init(MSCompFormat format, mscomp_stream* stream);
+MSCompStatus ms_inflate(mscomp_stream* stream);
+MSCompStatus ms_inflate_end(mscomp_stream* stream);
+MSCompStatus lznt1_inflate_init(mscomp_stream* stream);
+MSCompStatus lznt1_inflate(mscomp_stream* stream);
+MSCompStatus lznt1_inflate_end(mscomp_stream* stream);
 
 /* ================= Part 2: batch interface (device pointers) ================= */
 typedef struct mscomp_amd_ctx  mscomp_amd_ctx;    /* one per (device, stream); owns scratch in HBM  */

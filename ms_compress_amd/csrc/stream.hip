@@ -27,9 +27,9 @@ struct DeflateState {                       // what lznt1_compress.cpp:32-40 kee
 	uint8_t* scratch = nullptr; size_t scratch_cap = 0;      // host staging of a batch's output
 };
 
-bool stream_ok(const mscomp_stream* s, MSCompFormat f)     // CHECK_STREAM (internal.h:481)
+bool stream_ok(const mscomp_stream* s, MSCompFormat f, bool compressing = true)     // CHECK_STREAM (internal.h:481)
 {
-	return s && s->format == f && s->compressing && !(s->in == nullptr && s->in_avail != 0) && !(s->out == nullptr && s->out_avail != 0);
+	return s && s->format == f && s->compressing == compressing && !(s->in == nullptr && s->in_avail != 0) && !(s->out == nullptr && s->out_avail != 0);
 }
 void take_in(mscomp_stream* s, size_t n)  { s->in += n;  s->in_total += n;  s->in_avail -= n; }
 void give_out(mscomp_stream* s, size_t n) { s->out += n; s->out_total += n; s->out_avail -= n; }
@@ -66,9 +66,158 @@ MSCompStatus write_chunk(mscomp_stream* s, DeflateState* st, const uint8_t* in, 
 	return MSCOMP_OK;
 }
 
+// ---- streaming decompression (lznt1_decompress.cpp:122-290) ----
+struct InflateState {                       // lznt1_decompress.cpp:27-34: one partial input chunk, one pending output chunk
+	bool end_of_stream = false;
+	uint8_t in[CHUNK + 2];
+	size_t in_needed = 0, in_avail = 0;
+	uint8_t out[CHUNK];
+	size_t out_pos = 0, out_avail = 0;
+};
+uint32_t rd16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+// one complete chunk (header included) -> its bytes, decoded on the GPU against the 4096-byte limit; any failure is DATA_ERROR (:160-166)
+MSCompStatus gpu_chunk(const uint8_t* chunk, size_t in_size, uint8_t* out, size_t* out_size)
+{
+	size_t len = CHUNK;
+	const MSCompStatus r = lznt1_decompress(chunk, in_size, out, &len);
+	if (r == MSCOMP_ERRNO || r == MSCOMP_MEM_ERROR) { return r; }
+	if (r != MSCOMP_OK) { return MSCOMP_DATA_ERROR; }
+	*out_size = len;
+	return MSCOMP_OK;
+}
+
+// lznt1_decompress_chunk_read (:122-209): the chunk at `in` (*in_len bytes are there); on return *in_len = bytes of it that were used
+MSCompStatus read_chunk(mscomp_stream* s, InflateState* st, const uint8_t* in, size_t* in_len)
+{
+	const uint32_t header = rd16(in);
+	if (header == 0) {                                               // :128-134
+		if (s->in_avail + st->in_avail != 2) { return MSCOMP_DATA_ERROR; }
+		*in_len = 2; st->end_of_stream = true;
+		return MSCOMP_OK;
+	}
+	const size_t in_size = (header & 0x0FFFu) + 3;
+	if (in_size > *in_len) {                                         // not all of the chunk is here yet (:136-143)
+		if (in != st->in) { memcpy(st->in, in, *in_len); }
+		st->in_needed = in_size - *in_len; st->in_avail = *in_len;
+		return MSCOMP_OK;
+	}
+	*in_len = in_size;
+	if ((header & 0x7000u) != 0x3000u) { return MSCOMP_DATA_ERROR; }   // :151
+	if (header & 0x8000u) {
+		size_t out_size = 0;
+		if (s->out_avail < CHUNK) {                                  // through the state's buffer (:155-172)
+			const MSCompStatus r = gpu_chunk(in, in_size, st->out, &out_size);
+			if (r != MSCOMP_OK) { return r; }
+			const size_t copy = out_size < s->out_avail ? out_size : s->out_avail;
+			memcpy(s->out, st->out, copy);
+			st->out_pos = copy; st->out_avail = out_size - copy;
+			give_out(s, copy);
+		} else {                                                     // straight into the caller's window (:175-188)
+			const MSCompStatus r = gpu_chunk(in, in_size, s->out, &out_size);
+			if (r != MSCOMP_OK) { return r; }
+			give_out(s, out_size);
+		}
+	} else {                                                         // stored chunk (:190-207)
+		const size_t out_size = in_size - 2;
+		if (s->out_avail < out_size) {
+			const size_t first = s->out_avail;
+			memcpy(s->out, in + 2, first);
+			memcpy(st->out, in + 2 + first, out_size - first);
+			st->out_pos = 0; st->out_avail = out_size - first;
+			give_out(s, first);
+		} else { memcpy(s->out, in + 2, out_size); give_out(s, out_size); }
+	}
+	return MSCOMP_OK;
+}
+bool possible_end(const mscomp_stream* s, const InflateState* st)     // :223-227
+{
+	return (!s->in_avail || (s->in_avail == 1 && s->in[0] == 0)) && (!st->in_avail || (st->in_avail == 1 && st->in[0] == 0)) && !st->out_avail;
+}
+
 } // namespace
 
 extern "C" {
+
+MSCompStatus lznt1_inflate_init(mscomp_stream* s)
+{
+	if (!s) { return MSCOMP_ARG_ERROR; }                     // INIT_STREAM (internal.h:473-480)
+	s->format = MSCOMP_LZNT1; s->compressing = false;
+	s->in = nullptr; s->out = nullptr; s->in_avail = 0; s->out_avail = 0; s->in_total = 0; s->out_total = 0;
+	s->error[0] = 0; s->warning[0] = 0; s->state = nullptr;
+	InflateState* st = new (std::nothrow) InflateState();
+	if (!st) { return MSCOMP_MEM_ERROR; }
+	s->state = reinterpret_cast<mscomp_internal_state*>(st);
+	return MSCOMP_OK;
+}
+
+MSCompStatus lznt1_inflate(mscomp_stream* s)
+{
+	InflateState* st = s ? reinterpret_cast<InflateState*>(s->state) : nullptr;
+	if (!stream_ok(s, MSCOMP_LZNT1, false) || !st) { return MSCOMP_ARG_ERROR; }               // :232
+	MSCompStatus r;
+	if (st->out_avail) {                                             // DUMP_OUT (internal.h:493-513)
+		const size_t k = st->out_avail < s->out_avail ? st->out_avail : s->out_avail;
+		memcpy(s->out, st->out + st->out_pos, k);
+		s->out += k; s->out_total += k;
+		if (st->out_avail == k) { s->out_avail -= k; st->out_avail = 0; }
+		else { s->out_avail = 0; st->out_pos += k; st->out_avail -= k; return MSCOMP_OK; }
+	}
+	if (st->end_of_stream) { return (s->in_avail || st->in_avail) ? MSCOMP_DATA_ERROR : MSCOMP_STREAM_END; }   // :237-241
+	if (st->in_avail) {                                              // APPEND_IN (internal.h:517-533) with the body of :243-252
+		for (;;) {
+			const size_t k = st->in_needed < s->in_avail ? st->in_needed : s->in_avail;
+			if (k) { memcpy(st->in + st->in_avail, s->in, k); st->in_avail += k; st->in_needed -= k; take_in(s, k); }
+			if (st->in_needed) { return MSCOMP_OK; }
+			size_t in_len = st->in_avail;
+			r = read_chunk(s, st, st->in, &in_len);
+			if (in_len != st->in_avail) { return MSCOMP_ARG_ERROR; }
+			if (r != MSCOMP_OK) { return r; }
+			if (st->end_of_stream) { return MSCOMP_STREAM_END; }
+			if (st->in_needed) { continue; }                         // that was only the header: now the rest of the chunk
+			break;
+		}
+		st->in_avail = 0;
+	}
+	while (s->out_avail && s->in_avail >= 2) {                       // :255-262
+		// a run of complete, well-formed chunks with 4096 bytes of room for each would be decoded one by one straight into the
+		// window: the same bytes come from ONE GPU batch (if it reports anything but success, go chunk by chunk to stop where the
+		// reference stops)
+		{
+			size_t k = 0, used = 0;
+			while ((k + 1) * CHUNK <= s->out_avail && s->in_avail - used >= 2) {
+				const uint32_t h = rd16(s->in + used);
+				const size_t sz = (h & 0x0FFFu) + 3;
+				if (h == 0 || (h & 0x7000u) != 0x3000u || sz > s->in_avail - used) { break; }
+				used += sz; ++k;
+			}
+			if (k >= 2) {
+				size_t len = k * CHUNK;
+				if (lznt1_decompress(s->in, used, s->out, &len) == MSCOMP_OK) { take_in(s, used); give_out(s, len); continue; }
+			}
+		}
+		size_t in_size = s->in_avail;
+		r = read_chunk(s, st, s->in, &in_size);
+		if (r != MSCOMP_OK) { return r; }
+		take_in(s, in_size);
+		if (st->end_of_stream) { return MSCOMP_STREAM_END; }
+	}
+	if (s->out_avail && s->in_avail) {                               // one byte left: half a header (:264-271)
+		st->in[0] = s->in[0]; st->in_needed = 1; st->in_avail = 1;
+		s->in += 1; s->in_total += 1; s->in_avail = 0;
+	}
+	return possible_end(s, st) ? MSCOMP_POSSIBLE_STREAM_END : MSCOMP_OK;
+}
+
+MSCompStatus lznt1_inflate_end(mscomp_stream* s)
+{
+	InflateState* st = s ? reinterpret_cast<InflateState*>(s->state) : nullptr;
+	if (!stream_ok(s, MSCOMP_LZNT1, false) || !st) { return MSCOMP_ARG_ERROR; }               // :276
+	const MSCompStatus r = possible_end(s, st) ? MSCOMP_OK : MSCOMP_DATA_ERROR;                // :281-285
+	delete st;
+	s->state = nullptr;
+	return r;
+}
 
 MSCompStatus lznt1_deflate_init(mscomp_stream* s)
 {
@@ -186,6 +335,33 @@ MSCompStatus ms_deflate_end(mscomp_stream* s)
 {
 	if (!s) { return MSCOMP_ARG_ERROR; }
 	if (s->format == MSCOMP_LZNT1) { return lznt1_deflate_end(s); }
+	if (s->format == MSCOMP_NONE) { return stream_ok(s, MSCOMP_NONE) ? MSCOMP_OK : MSCOMP_ARG_ERROR; }
+	return MSCOMP_ARG_ERROR;
+}
+// mscomp.cpp:167-196; the copy codec initialises and checks its inflate streams as COMPRESSING ones (mscomp.cpp:33,48-59)
+MSCompStatus ms_inflate_init(MSCompFormat format, mscomp_stream* s)
+{
+	if (format == MSCOMP_LZNT1) { return lznt1_inflate_init(s); }
+	if (format == MSCOMP_NONE) { return ms_deflate_init(MSCOMP_NONE, s); }
+	return MSCOMP_ARG_ERROR;                                  // Xpress: not offloaded (keep the reference's xpress_inflate); Xpress+Huffman: none in the reference
+}
+MSCompStatus ms_inflate(mscomp_stream* s)
+{
+	if (!s) { return MSCOMP_ARG_ERROR; }
+	if (s->format == MSCOMP_LZNT1) { return lznt1_inflate(s); }
+	if (s->format == MSCOMP_NONE) {
+		if (!stream_ok(s, MSCOMP_NONE)) { return MSCOMP_ARG_ERROR; }
+		const size_t n = s->in_avail < s->out_avail ? s->in_avail : s->out_avail;
+		if (n) { memcpy(s->out, s->in, n); }
+		give_out(s, n); take_in(s, n);
+		return MSCOMP_OK;
+	}
+	return MSCOMP_ARG_ERROR;
+}
+MSCompStatus ms_inflate_end(mscomp_stream* s)
+{
+	if (!s) { return MSCOMP_ARG_ERROR; }
+	if (s->format == MSCOMP_LZNT1) { return lznt1_inflate_end(s); }
 	if (s->format == MSCOMP_NONE) { return stream_ok(s, MSCOMP_NONE) ? MSCOMP_OK : MSCOMP_ARG_ERROR; }
 	return MSCOMP_ARG_ERROR;
 }

@@ -101,3 +101,76 @@ def test_copy_codec_and_argument_errors(gpu_ctx):
     assert mine.ms_deflate_init(2, C.byref(s)) == 0
     assert mine.ms_deflate_end(C.byref(s)) == -3                     # ended before MSCOMP_FINISH was answered with MSCOMP_STREAM_END
     assert mine.ms_deflate(C.byref(s), NO_FLUSH) == -2               # no state any more
+
+
+def drive_inflate(lib, fmt, stream, steps, tail_window, cap):
+    """steps: (bytes offered, output window). Afterwards everything left is offered with `tail_window` until the call makes no
+    progress, fails, or reports an end."""
+    for f in (lib.ms_inflate_init, lib.ms_inflate, lib.ms_inflate_end):
+        f.restype = C.c_int
+    lib.ms_inflate_init.argtypes = [C.c_int, C.POINTER(Stream)]
+    lib.ms_inflate.argtypes = [C.POINTER(Stream)]
+    lib.ms_inflate_end.argtypes = [C.POINTER(Stream)]
+    s = Stream()
+    assert lib.ms_inflate_init(fmt, C.byref(s)) == 0
+    inbuf = C.create_string_buffer(bytes(stream), max(1, len(stream)))
+    outbuf = C.create_string_buffer(cap + 8192)
+    ipos = opos = 0
+    trace = []
+
+    def call(offer, window):
+        nonlocal ipos, opos
+        offer = min(offer, len(stream) - ipos); window = min(window, cap - opos)
+        s.in_ = C.addressof(inbuf) + ipos; s.in_avail = offer
+        s.out = C.addressof(outbuf) + opos; s.out_avail = window
+        st = lib.ms_inflate(C.byref(s))
+        took, gave = offer - s.in_avail, window - s.out_avail
+        ipos += took; opos += gave
+        trace.append((st, took, gave, s.in_total, s.out_total))
+        return st, took + gave
+
+    alive = True
+    for offer, window in steps:
+        st, _ = call(offer, window)
+        if st < 0 or st == 1:
+            alive = False
+            break
+    for _ in range(100000):
+        if not alive:
+            break
+        st, progress = call(len(stream) - ipos, tail_window)
+        if st != 0 or progress == 0:
+            break
+    end = lib.ms_inflate_end(C.byref(s))
+    return outbuf.raw[:opos], trace, end
+
+
+def test_lznt1_inflate_matches_reference_call_by_call(oracle, gpu_ctx):
+    import ms_compress_amd as m
+    ref = oracle.load_ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    mine = m.load_library()
+    rnd = random.Random(11)
+    datas = [b"", b"x", cases.family("words", 4096, rnd), cases.family("lz", 12289, rnd), cases.family("random", 9000, rnd),
+             cases.mixed_buffer()[95000:95000 + 120000]]
+    streams = []
+    for d in datas:
+        c = oracle.oracle_compress(2, d)[1]
+        streams += [(c, len(d)), (c + b"\0\0", len(d)), (c + b"\0", len(d)), (c + c, 2 * len(d)), (c[: len(c) // 2], len(d)), (c, max(0, len(d) - 1))]
+    big = oracle.oracle_compress(2, datas[-1])[1]
+    streams += [(big[:1] + bytes([big[1] ^ 0x40]) + big[2:], len(datas[-1])), (big[:5000] + b"\0\0" + big[5002:], len(datas[-1])),
+                (big[:3000] + bytes(rnd.getrandbits(8) for _ in range(50)) + big[3050:], len(datas[-1]))]
+    n_cmp = 0
+    for stream, cap in streams:
+        plans = [([], 1 << 30), ([(4096, 4096)] * 8, 1 << 30), ([(1000, 700)] * 30, 100), ([(3, 5000)] * 40, 4096)]
+        for _ in range(3):
+            plans.append(([(rnd.choice((1, 2, 3, 17, 4097, 4098, 4099, 10000, 60000)), rnd.choice((0, 1, 100, 4095, 4096, 4097, 9000, 1 << 20)))
+                           for _ in range(rnd.randint(1, 40))], rnd.choice((1, 4095, 4096, 1 << 20))))
+        for steps, tail in plans:
+            want = drive_inflate(ref, 2, stream, steps, tail, cap)
+            got = drive_inflate(mine, 2, stream, steps, tail, cap)
+            assert got[1] == want[1], (len(stream), cap, steps[:4], tail, got[1][-3:], want[1][-3:])
+            assert got[0] == want[0] and got[2] == want[2]
+            n_cmp += 1
+    assert n_cmp >= 200
