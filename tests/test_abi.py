@@ -101,3 +101,22 @@ def test_plan_layout_is_the_max_compressed_size_layout():
             pos += (want + 15) // 16 * 16
         assert total == pos
     assert lib.mscomp_amd_plan_layout(7, 1, lens.ctypes.data, 16, None, None) == 2 ** 64 - 1
+
+
+def test_stream_object_has_the_reference_layout():
+    """mscomp_stream as the streaming tests bind it (include/mscomp/general.h:95-121, default build with error + warning texts):
+    576 bytes, the state pointer last"""
+    import ctypes as C
+
+    class Stream(C.Structure):
+        _fields_ = [("format", C.c_int), ("compressing", C.c_bool), ("in_", C.c_void_p), ("in_avail", C.c_size_t), ("in_total", C.c_size_t),
+                    ("out", C.c_void_p), ("out_avail", C.c_size_t), ("out_total", C.c_size_t), ("error", C.c_char * 256),
+                    ("warning", C.c_char * 256), ("state", C.c_void_p)]
+    assert C.sizeof(Stream) == 576 and Stream.state.offset == 568 and Stream.in_.offset == 8 and Stream.error.offset == 56
+    import ms_compress_amd as m
+    lib = m.load_library()
+    s = Stream()
+    lib.ms_deflate_init.argtypes = [C.c_int, C.POINTER(Stream)]
+    lib.ms_deflate_end.argtypes = [C.POINTER(Stream)]
+    assert lib.ms_deflate_init(0, C.byref(s)) == 0 and s.format == 0 and s.compressing and not s.state     # the copy codec needs no GPU
+    assert lib.ms_deflate_end(C.byref(s)) == 0
