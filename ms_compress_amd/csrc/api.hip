@@ -545,7 +545,11 @@ static MSCompStatus one_shot(MSCompFormat format, bool decompress, const uint8_t
 	if (!tl_ctx) { MSCompStatus s = mscomp_amd_ctx_create(dev, nullptr, &tl_ctx); if (s != MSCOMP_OK) { return s; } }
 	mscomp_amd_ctx* c = tl_ctx;
 	const size_t cap = *out_len;
-	if (!c->one_in.reserve(in_len + 64) || !c->one_out.reserve(cap + 64) || !c->one_meta.reserve(64)) { return MSCOMP_MEM_ERROR; }
+	// the device copy of the output never needs more than the format can produce from in_len bytes (a caller may pass a very generous
+	// capacity): LZNT1 chunks are at least 3 bytes and give at most 4096
+	size_t dev_cap = cap;
+	if (decompress && format == MSCOMP_LZNT1) { const size_t most = (in_len / 3 + 1) * 4096; if (most < dev_cap) { dev_cap = most; } }
+	if (!c->one_in.reserve(in_len + 64) || !c->one_out.reserve(dev_cap + 64) || !c->one_meta.reserve(64)) { return MSCOMP_MEM_ERROR; }
 	const uint64_t in_off[1] = { 0 }, in_ln[1] = { in_len }, out_off[1] = { 0 }, out_cp[1] = { cap };
 	uint8_t* d_in = static_cast<uint8_t*>(c->one_in.p); uint8_t* d_out = static_cast<uint8_t*>(c->one_out.p);
 	uint64_t* d_len = static_cast<uint64_t*>(c->one_meta.p); int32_t* d_st = reinterpret_cast<int32_t*>(d_len + 1);

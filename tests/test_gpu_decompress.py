@@ -141,3 +141,15 @@ def test_round_trip_full_size_units(oracle, gpu_ctx, fmt):
     q = m.Plan(gpu_ctx, f, c_off, clen, in_off, in_len, decompress=True); q.execute(d_c, d_back, d_len2, d_st2); torch.cuda.synchronize(); q.close()
     assert bool((d_st2 == 0).all()) and torch.equal(d_len2.cpu(), torch.from_numpy(in_len.astype(np.int64)))
     assert torch.equal(d_back[: len(blob)], d_in)
+
+
+def test_one_shot_lznt1_with_a_very_generous_capacity(oracle, gpu_ctx):
+    """*out_len may be far larger than anything the stream can produce: the device staging is sized by the input, not by the capacity"""
+    import ctypes as C
+    import ms_compress_amd as m
+    data = cases.mixed_buffer()[:50000]
+    comp = oracle.oracle_compress(2, data)[1]
+    lib = m.load_library()
+    out = C.create_string_buffer(len(data) + 16)
+    n = C.c_size_t(1 << 40)                                          # "a terabyte of room" (the buffer behind it is only as large as needed)
+    assert lib.ms_decompress(2, comp, len(comp), out, C.byref(n)) == 0 and n.value == len(data) and out.raw[: len(data)] == data
