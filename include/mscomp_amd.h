@@ -18,8 +18,14 @@
  * the current device; there is no CPU encoder in this library -- if no usable GPU/HIP runtime is present
  * the calls return MSCOMP_ERRNO and never fall back.
  *
+ * Part 1 also holds the rows SURVEY.md 8f lists next, each declared below with the reference file:line it replaces:
+ * the one-shot decompressors (ms_decompress, lznt1_decompress, xpress_decompress, xpress_huff_decompress) and the
+ * LZNT1 streaming compressor / decompressor with the reference's stream object (ms_deflate*, ms_inflate*, lznt1_deflate*,
+ * lznt1_inflate*). Same rule: the bytes come from the GPU, there is no CPU codec to fall back to.
+ *
  * Part 2 is the additive batch interface the GPU needs (SURVEY.md 8b "batch extension"): many independent
- * units (buffers) already resident in HBM, compressed in one pass, output written to HBM.
+ * units (buffers) already resident in HBM, compressed (or decompressed) in one pass, output written to HBM; plus
+ * capacity planning and device-side compaction of a batch's outputs.
  *
  * Plain C types only (no torch / HIP types in any signature; a hipStream_t is passed as void*).
  */
