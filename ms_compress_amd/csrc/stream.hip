@@ -316,7 +316,8 @@ MSCompStatus ms_deflate_init(MSCompFormat format, mscomp_stream* s)
 		s->error[0] = 0; s->warning[0] = 0; s->state = nullptr;
 		return MSCOMP_OK;
 	}
-	return MSCOMP_ARG_ERROR;                                  // Xpress: the reference's streaming compressor only returns errors; Xpress+Huffman: none
+	if (format == MSCOMP_XPRESS) { return MSCOMP_MEM_ERROR; }  // what the reference's unfinished xpress_deflate_init returns (xpress_compress.cpp:50-75)
+	return MSCOMP_ARG_ERROR;                                  // Xpress+Huffman: no entry in the reference's table (mscomp.cpp:141,147)
 }
 MSCompStatus ms_deflate(mscomp_stream* s, MSCompFlush flush)
 {
