@@ -162,6 +162,16 @@ def roofline(fmt, prof, in_bytes, out_bytes, steps):
             "kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
 
 
+def _cpu_timed(fn, fmt, units, caps, cores, budget_s):
+    """passes and seconds of fn over the units on `cores` C threads (oracle.loader.time_units: no interpreter between the calls)"""
+    from oracle import loader
+    dt1, st, _ = loader.time_units(fn, fmt, units, caps, cores, 1)
+    assert bool((st == 0).all()), "the CPU baseline reported an error status"
+    more = max(0, min(19, int(budget_s / max(dt1, 1e-3)) - 1))
+    dt = dt1 + (loader.time_units(fn, fmt, units, caps, cores, more)[0] if more else 0.0)
+    return 1 + more, dt
+
+
 def cpu_baseline(fmt, blob, budget_s=12.0):
     """The reference's own CPU encoder (oracle/_ref, compiled from /root/reference) -- or our C port when that file did not
     travel -- on this host's cores, over a bounded sample of the SAME workload (prefix of the batch, split on 64 KiB / 4 KiB
@@ -175,18 +185,8 @@ def cpu_baseline(fmt, blob, budget_s=12.0):
     data = blob[:sample].tobytes()
     piece = max(65536, sample // cores // 65536 * 65536)
     slices = [data[o:o + piece] for o in range(0, sample, piece)]
-    fn = (lambda d: loader.ref_compress(fmt, d)) if ref is not None else (lambda d: loader.oracle_compress(fmt, d))
-    passes, t0 = 0, time.perf_counter()
-    while True:
-        th = [threading.Thread(target=fn, args=(s,)) for s in slices]   # ctypes releases the GIL inside the C call
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        passes += 1
-        if time.perf_counter() - t0 > budget_s or passes >= 20:
-            break
-    dt = time.perf_counter() - t0
+    caps = [loader.load_oracle().orc_max_compressed_size(fmt, len(x)) + 2 for x in slices]
+    passes, dt = _cpu_timed(ref.ms_compress if ref is not None else None, fmt, slices, caps, len(slices), budget_s)
     return {"value": round(sample * passes / dt / 1e6, 1), "unit": "MB/s", "cores": len(slices), "kind": kind,
             "sample": "%d passes over the first %d B of the batch, %d threads x %d B independent ms_compress calls" % (passes, sample, len(slices), piece)}
 
@@ -204,32 +204,11 @@ def cpu_decompress_baseline(fmt, blob, budget_s=3.0):
     data = blob[:sample].tobytes()
     comp = loader.ref_compress if ref is not None else loader.oracle_compress
     units = [data[o:o + unit] for o in range(0, sample, unit)]
-    pool = [[] for _ in range(min(cores, len(units)))]
-    for i, u in enumerate(units):
-        pool[i % len(pool)].append((comp(fmt, u)[1], len(u)))
-
-    import ctypes as C
-    lib = ref if ref is not None else loader.load_oracle()
-    fn = lib.ms_decompress if ref is not None else lib.orc_decompress
-
-    def work(items):                               # one output buffer per thread; the GIL is released inside the C call
-        out = C.create_string_buffer(unit + 64)
-        ln = C.c_size_t(0)
-        for c, n in items:
-            ln.value = n
-            fn(fmt, c, len(c), out, C.byref(ln))
-    passes, t0 = 0, time.perf_counter()
-    while True:
-        th = [threading.Thread(target=work, args=(it,)) for it in pool]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        passes += 1
-        if time.perf_counter() - t0 > budget_s or passes >= 20:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": round(sample * passes / dt / 1e6, 1), "unit": "MB/s (output)", "cores": len(pool), "kind": kind,
+    streams = [comp(fmt, u)[1] for u in units]
+    threads = min(cores, len(units))
+    fn = ref.ms_decompress if ref is not None else loader.load_oracle().orc_decompress
+    passes, dt = _cpu_timed(fn, fmt, streams, [len(u) for u in units], threads, budget_s)
+    return {"value": round(sample * passes / dt / 1e6, 1), "unit": "MB/s (output)", "cores": threads, "kind": kind,
             "sample": "%d passes over the first %d B of the batch as %d independent ms_decompress calls of %d B" % (passes, sample, len(units), unit)}
 
 

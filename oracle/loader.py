@@ -49,6 +49,8 @@ def load_oracle():
         lib.orc_compress_units.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_int]
         lib.orc_compress_units.restype = C.c_int
+        lib.orc_time_units.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        lib.orc_time_units.restype = C.c_double
         _oracle = lib
     return _oracle
 
@@ -95,6 +97,22 @@ def oracle_decompress_ex(fmt, data, cap):
     lib = load_oracle()
     st, out = _one_shot(lib.orc_decompress, fmt, data, cap)
     return st, out, bool(lib.orc_last_undefined())
+
+
+def time_units(fn, fmt, units, caps, threads, passes):
+    """Seconds for `passes` passes of fn (a ctypes function with the one-shot signature, e.g. load_ref().ms_decompress; None = the
+    oracle's compressor) over independent units, on `threads` C threads (no interpreter between the calls). Returns (seconds, statuses, lengths)."""
+    import numpy as np
+    lib = load_oracle()
+    in_off = np.zeros(len(units) + 1, dtype=np.uint64); in_off[1:] = np.cumsum([len(u) for u in units])
+    out_off = np.zeros(len(units) + 1, dtype=np.uint64); out_off[1:] = np.cumsum([int(c) for c in caps])
+    blob = np.frombuffer(b"".join(bytes(u) for u in units) or b"\0", dtype=np.uint8)
+    out = np.zeros(int(out_off[-1]) + 64, dtype=np.uint8)
+    out_len = np.zeros(len(units), dtype=np.uint64); status = np.zeros(len(units), dtype=np.int32)
+    fp = C.cast(fn, C.c_void_p) if fn is not None else None
+    dt = lib.orc_time_units(fp, fmt, blob.ctypes.data, in_off.ctypes.data, len(units), out.ctypes.data, out_off.ctypes.data,
+                            out_len.ctypes.data, status.ctypes.data, threads, passes)
+    return dt, status, out_len
 
 
 def ref_compress(fmt, data, cap=None):

@@ -759,3 +759,44 @@ int orc_compress_units(int format, const uint8_t* in, const uint64_t* in_off, si
 	pthread_attr_destroy(&at);
 	return 0;
 }
+
+/* The same driver for ANY function with the one-shot signature (the compiled reference's ms_compress / ms_decompress, passed
+ * as a pointer by bench.py): `passes` passes over the units, seconds spent inside (no interpreter between the calls). */
+#include <time.h>
+typedef int (*one_shot_fn)(int, const uint8_t*, size_t, uint8_t*, size_t*);
+typedef struct { units_job j; one_shot_fn fn; } fn_job;
+static void* fn_worker(void* arg)
+{
+	fn_job* f = (fn_job*)arg; units_job* j = &f->j;
+	for (;;) {
+		pthread_mutex_lock(&j->mu);
+		const size_t i0 = j->next, i1 = (i0 + 4 < j->n_units) ? i0 + 4 : j->n_units;
+		j->next = i1;
+		pthread_mutex_unlock(&j->mu);
+		if (i0 >= j->n_units) { return NULL; }
+		for (size_t i = i0; i < i1; ++i) {
+			size_t ol = (size_t)(j->out_off[i + 1] - j->out_off[i]);
+			const int st = f->fn(j->format, j->in + j->in_off[i], (size_t)(j->in_off[i + 1] - j->in_off[i]), j->out + j->out_off[i], &ol);
+			j->status[i] = st; j->out_len[i] = st == ORC_OK ? ol : 0;
+		}
+	}
+}
+double orc_time_units(void* fn, int format, const uint8_t* in, const uint64_t* in_off, size_t n_units,
+                      uint8_t* out, const uint64_t* out_off, uint64_t* out_len, int32_t* status, int threads, int passes)
+{
+	struct timespec t0, t1;
+	if (threads < 1) { threads = 1; }
+	if (threads > 256) { threads = 256; }
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (int p = 0; p < passes; ++p) {
+		fn_job f = { { format, in, in_off, n_units, out, out_off, out_len, status, 0, PTHREAD_MUTEX_INITIALIZER }, fn ? (one_shot_fn)fn : (one_shot_fn)orc_compress };
+		pthread_t th[256]; pthread_attr_t at; int started = threads;
+		pthread_attr_init(&at); pthread_attr_setstacksize(&at, 8u << 20);
+		for (int t = 1; t < threads; ++t) { if (pthread_create(&th[t], &at, fn_worker, &f)) { started = t; break; } }
+		fn_worker(&f);
+		for (int t = 1; t < started; ++t) { pthread_join(th[t], NULL); }
+		pthread_attr_destroy(&at);
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -42,6 +42,11 @@ void orc_xpress_match_table(const uint8_t* buf, size_t n, uint32_t max_offset, u
 int orc_compress_units(int format, const uint8_t* in, const uint64_t* in_off, size_t n_units,
                        uint8_t* out, const uint64_t* out_off, uint64_t* out_len, int32_t* status, int threads);
 
+/* `passes` passes of fn(format, unit i ...) over n_units independent units on `threads` threads; fn = any one-shot function (NULL:
+ * orc_compress); returns the seconds spent. in_off / out_off have n_units + 1 entries (unit i = [off[i], off[i+1])). */
+double orc_time_units(void* fn, int format, const uint8_t* in, const uint64_t* in_off, size_t n_units,
+                      uint8_t* out, const uint64_t* out_off, uint64_t* out_len, int32_t* status, int threads, int passes);
+
 #ifdef __cplusplus
 }
 #endif
