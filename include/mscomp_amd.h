@@ -144,7 +144,7 @@ MSCompStatus mscomp_amd_compress_batch(mscomp_amd_ctx* ctx, MSCompFormat format,
 /* The same for decompression: unit i holds one compressed buffer (what one ms_decompress call takes), out_cap[i] is the
  * capacity the caller passes in *out_len. d_status[i] is MSCOMP_OK / MSCOMP_BUF_ERROR / MSCOMP_DATA_ERROR exactly as the
  * reference's one-shot call returns them; d_out_len[i] is the decompressed size on MSCOMP_OK (0 otherwise; the output bytes
- * of a failed unit are unspecified). Executed with mscomp_amd_plan_execute. Units are limited to 4 GiB - 256 of input. */
+ * of a failed unit are unspecified). Executed with mscomp_amd_plan_execute. Units are limited to 4 GiB - 4096 of input. */
 MSCompStatus mscomp_amd_plan_create_decompress(mscomp_amd_ctx* ctx, MSCompFormat format, size_t n_units,
                                                const uint64_t* in_off, const uint64_t* in_len,
                                                const uint64_t* out_off, const uint64_t* out_cap, mscomp_amd_plan** plan);

@@ -194,7 +194,7 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 	for (size_t i = 0; i < n_units; ++i) {
 		h[i] = in_off[i]; h[n_units + i] = in_len[i]; h[2 * n_units + i] = out_off[i]; h[3 * n_units + i] = out_cap[i];
 		h_cp[i] = (uint32_t)chunks;
-		if (decompress && in_len[i] > 0xFFFFFF00u) { delete p; return MSCOMP_ARG_ERROR; }   // chunk offsets inside a unit are 32-bit
+		if (decompress && in_len[i] > 0xFFFFF000u) { delete p; return MSCOMP_ARG_ERROR; }   // offsets inside a unit are 32-bit (4 GiB - 4096 at most)
 		chunks += chunks_of(format, decompress, in_len[i]);
 		total += in_len[i];
 		if (chunks > 0x7FFFFFF0u) { delete p; return MSCOMP_ARG_ERROR; }

@@ -570,7 +570,7 @@ __global__ __launch_bounds__(64) void xpd_kernel(const uint8_t* __restrict__ d_i
 		if (lane == 0) { d_status[u] = ok ? 0 : -3; d_out_len[u] = 0; }
 		return;
 	}
-	// ---- input ring: q = offset from the 16-byte aligned base (32 bits: units are below 4 GiB - 256); block b = q in [1024 b, 1024 (b+1)) ----
+	// ---- input ring: q = offset from the 16-byte aligned base (32 bits: units are below 4 GiB - 4096); block b = q in [1024 b, 1024 (b+1)) ----
 	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
 	const uint8_t* ab = src - a0;
 	const uint32_t endq = a0 + n;
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(64) void xhd_parse_kernel(const uint8_t* __restrict
 	// ---- input ring (see xpd_kernel) ----
 	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
 	const uint8_t* ab = src - a0;
-	const uint32_t endq = a0 + n;                                        // units are below 4 GiB - 256
+	const uint32_t endq = a0 + n;                                        // units are below 4 GiB - 4096
 	uint32_t loaded = 0;                                                 // blocks of 2048 input bytes brought to LDS so far (the last two are resident)
 	// a block is loaded when the walk gets there (one HBM round trip per 2 KiB of input: nothing next to ~5000 symbols); values that
 	// live across the walk in registers (a prefetched block) made the compiler wait for memory and shuffle them on every symbol
@@ -751,7 +751,8 @@ __global__ __launch_bounds__(64) void xhd_parse_kernel(const uint8_t* __restrict
 		_Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) { const u64 q_ = (u64)loaded * XHD_INB + ((uint32_t)i_ * 64u + lane) * 16u; \
 			*reinterpret_cast<uint4*>(b_ + ((uint32_t)i_ * 64u + lane) * 16u) = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } \
 		++loaded; __syncthreads(); }
-	#define XHD_NEED(q, margin) while ((u64)loaded * XHD_INB < (u64)(q) + (margin) && (u64)loaded * XHD_INB < endq) { XHD_BLOCK() }
+	// loaded * 2048 never lies behind the walk, so the distance to it is a plain 32-bit difference (units end below 4 GiB - 4096)
+	#define XHD_NEED(q, margin) while (loaded * XHD_INB - (q) < (margin) && loaded * XHD_INB < endq) { XHD_BLOCK() }
 	XHD_BLOCK() XHD_BLOCK()
 	auto rb = [&](uint32_t q) -> uint32_t { return S.in[q & (2u * XHD_INB - 1u)]; };
 	uint32_t ip = a0;
@@ -803,7 +804,7 @@ __global__ __launch_bounds__(64) void xhd_parse_kernel(const uint8_t* __restrict
 		XHD_NEED(ip, 320u)
 		uint32_t mask = (rb(ip) << 16) | (rb(ip + 1) << 24) | rb(ip + 2) | (rb(ip + 3) << 8);   // Bitstream.h:44
 		uint32_t bits = 32; ip += 4u;
-		const u64 chunk_end = op + 65536u;
+		uint32_t prod = 0;                                               // bytes of this chunk so far, saturating
 		bool stream_end = false;
 		#define XHD_SKIP(k) { mask <<= (k); bits -= (k); if (bits < 16u && ip + 2u <= endq) { XHD_NEED(ip, 2u) mask |= (rb(ip) | (rb(ip + 1) << 8)) << (16u - bits); bits |= 16u; ip += 2u; } }
 		#define XHD_MASK_ZERO() (bits == 0 || (mask >> (32u - bits)) == 0)
@@ -812,13 +813,13 @@ __global__ __launch_bounds__(64) void xhd_parse_kernel(const uint8_t* __restrict
 			if (f_) { n_ = f_ & 0xFu; sym = f_ >> 4; if (n_ > r_) { sym = 0xFFFFu; } else { XHD_SKIP(n_) } } \
 			else { n_ = 1; while (x_ >= S.lims[n_]) { ++n_; } \
 				if (n_ > r_) { sym = 0xFFFFu; } else { XHD_SKIP(n_) const uint32_t s_ = S.poss[n_] + ((x_ - S.lims[n_ - 1u]) >> (15u - n_)); sym = s_ >= 512u ? 0xFFFFu : S.syms[s_]; } } }
-		while (op < chunk_end || !XHD_MASK_ZERO()) {
+		while (prod < 65536u || !XHD_MASK_ZERO()) {
 			uint32_t sym;
 			XHD_DECODE(sym)
 			if (sym < 0x100u) {
 				if (op == cap) { status = -5; break; }
 				XHD_EMIT(0x80000000u | sym)
-				++op;
+				++op; ++prod;
 			} else {
 				if (sym == 0xFFFFu) { status = -3; break; }
 				if (sym == 0x100u && ip == endq && XHD_MASK_ZERO()) { stream_end = true; break; }   // :91
@@ -846,7 +847,7 @@ __global__ __launch_bounds__(64) void xhd_parse_kernel(const uint8_t* __restrict
 				XHD_SKIP(ob)
 				if (off > op) { status = -3; break; }                    // :120
 				if (len > cap - op) { status = -5; break; }              // :121
-				op += len;
+				op += len; prod = prod + len < prod ? 0xFFFFFFFFu : prod + len;
 				while (len > LZT_MAXLEN) { XHD_EMIT(off | (LZT_MAXLEN << 16)) len -= LZT_MAXLEN; }
 				XHD_EMIT(off | (len << 16))
 			}
