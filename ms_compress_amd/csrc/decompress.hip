@@ -1,5 +1,13 @@
 // decompress.hip -- gfx950 decompressors, batch form: n independent units resident in HBM.
 //
+//   LZNT1           lzd_seg_kernel -> lzd_verify_kernel -> scan -> lzd_chunk_kernel<false> -> lzd_finalize_kernel -> lzd_chunk_kernel<true>
+//                   (chunk-parallel; the header chain and the output offsets are speculated and verified)        [this comment]
+//   Xpress          xpd_kernel            one wave walks and copies one stream (8 KiB window in an LDS ring)      [comment at the kernel]
+//   Xpress+Huffman  xhd_parse_kernel      one wave walks the symbols of one buffer and writes 32-bit tokens       [comment at the kernel]
+//                   lz_copy_kernel        tokens -> bytes, 64 at a time (sources chased with ds_bpermute / LDS / HBM)
+// Per unit, status and length are what the reference's one-shot call returns (MSCOMP_OK / MSCOMP_BUF_ERROR / MSCOMP_DATA_ERROR); the
+// oracle restates those semantics (oracle/mscomp_oracle.c) and tests/test_gpu_decompress.py compares both with the compiled reference.
+//
 // LZNT1 follows the one-shot semantics of the reference, which is its streaming inflate driven once over the whole
 // buffer (/root/reference/src/lznt1_decompress.cpp:122-290 through ALL_AT_ONCE_WRAPPER_DECOMPRESS,
 // /root/reference/include/mscomp/internal.h:616-630):
