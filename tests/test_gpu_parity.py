@@ -288,3 +288,28 @@ def test_compact_batch_packs_outputs_back_to_back(oracle, gpu_ctx):
         acc = 0
         for i, u in enumerate(units):
             assert int(poff[i]) == acc; acc += len(oracle.oracle_compress(fmt, u)[1])
+
+
+def test_one_shot_calls_from_several_host_threads(oracle, gpu_ctx):
+    """The reference's one-shot calls are reentrant; here every calling host thread gets its own GPU context. Four threads compress
+    and decompress different buffers of all three formats at the same time through the host-pointer entry points."""
+    import threading
+    import ms_compress_amd as m
+    bufs = [cases.mixed_buffer()[k * 50000: k * 50000 + 120000 + 1000 * k] for k in range(4)]
+    errors = []
+
+    def work(k):
+        try:
+            for rep in range(3):
+                for fmt in (2, 3, 4):
+                    c = m.compress(fmt, bufs[k])
+                    assert c == oracle.oracle_compress(fmt, bufs[k])[1], ("compress", k, fmt)
+                    assert m.decompress(fmt, c, len(bufs[k])) == bufs[k], ("decompress", k, fmt)
+        except Exception as e:                     # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
