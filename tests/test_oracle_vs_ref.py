@@ -95,3 +95,19 @@ def test_decompress_semantics(oracle, ref, fmt):
         assert (so, oo) == (sr, orf), (fmt, len(stream), cap, so, sr)
         asked += 1
     assert asked > len(streams) * 0.9
+
+
+def test_threaded_cpu_baseline_driver(oracle, ref):
+    """bench.py's CPU baselines: orc_time_units drives the reference's ms_compress / ms_decompress over independent units on C threads
+    and must hand back what single calls give"""
+    data = cases.mixed_buffer()
+    units = [data[o:o + 65536] for o in range(0, 5 * 65536, 65536)]
+    for fmt in (2, 3, 4):
+        caps = [ref.ms_max_compressed_size(fmt, len(u)) for u in units]
+        dt, st, ln = oracle.time_units(ref.ms_compress, fmt, units, caps, 3, 2)
+        comp = [oracle.ref_compress(fmt, u)[1] for u in units]
+        assert dt > 0 and (st == 0).all() and [int(x) for x in ln] == [len(c) for c in comp]
+        dt, st, ln = oracle.time_units(ref.ms_decompress, fmt, comp, [len(u) for u in units], 3, 2)
+        assert (st == 0).all() and [int(x) for x in ln] == [len(u) for u in units]
+        dt, st, ln = oracle.time_units(None, fmt, units, caps, 2, 1)                 # the oracle's own compressor
+        assert (st == 0).all() and [int(x) for x in ln] == [len(c) for c in comp]
