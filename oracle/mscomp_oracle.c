@@ -671,6 +671,7 @@ static int xh_decompress_chunk_o(const uint8_t** pin, const uint8_t* in_end, uin
 	if (xh_decode_symbol(d, &b) == 0x100 && b.in == b.end && xh_mask_is_zero(&b)) { *pin = b.in; return 1; }     /* :130-134 */
 	return 0;
 }
+static __thread uint64_t* orc_xh_starts; static __thread size_t orc_xh_nstarts, orc_xh_maxstarts;
 static int xpress_huff_decompress_o(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)
 {
 	const size_t cap = *out_len;
@@ -685,6 +686,7 @@ static int xpress_huff_decompress_o(const uint8_t* in, size_t n, uint8_t* out, s
 			if (ip != in_end) { free(d); return ORC_DATA_ERROR; }
 			break;
 		}
+		if (orc_xh_starts && orc_xh_nstarts < orc_xh_maxstarts) { orc_xh_starts[orc_xh_nstarts] = (uint64_t)(ip - in); } if (orc_xh_starts) { ++orc_xh_nstarts; }
 		for (unsigned i = 0; i < 256; ++i) { cl[2 * i] = ip[i] & 0xF; cl[2 * i + 1] = ip[i] >> 4; }
 		ip += 256;
 		if (!xh_set_code_lengths(d, cl)) { free(d); return ORC_DATA_ERROR; }
@@ -799,4 +801,19 @@ double orc_time_units(void* fn, int format, const uint8_t* in, const uint64_t* i
 	}
 	clock_gettime(CLOCK_MONOTONIC, &t1);
 	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* research helper (chunk-parallel Xpress-Huffman decoding): where do the chunks of a stream start? Decodes the stream
+ * (cap bytes of room) and records the input offset of every chunk's table; returns the number of chunks or a negative status. */
+long orc_xh_chunk_starts(const uint8_t* in, size_t n, size_t cap, uint64_t* starts, size_t max_starts)
+{
+	uint8_t* out = (uint8_t*)malloc(cap + 64);
+	if (!out) { return ORC_MEM_ERROR; }
+	size_t len = cap;
+	orc_xh_starts = starts; orc_xh_nstarts = 0; orc_xh_maxstarts = max_starts;
+	const int st = xpress_huff_decompress_o(in, n, out, &len);
+	const long k = (long)orc_xh_nstarts;
+	orc_xh_starts = NULL;
+	free(out);
+	return st == ORC_OK ? k : st;
 }
