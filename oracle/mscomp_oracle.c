@@ -581,6 +581,9 @@ static int xpress_huff_compress_o(const uint8_t* d, size_t n, uint8_t* out, size
  * its chunk loop (:39-129). The fast loop (:50-84) decides nothing differently from the checked loop (:87-127) while it runs
  * (>= 13 input bytes and >= 16 output bytes away from the ends), so the checked loop is restated for every symbol.
  * InputBitstream: Bitstream.h:34-106; HuffmanDecoder<15,512>: HuffmanDecoder.h:28-114. */
+/* research hooks (tools/xh_marker_study.py, tools/xh_depth_study.py): chunk starts, copy-chain depth per output byte */
+static __thread uint64_t* orc_xh_starts; static __thread size_t orc_xh_nstarts, orc_xh_maxstarts;
+static __thread uint32_t* orc_xh_depth;      /* research: copy-chain depth per output byte (0 = literal) */
 typedef struct { const uint8_t* in; const uint8_t* end; uint32_t mask; unsigned bits; } xh_ibs;
 static inline uint32_t xh_peek(const xh_ibs* b, unsigned n) { return (b->mask >> 16) >> (16 - n); }              /* Bitstream.h:55 */
 static inline int xh_mask_is_zero(const xh_ibs* b) { return b->bits == 0 || (b->mask >> (32 - b->bits)) == 0; } /* :58 */
@@ -639,6 +642,7 @@ static int xh_decompress_chunk_o(const uint8_t** pin, const uint8_t* in_end, uin
 		if (sym == 0x100 && b.in == b.end && xh_mask_is_zero(&b)) { *pin = b.in; *pop = op; return 1; }           /* :91 */
 		if (sym < 0x100) {
 			if (op == cap) { return ORC_BUF_ERROR; }
+			if (orc_xh_depth) { orc_xh_depth[op] = 0; }
 			out_base[op++] = (uint8_t)sym;
 		} else {
 			uint32_t len = sym & 0xF, off;
@@ -664,6 +668,7 @@ static int xh_decompress_chunk_o(const uint8_t** pin, const uint8_t* in_end, uin
 			}
 			if (off > op) { return ORC_DATA_ERROR; }                                                              /* :120 */
 			if (len > cap - op) { return ORC_BUF_ERROR; }                                                         /* :121 */
+			if (orc_xh_depth) { for (uint32_t i = 0; i < len; ++i) { orc_xh_depth[op + i] = orc_xh_depth[op + i - off] + 1; } }
 			for (uint32_t i = 0; i < len; ++i) { out_base[op] = out_base[op - off]; ++op; }
 		}
 	}
@@ -671,7 +676,6 @@ static int xh_decompress_chunk_o(const uint8_t** pin, const uint8_t* in_end, uin
 	if (xh_decode_symbol(d, &b) == 0x100 && b.in == b.end && xh_mask_is_zero(&b)) { *pin = b.in; return 1; }     /* :130-134 */
 	return 0;
 }
-static __thread uint64_t* orc_xh_starts; static __thread size_t orc_xh_nstarts, orc_xh_maxstarts;
 static int xpress_huff_decompress_o(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)
 {
 	const size_t cap = *out_len;
@@ -816,4 +820,18 @@ long orc_xh_chunk_starts(const uint8_t* in, size_t n, size_t cap, uint64_t* star
 	orc_xh_starts = NULL;
 	free(out);
 	return st == ORC_OK ? k : st;
+}
+
+/* research helper: how long are the copy chains of a stream? depth[i] = 0 for a literal byte, else depth of its source + 1
+ * (depth: cap entries). Returns the decoded length or a negative status. */
+long long orc_xh_copy_depths(const uint8_t* in, size_t n, size_t cap, uint32_t* depth)
+{
+	uint8_t* out = (uint8_t*)malloc(cap + 64);
+	if (!out) { return ORC_MEM_ERROR; }
+	size_t len = cap;
+	orc_xh_depth = depth;
+	const int st = xpress_huff_decompress_o(in, n, out, &len);
+	orc_xh_depth = NULL;
+	free(out);
+	return st == ORC_OK ? (long long)len : st;
 }
