@@ -553,7 +553,7 @@ void launch_lzd_finalize(hipStream_t st, const BatchTables& bt, const LzdBufs& b
 // xpress_decompress (/root/reference/src/xpress_decompress.cpp:405-462, READ_SYMBOL :62-107): a stream is one chain of tokens - where
 // a token starts depends on every token before it (32-bit flag words, 1 / 2 / 3 / 4 / 6 / 10-byte tokens, a length nibble shared
 // by two matches) - so a stream is decoded by one wave, streams in parallel. All lanes run the token walk (it is uniform).
-// The input is staged through a 2 KiB LDS ring (the next 1 KiB block is in flight in registers), the output through a 10 KiB ring
+// The input is staged through a 2 KiB LDS ring (1 KiB blocks, loaded when the walk gets there), the output through a 10 KiB ring
 // from which matches are copied (offsets reach 8192 bytes back) and which goes to HBM in 2 KiB pieces: 12.3 KiB of LDS, 13
 // streams per CU. A literal run and a match are moved by the lanes together. The 8 bytes at the next token are fetched (3
 // aligned dword reads) before the current token's bytes are moved, so a token costs about one LDS round trip.
