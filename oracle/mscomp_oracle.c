@@ -835,3 +835,51 @@ long long orc_xh_copy_depths(const uint8_t* in, size_t n, size_t cap, uint32_t* 
 	free(out);
 	return st == ORC_OK ? (long long)len : st;
 }
+
+/* research helper: ONE chunk of an Xpress-Huffman stream, parsed without its output -- what a speculative chunk wave would
+ * compute. `at` = offset of the chunk's 256-byte table. res[0] = offset where the next chunk starts, res[1] = bytes the chunk produces,
+ * res[2] = how far its matches reach in front of the chunk's first byte (max of offset - bytes produced so far, 0 if none), res[3] = tokens.
+ * Returns 0 (chunk done), 1 (the stream ends here) or a negative status (bad table / bad data; capacity is not checked). */
+int orc_xh_parse_chunk(const uint8_t* in, size_t n, size_t at, uint64_t res[4])
+{
+	xh_dec d; uint8_t cl[512];
+	res[0] = res[1] = res[2] = res[3] = 0;
+	if (n - at < 260) { return ORC_DATA_ERROR; }
+	for (unsigned i = 0; i < 256; ++i) { cl[2 * i] = in[at + i] & 0xF; cl[2 * i + 1] = in[at + i] >> 4; }
+	if (!xh_set_code_lengths(&d, cl)) { return ORC_DATA_ERROR; }
+	const uint8_t* p = in + at + 256; const uint8_t* in_end = in + n;
+	xh_ibs b = { p + 4, in_end, (get16(p) << 16) | get16(p + 2), 32 };
+	uint64_t op = 0, reach = 0, ntok = 0;
+	int ended = 0;
+	while (op < 65536 || !xh_mask_is_zero(&b)) {
+		const unsigned sym = xh_decode_symbol(&d, &b);
+		if (sym == XH_INVALID) { return ORC_DATA_ERROR; }
+		if (sym == 0x100 && b.in == b.end && xh_mask_is_zero(&b)) { ended = 1; break; }
+		++ntok;
+		if (sym < 0x100) { ++op; continue; }
+		uint32_t len = sym & 0xF, off;
+		if (len == 0xF) {
+			if (b.end - b.in < 1) { return ORC_DATA_ERROR; }
+			if ((len = *b.in++) == 0xFF) {
+				if (b.end - b.in < 2) { return ORC_DATA_ERROR; }
+				len = get16(b.in); b.in += 2;
+				if (len == 0) { if (b.end - b.in < 4) { return ORC_DATA_ERROR; } len = get32(b.in); b.in += 4; }
+				if (len < 0xF) { return ORC_DATA_ERROR; }
+				len -= 0xF;
+			}
+			len += 0xF;
+		}
+		len += 3;
+		const unsigned off_bits = (sym >> 4) & 0xF;
+		if (off_bits > b.bits) { return ORC_DATA_ERROR; }
+		off = xh_peek(&b, off_bits) + (1u << off_bits); xh_skip(&b, off_bits);
+		if (off > op && off - op > reach) { reach = off - op; }
+		op += len;
+	}
+	if (!ended) {
+		const uint8_t* keep = b.in;
+		if (xh_decode_symbol(&d, &b) == 0x100 && b.in == b.end && xh_mask_is_zero(&b)) { ended = 1; } else { b.in = keep; }
+	}
+	res[0] = (uint64_t)(b.in - in); res[1] = op; res[2] = reach; res[3] = ntok;
+	return ended;
+}
