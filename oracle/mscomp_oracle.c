@@ -584,6 +584,7 @@ static int xpress_huff_compress_o(const uint8_t* d, size_t n, uint8_t* out, size
 /* research hooks (tools/xh_marker_study.py, tools/xh_depth_study.py): chunk starts, copy-chain depth per output byte */
 static __thread uint64_t* orc_xh_starts; static __thread size_t orc_xh_nstarts, orc_xh_maxstarts;
 static __thread uint32_t* orc_xh_depth;      /* research: copy-chain depth per output byte (0 = literal) */
+static __thread int orc_xh_depth_mode;
 typedef struct { const uint8_t* in; const uint8_t* end; uint32_t mask; unsigned bits; } xh_ibs;
 static inline uint32_t xh_peek(const xh_ibs* b, unsigned n) { return (b->mask >> 16) >> (16 - n); }              /* Bitstream.h:55 */
 static inline int xh_mask_is_zero(const xh_ibs* b) { return b->bits == 0 || (b->mask >> (32 - b->bits)) == 0; } /* :58 */
@@ -668,7 +669,9 @@ static int xh_decompress_chunk_o(const uint8_t** pin, const uint8_t* in_end, uin
 			}
 			if (off > op) { return ORC_DATA_ERROR; }                                                              /* :120 */
 			if (len > cap - op) { return ORC_BUF_ERROR; }                                                         /* :121 */
-			if (orc_xh_depth) { for (uint32_t i = 0; i < len; ++i) { orc_xh_depth[op + i] = orc_xh_depth[op + i - off] + 1; } }
+			if (orc_xh_depth) {   /* mode 0: byte i copies byte i - off; mode 1: byte i of a match copies byte (i mod off) of its first period */
+				for (uint32_t i = 0; i < len; ++i) { orc_xh_depth[op + i] = orc_xh_depth[orc_xh_depth_mode ? op - off + (i % off) : op + i - off] + 1; }
+			}
 			for (uint32_t i = 0; i < len; ++i) { out_base[op] = out_base[op - off]; ++op; }
 		}
 	}
@@ -824,6 +827,7 @@ long orc_xh_chunk_starts(const uint8_t* in, size_t n, size_t cap, uint64_t* star
 
 /* research helper: how long are the copy chains of a stream? depth[i] = 0 for a literal byte, else depth of its source + 1
  * (depth: cap entries). Returns the decoded length or a negative status. */
+void orc_xh_depth_first_period(int on) { orc_xh_depth_mode = on; }
 long long orc_xh_copy_depths(const uint8_t* in, size_t n, size_t cap, uint32_t* depth)
 {
 	uint8_t* out = (uint8_t*)malloc(cap + 64);
