@@ -46,7 +46,7 @@ struct mscomp_amd_ctx {
 	DevBuf wrec, sbrec;                                // ... state / counts / prefixes per window (6 x u32), per super-block (tot 4 x u32, pre 3 x u64, seams)
 	DevBuf tokbits, counts, extra, lens, codes, fb_list, fbflag;   // Xpress+Huffman per-chunk scratch
 	DevBuf dz_cin, dz_csize, dz_unit;                  // LZNT1 decompression: header offset / decoded size per chunk slot, per-unit records
-	DevBuf dz_tok, dz_ntok;                            // Xpress+Huffman decompression: 32-bit tokens of every unit, token counts
+	DevBuf dz_tok, dz_ntok, dz_xhc;                    // Xpress+Huffman decompression: 32-bit tokens of every unit, token counts, candidate chunk records
 	DevBuf cp_tab;                                     // compaction: out_off (u64) | tile_prefix (u32) of the batch being packed
 	DevBuf one_in, one_out, one_meta;                  // staging of the host-pointer one-shot path
 	bool profiling = false;
@@ -61,7 +61,8 @@ struct mscomp_amd_plan {
 	uint32_t n_units = 0, n_chunks = 0;
 	uint64_t total_in = 0;
 	DevBuf tables;                                     // in_off | out_off | chunk_prefix
-	DevBuf tokpre;                                     // decompression by tokens: first token slot of every unit (u64, n_units + 1)
+	DevBuf tokpre;                                     // decompression by tokens: first token slot | first candidate slot of every unit (2 x (n_units + 1) u64)
+	uint32_t xhc_slots = 0;                            // candidate chunk slots of the batch
 	BatchTables bt{};
 	// the launch sequence of plan_execute as a hipGraph: captured on the plan's second execution, replayed while the
 	// arguments and the scratch buffers stay where they were
@@ -93,7 +94,11 @@ struct KernelTimer {
 
 uint32_t chunks_of(MSCompFormat f, bool decompress, uint64_t n)
 {
-	if (decompress) { return f == MSCOMP_LZNT1 ? (uint32_t)(n ? (n + LZD_SEG - 1u) / LZD_SEG : 1u) : 1u; }   // LZNT1: segments of the header walk
+	if (decompress) {                                  // LZNT1: segments of the header walk; Xpress+Huffman: tiles of the candidate search
+		if (f == MSCOMP_LZNT1) { return (uint32_t)(n ? (n + LZD_SEG - 1u) / LZD_SEG : 1u); }
+		if (f == MSCOMP_XPRESS_HUFF) { return (uint32_t)(n ? (n + XHC_TILE_BYTES - 1u) / XHC_TILE_BYTES : 1u); }
+		return 1u;
+	}
 	switch (f) {
 	case MSCOMP_LZNT1:       return (uint32_t)((n + 4095u) / 4096u);
 	case MSCOMP_XPRESS_HUFF: return (uint32_t)((n + 65535u) / 65536u);   // n==0 -> 0 chunks, 0 bytes of output
@@ -149,7 +154,7 @@ void mscomp_amd_ctx_destroy(mscomp_amd_ctx* c)
 	c->wtok.release(); c->wmat.release(); c->wfar.release(); c->wrec.release(); c->sbrec.release();
 	c->tokbits.release(); c->counts.release(); c->extra.release(); c->lens.release(); c->codes.release();
 	c->fb_list.release(); c->fbflag.release();
-	c->dz_cin.release(); c->dz_csize.release(); c->dz_unit.release(); c->dz_tok.release(); c->dz_ntok.release();
+	c->dz_cin.release(); c->dz_csize.release(); c->dz_unit.release(); c->dz_tok.release(); c->dz_ntok.release(); c->dz_xhc.release();
 	delete c;
 }
 
@@ -220,15 +225,21 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 		}
 		if (okd && format == MSCOMP_XPRESS_HUFF) {
 			// a symbol gives one token, a match one more per 32766 bytes; no token without an output byte
-			std::vector<uint64_t> tp(n_units + 1);
-			uint64_t slots = 0;
+			std::vector<uint64_t> tp(2 * (n_units + 1));
+			uint64_t slots = 0, cands = 0;
 			for (size_t i = 0; i < n_units; ++i) {
-				tp[i] = slots;
+				tp[i] = slots; tp[n_units + 1 + i] = cands;
 				const uint64_t by_in = 8 * in_len[i] + out_cap[i] / 32766u + 1, cnt = out_cap[i] < by_in ? out_cap[i] : by_in;
 				slots += cnt + 64;
+				// candidate chunk starts: a chunk gives 65536 bytes and takes at least 260; a quarter more for windows that only look like a table
+				const uint64_t by_out = out_cap[i] / 65536u + 2, by_len = in_len[i] / 260u + 1, most = by_out < by_len ? by_out : by_len;
+				cands += most + most / 4 + 2;
 			}
-			tp[n_units] = slots;
-			okd = p->tokpre.reserve(tp.size() * 8) && c->dz_tok.reserve(slots * 4 + 256) && c->dz_ntok.reserve((n_units + 1) * 8);
+			tp[n_units] = slots; tp[2 * n_units + 1] = cands;
+			if (cands > 0x7FFFFFF0u) { p->tables.release(); delete p; return MSCOMP_ARG_ERROR; }
+			p->xhc_slots = (uint32_t)cands;
+			okd = p->tokpre.reserve(tp.size() * 8) && c->dz_tok.reserve(slots * 4 + 256) && c->dz_ntok.reserve((n_units + 1) * 8) &&
+			      c->dz_xhc.reserve(((size_t)n_units + 1) * 8 + (size_t)cands * (4 * 4 + 3 * 8) + 64);
 			if (okd && (hipMemcpyAsync(p->tokpre.p, tp.data(), tp.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
 			            hipStreamSynchronize(c->stream) != hipSuccess)) { p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_ERRNO; }
 		}
@@ -332,8 +343,21 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 		}
 		case MSCOMP_XPRESS_HUFF: {
 			const u64* tp = static_cast<const u64*>(p->tokpre.p); uint32_t* tok = static_cast<uint32_t*>(c->dz_tok.p); u64* ntok = static_cast<u64*>(c->dz_ntok.p);
-			{ KernelTimer t(c, "xhd_parse_kernel"); launch_xpress_huff_decompress(st, d_in, p->bt, tp, tok, ntok, d_out, d_out_len, d_status, 0); }
-			{ KernelTimer t(c, "lz_copy_kernel"); launch_xpress_huff_decompress(st, d_in, p->bt, tp, tok, ntok, d_out, d_out_len, d_status, 1); }
+			const u64* cp = tp + (p->n_units + 1u);
+			XhcBufs xb;
+			{
+				const size_t nu = (size_t)p->n_units + 1, ns = p->xhc_slots;
+				uint8_t* q = static_cast<uint8_t*>(c->dz_xhc.p);
+				xb.res_prod = reinterpret_cast<u64*>(q); q += ns * 8; xb.res_ntok = reinterpret_cast<u64*>(q); q += ns * 8; xb.tok_off = reinterpret_cast<u64*>(q); q += ns * 8;
+				xb.cand_pos = reinterpret_cast<uint32_t*>(q); q += ns * 4; xb.res_end = reinterpret_cast<uint32_t*>(q); q += ns * 4;
+				xb.res_reach = reinterpret_cast<uint32_t*>(q); q += ns * 4; xb.res_state = reinterpret_cast<uint32_t*>(q); q += ns * 4;
+				xb.cand_cnt = reinterpret_cast<uint32_t*>(q); q += nu * 4; xb.mode = reinterpret_cast<uint32_t*>(q);
+			}
+			static const char* const names[6] = { "xhc_mark_kernel", "xhc_parse_kernel", "xhc_chain_kernel", "xhc_parse2_kernel", "xhd_parse_kernel", "lz_copy_kernel" };
+			for (int ph = 0; ph < 6; ++ph) {
+				KernelTimer t(c, names[ph]);
+				launch_xpress_huff_decompress(st, d_in, p->bt, tp, tok, ntok, cp, p->xhc_slots, xb, d_out, d_out_len, d_status, ph);
+			}
 			return MSCOMP_OK;
 		}
 		default:

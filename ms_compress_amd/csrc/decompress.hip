@@ -737,10 +737,11 @@ struct XhdLds {
 // tokens of unit u: tok[tok_prefix[u] ...], ntok[u]; d_out_len / d_status as the caller sees them (the bytes follow in lz_copy_kernel)
 __global__ __launch_bounds__(64) void xhd_parse_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, const u64* __restrict__ tok_prefix,
                                                       uint32_t* __restrict__ tok, u64* __restrict__ ntok,
-                                                      u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
+                                                      u64* __restrict__ d_out_len, int32_t* __restrict__ d_status, const uint32_t* __restrict__ mode)
 {
 	__shared__ XhdLds S;
 	const uint32_t lane = threadIdx.x, u = blockIdx.x;
+	if (mode[u] != XHC_SERIAL) { return; }                               // the chunk-parallel path has done this buffer
 	const uint32_t n = (uint32_t)bt.in_len[u];
 	const u64 cap = bt.out_cap[u];
 	const uint8_t* src = d_in + bt.in_off[u];
@@ -880,6 +881,243 @@ __global__ __launch_bounds__(64) void xhd_parse_kernel(const uint8_t* __restrict
 }
 
 // ===================================================================================================================
+// Xpress+Huffman: the chunks of ONE buffer in parallel (speculative chunk starts)
+// ===================================================================================================================
+// Where a chunk starts is not stored, but its first 256 bytes are a complete prefix code: the 512 nibbles l satisfy sum 2^(15-l) = 2^15
+// (tools/xh_marker_study.py: true for every chunk of the corpus, and for 78 other offsets in 80 MB of streams). xhc_mark_kernel lists the
+// offsets of a buffer with that property (plus offset 0), xhc_parse_kernel<1> walks every candidate as ONE chunk on its own, xhc_chain_kernel
+// follows end(k) == start(k+1) from offset 0, places the chunks in the output and the token stream and checks that no match reaches in
+// front of the buffer; xhc_parse_kernel<2> then writes the tokens of the accepted chunks. Anything unexpected (more candidates than room,
+// a broken chain, an error inside a chunk, output beyond the capacity) sends the buffer to the serial walk, which reports the reference's status.
+#define XHC_TILE 16384u                 // input bytes per block of xhc_mark_kernel
+#define XHC_MAXC 8192u                  // candidates of a buffer the chain check can hold
+__global__ __launch_bounds__(256) void xhc_mark_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, const u64* __restrict__ cand_prefix, XhcBufs xb)
+{
+	__shared__ uint8_t s_b[XHC_TILE + 256u + 16u];
+	__shared__ uint32_t s_k[256];
+	const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+	const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, tile), t = tile - bt.chunk_prefix[u];
+	const uint32_t n = (uint32_t)bt.in_len[u];
+	const uint8_t* __restrict__ src = d_in + bt.in_off[u];
+	const uint32_t room = (uint32_t)(cand_prefix[u + 1] - cand_prefix[u]);
+	uint32_t* __restrict__ my = xb.cand_pos + cand_prefix[u];
+	const u64 T0 = (u64)t * XHC_TILE;
+	if (t == 0 && tid == 0) { const uint32_t i = atomicAdd(&xb.cand_cnt[u], 1u); if (i < room) { my[i] = 0; } }   // chunk 0 starts at offset 0
+	if (T0 >= n) { return; }
+	const uint32_t avail = n - T0 < XHC_TILE + 255u ? (uint32_t)(n - T0) : XHC_TILE + 255u;
+	for (uint32_t i = tid; i < avail; i += 256u) { s_b[i] = src[T0 + i]; }
+	{ const uint32_t lo = tid & 15u, hi = tid >> 4; s_k[tid] = (lo ? 1u << (15u - lo) : 0u) + (hi ? 1u << (15u - hi) : 0u); }
+	__syncthreads();
+	const uint32_t base = tid * 64u;                                     // this thread: offsets T0 + base .. + 63
+	uint32_t sum = 0;
+	for (uint32_t i = 0; i < 64u; ++i) {
+		const u64 p = T0 + base + i;
+		if (p + 260u > n) { break; }                                     // a chunk is a table and at least 4 bytes (:140)
+		if (i == 0) { for (uint32_t j = 0; j < 256u; ++j) { sum += s_k[s_b[base + j]]; } }
+		else { sum += s_k[s_b[base + i + 255u]] - s_k[s_b[base + i - 1u]]; }
+		if (sum == 32768u && p != 0) { const uint32_t k = atomicAdd(&xb.cand_cnt[u], 1u); if (k < room) { my[k] = (uint32_t)p; } }
+	}
+}
+
+// ONE chunk per wave, wherever a candidate says a chunk starts (speculative: see xhc_mark_kernel / xhc_chain_kernel). PASS 1: every candidate
+// is measured (where the next chunk would start, bytes produced, how far its matches reach in front of the chunk, tokens; 2 = not a chunk);
+// the candidate at offset 0 is chunk 0 for sure and writes its tokens at once. PASS 2: the chunks the chain check accepted write their
+// tokens at their place in the unit's token stream.
+template <int PASS>
+__global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, const u64* __restrict__ tok_prefix,
+                                                      const u64* __restrict__ cand_prefix, XhcBufs xb, uint32_t* __restrict__ tok)
+{
+	__shared__ XhdLds S;
+	const uint32_t lane = threadIdx.x, slot = blockIdx.x;
+	const uint32_t u = seg_of_flat(cand_prefix, bt.n_units, slot);
+	const uint32_t idx = slot - (uint32_t)cand_prefix[u];
+	const uint32_t have = xb.cand_cnt[u], room = (uint32_t)(cand_prefix[u + 1] - cand_prefix[u]);
+	if (idx >= (have < room ? have : room)) { return; }
+	if (PASS == 2 && (xb.mode[u] != XHC_SPEC || xb.tok_off[slot] == ~(u64)0 || xb.cand_pos[slot] == 0)) { return; }
+	const bool writing = PASS == 2 || xb.cand_pos[slot] == 0;
+	const uint32_t at = xb.cand_pos[slot];
+	const uint32_t n = (uint32_t)bt.in_len[u];
+	const uint8_t* src = d_in + bt.in_off[u];
+	const u64 tok_at = PASS == 2 ? xb.tok_off[slot] : (u64)0;
+	uint32_t* __restrict__ mytok = tok + tok_prefix[u] + tok_at;
+	const u64 tokcap = tok_prefix[u + 1] - tok_prefix[u] - tok_at;      // chunk 0 writes before the capacity is judged: never beyond the unit's slots
+	u64 reach = 0;
+	u64 nt = 0; uint32_t ns = 0, treg = 0;                               // tokens in HBM; tokens staged: token k of the batch waits in lane k
+	#define XHD_EMIT(w) { treg = lane == ns ? (w) : treg; ++ns; if (ns == 64u) { if (writing && nt + 64u <= tokcap) { mytok[nt + lane] = treg; } nt += 64u; ns = 0; } }
+	int32_t status = 1; u64 op = 0;                                      // 1 = running
+	// ---- input ring (see xpd_kernel) ----
+	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
+	const uint8_t* ab = src - a0;
+	const uint32_t endq = a0 + n;                                        // units are below 4 GiB - 4096
+	uint32_t loaded = 0;                                                 // blocks of 2048 input bytes brought to LDS so far (the last two are resident)
+	// a block is loaded when the walk gets there (one HBM round trip per 2 KiB of input: nothing next to ~5000 symbols); values that
+	// live across the walk in registers (a prefetched block) made the compiler wait for memory and shuffle them on every symbol
+	#define XHD_BLOCK() { uint8_t* b_ = S.in + (loaded & 1u) * XHD_INB; __syncthreads(); \
+		_Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) { const u64 q_ = (u64)loaded * XHD_INB + ((uint32_t)i_ * 64u + lane) * 16u; \
+			*reinterpret_cast<uint4*>(b_ + ((uint32_t)i_ * 64u + lane) * 16u) = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } \
+		++loaded; __syncthreads(); }
+	// loaded * 2048 never lies behind the walk, so the distance to it is a plain 32-bit difference (units end below 4 GiB - 4096)
+	#define XHD_NEED(q, margin) while (loaded * XHD_INB - (q) < (margin) && loaded * XHD_INB < endq) { XHD_BLOCK() }
+	loaded = (a0 + at) / XHD_INB;
+	XHD_BLOCK() XHD_BLOCK()
+	auto rb = [&](uint32_t q) -> uint32_t { return S.in[q & (2u * XHD_INB - 1u)]; };
+	uint32_t ip = a0 + at;
+	uint32_t state = 2, next_at = 0;                                      // 0 chunk done, 1 the stream ends with it, 2 not a chunk
+	while (status == 1) {
+		// ---- a chunk: 256 bytes of code lengths, then its bit stream (:137-152) ----
+		if (endq - ip < 260u) { if (ip == endq && at == 0) { state = 1; next_at = 0; } break; }   // an empty buffer is an empty stream (:140-144)
+		XHD_NEED(ip, 320u)
+		uint32_t cl[8];
+		{
+			const uint32_t w = rb(ip + 4u * lane) | (rb(ip + 4u * lane + 1u) << 8) | (rb(ip + 4u * lane + 2u) << 16) | (rb(ip + 4u * lane + 3u) << 24);
+			#pragma unroll
+			for (int k = 0; k < 8; ++k) { cl[k] = (w >> (4 * k)) & 0xFu; }   // symbols 8 lane .. 8 lane + 7
+		}
+		ip += 256u;
+		__syncthreads();
+		// SetCodeLengths (HuffmanDecoder.h:42-90): counts, limits, positions, canonical order
+		uint32_t last = 0, pos_acc = 0, prevcnt = 0; bool bad = false;
+		for (uint32_t i = lane; i < 512u; i += 64u) { S.syms[i] = 0xFFFFu; }
+		if (lane == 0) { S.lims[0] = 0; S.poss[0] = 0; }
+		for (uint32_t L = 1; L <= 15u; ++L) {
+			u64 m[8]; uint32_t cnt = 0, before = 0;
+			#pragma unroll
+			for (int k = 0; k < 8; ++k) { m[k] = __ballot(cl[k] == L); cnt += (uint32_t)__builtin_popcountll(m[k]); before += popc_below(m[k]); }
+			pos_acc += prevcnt; prevcnt = cnt;                           // poss[L] = poss[L-1] + cnts[L-1], cnts[0] = 0
+			if (L < 15u) { const uint32_t inc = cnt << (15u - L); if (last + inc > 32768u) { bad = true; } last += inc; }
+			else if (last + cnt > 32768u) { bad = true; }
+			if (lane == 0) { S.lims[L] = L < 15u ? last : 32768u; S.poss[L] = pos_acc; }
+			uint32_t mine = 0;
+			#pragma unroll
+			for (int k = 0; k < 8; ++k) { if (cl[k] == L) { const uint32_t at = pos_acc + before + mine; if (at < 512u) { S.syms[at] = (uint16_t)(lane * 8u + k); } ++mine; } }
+		}
+		if (bad) { status = -3; break; }                                 // :149
+		__syncthreads();
+		const uint32_t lims9 = S.lims[9];
+		for (uint32_t i = lane; i < 512u; i += 64u) {
+			uint32_t e = 0;
+			const uint32_t x = i << 6;
+			if (x < lims9) {
+				uint32_t L = 1;
+				while (x >= S.lims[L]) { ++L; }
+				const uint32_t sidx = S.poss[L] + ((x - S.lims[L - 1u]) >> (15u - L));
+				const uint32_t sym = sidx < 512u ? S.syms[sidx] : 0xFFFFu;
+				e = sym == 0xFFFFu ? 0u : ((sym << 4) | L);
+			}
+			S.fast[i] = (uint16_t)e;
+		}
+		__syncthreads();
+		// ---- the chunk's symbols (:87-127) ----
+		XHD_NEED(ip, 320u)
+		uint32_t mask = (rb(ip) << 16) | (rb(ip + 1) << 24) | rb(ip + 2) | (rb(ip + 3) << 8);   // Bitstream.h:44
+		uint32_t bits = 32; ip += 4u;
+		uint32_t prod = 0;                                               // bytes of this chunk so far, saturating
+		bool stream_end = false;
+		#define XHD_SKIP(k) { mask <<= (k); bits -= (k); if (bits < 16u && ip + 2u <= endq) { XHD_NEED(ip, 2u) mask |= (rb(ip) | (rb(ip + 1) << 8)) << (16u - bits); bits |= 16u; ip += 2u; } }
+		#define XHD_MASK_ZERO() (bits == 0 || (mask >> (32u - bits)) == 0)
+		#define XHD_DECODE(sym) { const uint32_t r_ = bits; const uint32_t x_ = r_ < 15u ? (((mask >> 16) >> (16u - r_)) << (15u - r_)) : (mask >> 17); \
+			const uint32_t f_ = S.fast[x_ >> 6]; uint32_t n_; \
+			if (f_) { n_ = f_ & 0xFu; sym = f_ >> 4; if (n_ > r_) { sym = 0xFFFFu; } else { XHD_SKIP(n_) } } \
+			else { n_ = 1; while (x_ >= S.lims[n_]) { ++n_; } \
+				if (n_ > r_) { sym = 0xFFFFu; } else { XHD_SKIP(n_) const uint32_t s_ = S.poss[n_] + ((x_ - S.lims[n_ - 1u]) >> (15u - n_)); sym = s_ >= 512u ? 0xFFFFu : S.syms[s_]; } } }
+		while (prod < 65536u || !XHD_MASK_ZERO()) {
+			uint32_t sym;
+			XHD_DECODE(sym)
+			if (sym < 0x100u) {
+				XHD_EMIT(0x80000000u | sym)
+				++op; ++prod;
+			} else {
+				if (sym == 0xFFFFu) { status = -3; break; }
+				if (sym == 0x100u && ip == endq && XHD_MASK_ZERO()) { stream_end = true; break; }   // :91
+				uint32_t len = sym & 0xFu;
+				if (len == 0xFu) {
+					XHD_NEED(ip, 8u)
+					if (endq - ip < 1u) { status = -3; break; }
+					len = rb(ip); ip += 1u;
+					if (len == 0xFFu) {
+						if (endq - ip < 2u) { status = -3; break; }
+						len = rb(ip) | (rb(ip + 1) << 8); ip += 2u;
+						if (len == 0) {
+							if (endq - ip < 4u) { status = -3; break; }
+							len = rb(ip) | (rb(ip + 1) << 8) | (rb(ip + 2) << 16) | (rb(ip + 3) << 24); ip += 4u;
+						}
+						if (len < 0xFu) { status = -3; break; }
+						len -= 0xFu;
+					}
+					len += 0xFu;
+				}
+				len += 3u;
+				const uint32_t ob = (sym >> 4) & 0xFu;
+				if (ob > bits) { status = -3; break; }                   // :117
+				const uint32_t off = ((mask >> 16) >> (16u - ob)) + (1u << ob);
+				XHD_SKIP(ob)
+				if (off > op && off - op > reach) { reach = off - op; }   // :120 is judged when the chunk's place in the output is known
+				op += len; prod = prod + len < prod ? 0xFFFFFFFFu : prod + len;
+				while (len > LZT_MAXLEN) { XHD_EMIT(off | (LZT_MAXLEN << 16)) len -= LZT_MAXLEN; }
+				XHD_EMIT(off | (len << 16))
+			}
+		}
+		if (status != 1) { break; }
+		if (!stream_end) {                                               // :128-134: is the next symbol the end of the stream?
+			const uint32_t ip_keep = ip;
+			uint32_t sym;
+			XHD_DECODE(sym)
+			if (sym == 0x100u && ip == endq && XHD_MASK_ZERO()) { stream_end = true; } else { ip = ip_keep; }
+		}
+		state = stream_end ? 1u : 0u; next_at = ip - a0;
+		break;                                                           // one chunk
+	}
+	#undef XHD_BLOCK
+	#undef XHD_NEED
+	#undef XHD_SKIP
+	#undef XHD_MASK_ZERO
+	#undef XHD_DECODE
+	if (writing && lane < ns && nt + ns <= tokcap) { mytok[nt + lane] = treg; }
+	#undef XHD_EMIT
+	if (PASS == 1 && lane == 0) {
+		xb.res_state[slot] = status == 1 ? state : 2u; xb.res_end[slot] = next_at; xb.res_prod[slot] = op; xb.res_ntok[slot] = nt + ns;
+		xb.res_reach[slot] = reach > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)reach;
+	}
+}
+
+// one wave per buffer: the chain of chunks from offset 0 through the measured candidates
+__global__ __launch_bounds__(64) void xhc_chain_kernel(BatchTables bt, const u64* __restrict__ cand_prefix, XhcBufs xb, u64* __restrict__ ntok,
+                                                      u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
+{
+	__shared__ uint32_t s_pos[XHC_MAXC];
+	const uint32_t lane = threadIdx.x, u = blockIdx.x;
+	const uint32_t n = (uint32_t)bt.in_len[u];
+	const u64 cap = bt.out_cap[u], base = cand_prefix[u];
+	const uint32_t room = (uint32_t)(cand_prefix[u + 1] - base), have = xb.cand_cnt[u];
+	bool ok = have >= 1u && have <= room && have <= XHC_MAXC;
+	const uint32_t cnt = ok ? have : 0u;
+	for (uint32_t i = lane; i < cnt; i += 64u) { s_pos[i] = xb.cand_pos[base + i]; xb.tok_off[base + i] = ~(u64)0; }
+	__syncthreads();
+	uint32_t pos = 0, steps = 0; u64 out = 0, nt = 0; bool success = false;
+	while (ok) {
+		uint32_t found = 0xFFFFFFFFu;
+		for (uint32_t i0 = 0; i0 < cnt; i0 += 64u) {
+			const u64 m = __ballot(i0 + lane < cnt && s_pos[i0 + lane] == pos);
+			if (m) { found = i0 + ctz64(m); break; }
+		}
+		if (found == 0xFFFFFFFFu) { break; }
+		const u64 sl = base + found;
+		const uint32_t st = xb.res_state[sl], reach = xb.res_reach[sl], end = xb.res_end[sl];
+		if (st == 2u || reach == 0xFFFFFFFFu || (u64)reach > out) { break; }     // not a chunk, or a match reaches in front of the buffer (:120)
+		if (lane == 0) { xb.tok_off[sl] = nt; }
+		out += xb.res_prod[sl]; nt += xb.res_ntok[sl];
+		if (st == 1u) { success = end == n; break; }
+		if (end <= pos || ++steps > cnt) { break; }
+		pos = end;
+	}
+	success = success && out <= cap;                                     // beyond the capacity: the serial walk says where and how
+	if (lane == 0) {
+		xb.mode[u] = success ? XHC_SPEC : XHC_SERIAL;
+		if (success) { d_status[u] = 0; d_out_len[u] = out; ntok[u] = nt; }
+	}
+}
+
+// ===================================================================================================================
 // tokens -> bytes (one wave per unit)
 // ===================================================================================================================
 // The output of a unit is produced 2048 bytes at a time. The tokens that start in the window set a bit per start and leave their
@@ -969,11 +1207,19 @@ __global__ __launch_bounds__(64) void lz_copy_kernel(BatchTables bt, const u64* 
 }
 
 void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
+                                   const u64* cand_prefix, uint32_t n_slots, const XhcBufs& xb,
                                    uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase)
 {
 	if (bt.n_units == 0) { return; }
-	if (phase == 0) { hipLaunchKernelGGL(xhd_parse_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, tok_prefix, tok, ntok, d_out_len, d_status); }
-	else            { hipLaunchKernelGGL(lz_copy_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out); }
+	switch (phase) {
+	case 0: (void)hipMemsetAsync(xb.cand_cnt, 0, ((size_t)bt.n_units + 1) * sizeof(uint32_t), st);
+	        hipLaunchKernelGGL(xhc_mark_kernel, dim3(bt.n_chunks), dim3(256), 0, st, d_in, bt, cand_prefix, xb); break;
+	case 1: hipLaunchKernelGGL(xhc_parse_kernel<1>, dim3(n_slots), dim3(64), 0, st, d_in, bt, tok_prefix, cand_prefix, xb, tok); break;
+	case 2: hipLaunchKernelGGL(xhc_chain_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, cand_prefix, xb, ntok, d_out_len, d_status); break;
+	case 3: hipLaunchKernelGGL(xhc_parse_kernel<2>, dim3(n_slots), dim3(64), 0, st, d_in, bt, tok_prefix, cand_prefix, xb, tok); break;
+	case 4: hipLaunchKernelGGL(xhd_parse_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, tok_prefix, tok, ntok, d_out_len, d_status, xb.mode); break;
+	default: hipLaunchKernelGGL(lz_copy_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out); break;
+	}
 }
 
 } // namespace msc

@@ -55,9 +55,15 @@ void launch_lzd_finalize(hipStream_t st, const BatchTables& bt, const LzdBufs& b
 // Xpress: one wave per stream
 void launch_xpress_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* d_out, u64* d_out_len, int32_t* d_status);
 
-// Xpress+Huffman: phase 0 = one wave per buffer walks the symbols and writes 32-bit tokens (tok_prefix[u] = first slot of unit u, ntok[u]),
-// status and length; phase 1 = the tokens become bytes
+// Xpress+Huffman, in phases: 0 mark candidate chunk starts, 1 walk every candidate as one chunk, 2 chain check per buffer, 3 tokens of the
+// accepted chunks, 4 serial walk of the buffers the speculation could not do, 5 tokens -> bytes. tok_prefix[u] = first token slot of unit u,
+// cand_prefix[u] = first candidate slot (n_slots in all); per candidate slot: offset, next offset, reach, state, bytes, tokens, token offset.
+#define XHC_TILE_BYTES 16384u
+enum { XHC_SERIAL = 1, XHC_SPEC = 2 };
+struct XhcBufs { uint32_t* cand_cnt; uint32_t* mode; uint32_t* cand_pos; uint32_t* res_end; uint32_t* res_reach; uint32_t* res_state;
+                 u64* res_prod; u64* res_ntok; u64* tok_off; };
 void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
+                                   const u64* cand_prefix, uint32_t n_slots, const XhcBufs& xb,
                                    uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase);
 
 // ---- utilities (util.hip) ----
