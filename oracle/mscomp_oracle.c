@@ -585,6 +585,7 @@ static int xpress_huff_compress_o(const uint8_t* d, size_t n, uint8_t* out, size
 static __thread uint64_t* orc_xh_starts; static __thread size_t orc_xh_nstarts, orc_xh_maxstarts;
 static __thread uint32_t* orc_xh_depth;      /* research: copy-chain depth per output byte (0 = literal) */
 static __thread int orc_xh_depth_mode;
+static __thread uint32_t* orc_xh_src;        /* research: source of every output byte (itself for a literal) */
 typedef struct { const uint8_t* in; const uint8_t* end; uint32_t mask; unsigned bits; } xh_ibs;
 static inline uint32_t xh_peek(const xh_ibs* b, unsigned n) { return (b->mask >> 16) >> (16 - n); }              /* Bitstream.h:55 */
 static inline int xh_mask_is_zero(const xh_ibs* b) { return b->bits == 0 || (b->mask >> (32 - b->bits)) == 0; } /* :58 */
@@ -644,6 +645,7 @@ static int xh_decompress_chunk_o(const uint8_t** pin, const uint8_t* in_end, uin
 		if (sym < 0x100) {
 			if (op == cap) { return ORC_BUF_ERROR; }
 			if (orc_xh_depth) { orc_xh_depth[op] = 0; }
+			if (orc_xh_src) { orc_xh_src[op] = (uint32_t)op; }
 			out_base[op++] = (uint8_t)sym;
 		} else {
 			uint32_t len = sym & 0xF, off;
@@ -669,6 +671,7 @@ static int xh_decompress_chunk_o(const uint8_t** pin, const uint8_t* in_end, uin
 			}
 			if (off > op) { return ORC_DATA_ERROR; }                                                              /* :120 */
 			if (len > cap - op) { return ORC_BUF_ERROR; }                                                         /* :121 */
+			if (orc_xh_src) { for (uint32_t i = 0; i < len; ++i) { orc_xh_src[op + i] = (uint32_t)(op - off + (i % off)); } }
 			if (orc_xh_depth) {   /* mode 0: byte i copies byte i - off; mode 1: byte i of a match copies byte (i mod off) of its first period */
 				for (uint32_t i = 0; i < len; ++i) { orc_xh_depth[op + i] = orc_xh_depth[orc_xh_depth_mode ? op - off + (i % off) : op + i - off] + 1; }
 			}
@@ -886,4 +889,14 @@ int orc_xh_parse_chunk(const uint8_t* in, size_t n, size_t at, uint64_t res[4])
 	}
 	res[0] = (uint64_t)(b.in - in); res[1] = op; res[2] = reach; res[3] = ntok;
 	return ended;
+}
+
+/* research helper: src[i] = i for a literal byte, else the byte of the match's first period it copies (< i); out: the bytes. */
+long long orc_xh_sources(const uint8_t* in, size_t n, size_t cap, uint32_t* src, uint8_t* out)
+{
+	size_t len = cap;
+	orc_xh_src = src;
+	const int st = xpress_huff_decompress_o(in, n, out, &len);
+	orc_xh_src = NULL;
+	return st == ORC_OK ? (long long)len : st;
 }
