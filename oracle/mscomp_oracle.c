@@ -319,6 +319,7 @@ static int xpress_compress_o(const uint8_t* d, size_t n, uint8_t* out, size_t* o
 /* Xpress decoder with the semantics of the reference's one-shot xpress_decompress (xpress_decompress.cpp:405-462, the
  * MSCOMP_WITH_OPT_DECOMPRESS build that config.h:47-48 selects; READ_SYMBOL :62-107). Its fast loop (:148-196) differs from
  * the checked loop only by what it may skip, not by what it decides, so the checked loop is restated for every token. */
+static __thread uint8_t* orc_xp_mark; static __thread uint32_t* orc_xp_halfpos;   /* research: flag-word starts of the true parse */
 static int xp_set_bits_are_highest(uint32_t x) { x = ~x; return !((x + 1) & x); }                 /* :41 */
 static int xpress_decompress_o(const uint8_t* in, size_t n, uint8_t* out, size_t* out_len)
 {
@@ -329,6 +330,7 @@ static int xpress_decompress_o(const uint8_t* in, size_t n, uint8_t* out, size_t
 		return ORC_DATA_ERROR;
 	}
 	while (ip + 4 <= n) {                                                                          /* :425 */
+		if (orc_xp_mark) { orc_xp_mark[ip] = have_half ? 2 : 1; if (have_half) { orc_xp_halfpos[ip] = (uint32_t)half; } }   /* research hook */
 		uint32_t flags = get32(in + ip), flagged = flags & 0x80000000u;
 		flags = (flags << 1) | 1; ip += 4;
 		do {
@@ -899,4 +901,46 @@ long long orc_xh_sources(const uint8_t* in, size_t n, size_t cap, uint32_t* src,
 	const int st = xpress_huff_decompress_o(in, n, out, &len);
 	orc_xh_src = NULL;
 	return st == ORC_OK ? (long long)len : st;
+}
+
+/* research helpers (would ONE Xpress stream parse in parallel?). orc_xp_flag_starts: mark[p] = 1 / 2 where the true parse reads a flag word
+ * (2: a length nibble is pending, its byte at halfpos[p]). orc_xp_sync: parse (input side only) from `start` as if a flag word began there
+ * with no nibble pending; returns the offset of the first flag word at which this parse is in the state of the true one, or n if it never is
+ * (it ran off the input or into an impossible token). */
+long long orc_xp_flag_starts(const uint8_t* in, size_t n, size_t cap, uint8_t* mark, uint32_t* halfpos)
+{
+	uint8_t* out = (uint8_t*)malloc(cap + 64);
+	if (!out) { return ORC_MEM_ERROR; }
+	size_t len = cap;
+	orc_xp_mark = mark; orc_xp_halfpos = halfpos;
+	const int st = xpress_decompress_o(in, n, out, &len);
+	orc_xp_mark = NULL; orc_xp_halfpos = NULL;
+	free(out);
+	return st == ORC_OK ? (long long)len : st;
+}
+size_t orc_xp_sync(const uint8_t* in, size_t n, size_t start, const uint8_t* mark, const uint32_t* halfpos)
+{
+	size_t ip = start, half = 0; int have_half = 0;
+	while (ip + 4 <= n) {
+		if ((mark[ip] == 1 && !have_half) || (mark[ip] == 2 && have_half && halfpos[ip] == (uint32_t)half)) { return ip; }
+		uint32_t flags = get32(in + ip);
+		ip += 4;
+		for (int t = 0; t < 32; ++t, flags <<= 1) {
+			if (ip >= n) { return n; }
+			if (!(flags & 0x80000000u)) { ++ip; continue; }
+			if (ip + 2 > n) { return n; }
+			const uint32_t sym = get16(in + ip); ip += 2;
+			if ((sym & 7) != 7) { continue; }
+			uint32_t len;
+			if (have_half) { len = in[half] >> 4; have_half = 0; }
+			else { if (ip >= n) { return n; } half = ip; have_half = 1; len = in[ip++] & 0xF; }
+			if (len != 0xF) { continue; }
+			if (ip >= n) { return n; }
+			if (in[ip++] != 0xFF) { continue; }
+			if (ip + 2 > n) { return n; }
+			const uint32_t l16 = get16(in + ip); ip += 2;
+			if (l16 == 0) { if (ip + 4 > n) { return n; } ip += 4; }
+		}
+	}
+	return n;
 }
