@@ -97,6 +97,12 @@ MSCompStatus ms_deflate_end(mscomp_stream* stream);
 MSCompStatus lznt1_deflate_init(mscomp_stream* stream);
 MSCompStatus lznt1_deflate(mscomp_stream* stream, MSCompFlush flush);
 MSCompStatus lznt1_deflate_end(mscomp_stream* stream);
+/* The Xpress streaming compressor is unfinished in the reference; its three entry points exist and return fixed statuses in the default
+ * build (include/xpress.h:52-54; src/xpress_compress.cpp:52-73 MSCOMP_MEM_ERROR, :74-218 MSCOMP_ARG_ERROR, :219-235 stream check). Exported
+ * with the same statuses so that a program naming them links against the drop-in and sees what it saw before. */
+MSCompStatus xpress_deflate_init(mscomp_stream* stream);
+MSCompStatus xpress_deflate(mscomp_stream* stream, MSCompFlush flush);
+MSCompStatus xpress_deflate_end(mscomp_stream* stream);
 /* ... and its streaming decompressor: ms_inflate_init / ms_inflate / ms_inflate_end (include/mscomp.h:174,198,213, src/mscomp.cpp:167-196;
  * MSCOMP_NONE and MSCOMP_LZNT1) and lznt1_inflate_init / lznt1_inflate / lznt1_inflate_end (include/lznt1.h:59-61,
  * src/lznt1_decompress.cpp:210-290). Every chunk is decoded on the GPU; xpress_inflate is not offloaded. */

@@ -6,7 +6,9 @@
 // xpress_huff_compress (/root/reference/src/xpress_huff_compress.cpp:247).
 #include "../../include/mscomp_amd.h"
 #include "kernels.h"
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <new>
 #include <string>
@@ -17,19 +19,24 @@ using namespace msc;
 
 namespace {
 
-static uint64_t g_scratch_epoch = 1;                   // bumped whenever a device buffer moves or a test hook changes a kernel choice
+// A captured hipGraph of a plan holds raw scratch pointers and a kernel choice. Two counters say when it is stale:
+// the context's own epoch (bumped whenever one of ITS device buffers moves; a context is used by one host thread at a
+// time, so a plain counter) and a process-wide one for the test hooks that switch kernels (atomic: any thread may call them
+// while other threads execute plans).
+static std::atomic<uint64_t> g_mode_epoch{1};
 struct DevBuf {
 	void* p = nullptr; size_t cap = 0;
+	uint64_t* epoch = nullptr;                         // the owning context's epoch (null for plan-owned tables)
 	bool reserve(size_t n)
 	{
 		if (n <= cap) { return true; }
-		++g_scratch_epoch;
+		if (epoch) { ++*epoch; }
 		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
 		const size_t want = n + n / 8 + 256;
 		if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
 		cap = want; return true;
 	}
-	void release() { if (p) { (void)hipFree(p); ++g_scratch_epoch; } p = nullptr; cap = 0; }
+	void release() { if (p) { (void)hipFree(p); if (epoch) { ++*epoch; } } p = nullptr; cap = 0; }
 };
 
 struct ProfRec { const char* name; hipEvent_t a, b; };
@@ -49,9 +56,17 @@ struct mscomp_amd_ctx {
 	DevBuf dz_tok, dz_ntok, dz_xhc;                    // Xpress+Huffman decompression: 32-bit tokens of every unit, token counts, candidate chunk records
 	DevBuf cp_tab;                                     // compaction: out_off (u64) | tile_prefix (u32) of the batch being packed
 	DevBuf one_in, one_out, one_meta;                  // staging of the host-pointer one-shot path
+	uint64_t epoch = 1;                                // bumped when one of the buffers above moves (captured graphs are stale then)
 	bool profiling = false;
 	std::vector<ProfRec> recs;
 	std::vector<hipEvent_t> free_events;
+	std::vector<DevBuf*> bufs()
+	{
+		return { &slots, &slot_size, &prefix, &tile_sums, &links, &lasthead, &mlen3, &moff, &wtok, &wmat, &wfar, &wrec, &sbrec,
+		         &tokbits, &counts, &extra, &lens, &codes, &fb_list, &fbflag, &dz_cin, &dz_csize, &dz_unit, &dz_tok, &dz_ntok, &dz_xhc,
+		         &cp_tab, &one_in, &one_out, &one_meta };
+	}
+	mscomp_amd_ctx() { for (DevBuf* b : bufs()) { b->epoch = &epoch; } }
 };
 
 struct mscomp_amd_plan {
@@ -68,7 +83,7 @@ struct mscomp_amd_plan {
 	// arguments and the scratch buffers stay where they were
 	hipGraphExec_t gexec = nullptr;
 	const void* g_args[4] = { nullptr, nullptr, nullptr, nullptr };
-	uint64_t g_epoch = 0;
+	uint64_t g_epoch = 0, g_mode = 0;
 	uint32_t executions = 0;
 };
 
@@ -128,12 +143,38 @@ size_t ms_max_compressed_size(MSCompFormat f, size_t n)
 }
 #endif
 
+// The LZNT1 bucket sort and the Xpress chain links are only bit-exact when the returning same-address LDS atomics of one
+// wave instruction are served in lane order (util.hip: lds_lane_order_kernel). That is how gfx950 behaves, but it is not an
+// architectural promise, so the library checks the device it is about to use -- once per device and process -- and refuses
+// (MSCOMP_ERRNO) to create a context on a device that fails: wrong bytes must never leave silently.
+static int lane_order_verdict(int device, hipStream_t st)
+{
+	static std::mutex mu;
+	static int verdict[64];                            // 0 = unknown, 1 = in order, -1 = out of order / check failed
+	if (device >= 64) { device = 63; }
+	std::lock_guard<std::mutex> lk(mu);
+	if (verdict[device] == 0) {
+		uint32_t* d_bad = nullptr;
+		uint32_t bad = 0xFFFFFFFFu;
+		if (hipMalloc(reinterpret_cast<void**>(&d_bad), 64) == hipSuccess) {
+			bad = run_lds_lane_order_check(st, 0x5EEDu + (uint32_t)device, 64, 64, 97, d_bad);     // 64 blocks x 64 rounds x 64 lanes x {add, exchange}
+			if (bad == 0) { bad = run_lds_lane_order_check(st, 0xC0FFEEu, 64, 64, 2048, d_bad); }
+			(void)hipFree(d_bad);
+		}
+		verdict[device] = bad == 0 ? 1 : -1;
+	}
+	return verdict[device];
+}
+
 MSCompStatus mscomp_amd_ctx_create(int device, void* hip_stream, mscomp_amd_ctx** out)
 {
 	if (!out) { return MSCOMP_ARG_ERROR; }
 	*out = nullptr;
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { return MSCOMP_ERRNO; }
+	DeviceGuard g(device);
+	if (!g.ok) { return MSCOMP_ERRNO; }
+	if (lane_order_verdict(device, (hipStream_t)hip_stream) != 1) { return MSCOMP_ERRNO; }
 	mscomp_amd_ctx* c = new (std::nothrow) mscomp_amd_ctx();
 	if (!c) { return MSCOMP_MEM_ERROR; }
 	c->device = device; c->stream = (hipStream_t)hip_stream;
@@ -148,13 +189,7 @@ void mscomp_amd_ctx_destroy(mscomp_amd_ctx* c)
 	(void)hipStreamSynchronize(c->stream);
 	for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
 	for (auto e : c->free_events) { (void)hipEventDestroy(e); }
-	c->slots.release(); c->slot_size.release(); c->prefix.release(); c->tile_sums.release();
-	c->one_in.release(); c->one_out.release(); c->one_meta.release(); c->cp_tab.release();
-	c->links.release(); c->lasthead.release(); c->mlen3.release(); c->moff.release();
-	c->wtok.release(); c->wmat.release(); c->wfar.release(); c->wrec.release(); c->sbrec.release();
-	c->tokbits.release(); c->counts.release(); c->extra.release(); c->lens.release(); c->codes.release();
-	c->fb_list.release(); c->fbflag.release();
-	c->dz_cin.release(); c->dz_csize.release(); c->dz_unit.release(); c->dz_tok.release(); c->dz_ntok.release(); c->dz_xhc.release();
+	for (DevBuf* b : c->bufs()) { b->release(); }
 	delete c;
 }
 
@@ -416,7 +451,8 @@ MSCompStatus mscomp_amd_plan_execute(mscomp_amd_plan* p, const uint8_t* d_in, ui
 	// ~3 % of an LZNT1 pass). Not while profiling (the per-kernel events are not part of the graph), not on the first
 	// execution (one-time function attributes are set there).
 	if (!no_graph && !c->profiling && p->executions >= 2 && p->n_units) {
-		const bool same = p->gexec && p->g_epoch == g_scratch_epoch && p->g_args[0] == d_in && p->g_args[1] == d_out &&
+		const uint64_t mode_now = g_mode_epoch.load(std::memory_order_acquire);
+		const bool same = p->gexec && p->g_epoch == c->epoch && p->g_mode == mode_now && p->g_args[0] == d_in && p->g_args[1] == d_out &&
 		                  p->g_args[2] == d_out_len && p->g_args[3] == d_status;
 		if (!same) {
 			if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
@@ -425,7 +461,7 @@ MSCompStatus mscomp_amd_plan_execute(mscomp_amd_plan* p, const uint8_t* d_in, ui
 				const MSCompStatus ls = plan_launch(p, d_in, d_out, d_out_len, d_status);
 				const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
 				if (ls == MSCOMP_OK && ee == hipSuccess && graph && hipGraphInstantiate(&p->gexec, graph, nullptr, nullptr, 0) == hipSuccess) {
-					p->g_epoch = g_scratch_epoch; p->g_args[0] = d_in; p->g_args[1] = d_out; p->g_args[2] = d_out_len; p->g_args[3] = d_status;
+					p->g_epoch = c->epoch; p->g_mode = mode_now; p->g_args[0] = d_in; p->g_args[1] = d_out; p->g_args[2] = d_out_len; p->g_args[3] = d_status;
 				} else { p->gexec = nullptr; }
 				if (graph) { (void)hipGraphDestroy(graph); }
 			}
@@ -536,7 +572,7 @@ MSCompStatus mscomp_amd_debug_xpress_matches(mscomp_amd_ctx* c, const uint8_t* d
 }
 
 // Test hook: which Xpress parse/emit kernel runs (0 = chosen by batch size, 1 = one wave per unit, 2 = four waves per unit).
-void mscomp_amd_debug_set_xpress_emit(int mode) { set_xpress_emit_mode(mode); ++g_scratch_epoch; }
+void mscomp_amd_debug_set_xpress_emit(int mode) { set_xpress_emit_mode(mode); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 // ... and which LZNT1 chunk kernel (0 = default, 1 = one wave per chunk, 2 = four waves per chunk).
 uint32_t mscomp_amd_debug_lzd_walked(mscomp_amd_ctx* c)
 {
@@ -546,7 +582,7 @@ uint32_t mscomp_amd_debug_lzd_walked(mscomp_amd_ctx* c)
 	return lzd_read_walked();
 }
 
-void mscomp_amd_debug_set_lznt1(int mode) { set_lznt1_mode(mode); ++g_scratch_epoch; }
+void mscomp_amd_debug_set_lznt1(int mode) { set_lznt1_mode(mode); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 
 // Hardware self-check (see util.hip): lanes whose returning LDS atomic was NOT served in lane order, summed over
 // blocks x rounds x 64 lanes x {add, exchange}; 0 on gfx950. 0xFFFFFFFF = the check could not run.
@@ -559,34 +595,97 @@ uint32_t mscomp_amd_debug_lds_lane_order(mscomp_amd_ctx* c, uint32_t seed, uint3
 }
 
 // ---- drop-in one-shot path (host pointers): H2D, one-unit batch on the GPU, D2H. No CPU encoder exists here. ----
+namespace {
+
+// One context per calling host thread (the reference is reentrant: SURVEY.md 8b "Threading"), destroyed with its thread. The
+// plans of recent calls are kept: a caller that compresses buffers of one size (pages, records, fixed blocks) pays the table
+// upload once and gets the captured hipGraph from its second call on.
+struct OneShotTls {
+	mscomp_amd_ctx* ctx = nullptr;
+	struct Entry { MSCompFormat format; bool decompress; uint64_t in_len, out_cap; mscomp_amd_plan* plan; uint64_t used; };
+	std::vector<Entry> plans;
+	uint64_t tick = 0;
+	void drop()
+	{
+		for (auto& e : plans) { mscomp_amd_plan_destroy(e.plan); }
+		plans.clear();
+		if (ctx) { mscomp_amd_ctx_destroy(ctx); ctx = nullptr; }
+	}
+	~OneShotTls() { drop(); }
+	MSCompStatus plan_for(MSCompFormat f, bool dec, uint64_t in_len, uint64_t out_cap, mscomp_amd_plan** out)
+	{
+		for (auto& e : plans) {
+			if (e.format == f && e.decompress == dec && e.in_len == in_len && e.out_cap == out_cap) { e.used = ++tick; *out = e.plan; return MSCOMP_OK; }
+		}
+		const uint64_t z = 0;
+		mscomp_amd_plan* p = nullptr;
+		const MSCompStatus s = plan_create_impl(ctx, f, dec, 1, &z, &in_len, &z, &out_cap, &p);
+		if (s != MSCOMP_OK) { return s; }
+		if (plans.size() >= 8) {
+			size_t lru = 0;
+			for (size_t i = 1; i < plans.size(); ++i) { if (plans[i].used < plans[lru].used) { lru = i; } }
+			mscomp_amd_plan_destroy(plans[lru].plan);
+			plans.erase(plans.begin() + (long)lru);
+		}
+		plans.push_back(Entry{ f, dec, in_len, out_cap, p, ++tick });
+		*out = p;
+		return MSCOMP_OK;
+	}
+};
+
+} // namespace
+
 static MSCompStatus one_shot(MSCompFormat format, bool decompress, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len)
 {
 	if (!out_len || (in_len && !in) || (*out_len && !out)) { return MSCOMP_ARG_ERROR; }
-	thread_local mscomp_amd_ctx* tl_ctx = nullptr;            // reentrant: one context per calling host thread
+	thread_local OneShotTls tls;
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess) { return MSCOMP_ERRNO; }   // no GPU / no HIP runtime: fail loudly, never fall back
-	if (tl_ctx && tl_ctx->device != dev) { mscomp_amd_ctx_destroy(tl_ctx); tl_ctx = nullptr; }
-	if (!tl_ctx) { MSCompStatus s = mscomp_amd_ctx_create(dev, nullptr, &tl_ctx); if (s != MSCOMP_OK) { return s; } }
-	mscomp_amd_ctx* c = tl_ctx;
+	if (tls.ctx && tls.ctx->device != dev) { tls.drop(); }
+	if (!tls.ctx) { MSCompStatus s = mscomp_amd_ctx_create(dev, nullptr, &tls.ctx); if (s != MSCOMP_OK) { return s; } }
+	mscomp_amd_ctx* c = tls.ctx;
+	DeviceGuard g(c->device);
 	const size_t cap = *out_len;
-	// the device copy of the output never needs more than the format can produce from in_len bytes (a caller may pass a very generous
-	// capacity): LZNT1 chunks are at least 3 bytes and give at most 4096
+	// The device copy of the output is sized by what the format can PRODUCE, never by a generous caller capacity (legal in the
+	// reference: *out_len = 1 << 40 must not become a hipMalloc of a terabyte). Compression: at most ms_max_compressed_size (+ the
+	// two uncounted LZNT1 End_of_buffer bytes), and a unit that fits that bound gets the status and bytes it would get with any larger
+	// capacity. LZNT1 decompression: a chunk takes at least 3 bytes and gives at most 4096. Xpress / Xpress+Huffman decompression
+	// has no such bound (a 10-byte match token can stand for 4 GiB), so the device capacity starts at 16 x the input and grows only
+	// when the decoder says MSCOMP_BUF_ERROR: OK and DATA_ERROR are final at any capacity, because everything the decoders of
+	// xpress_decompress.cpp:405-462 / xpress_huff_decompress.cpp:39-162 test before the output runs full is independent of where it ends.
 	size_t dev_cap = cap;
-	if (decompress && format == MSCOMP_LZNT1) { const size_t most = (in_len / 3 + 1) * 4096; if (most < dev_cap) { dev_cap = most; } }
-	if (!c->one_in.reserve(in_len + 64) || !c->one_out.reserve(dev_cap + 64) || !c->one_meta.reserve(64)) { return MSCOMP_MEM_ERROR; }
-	const uint64_t in_off[1] = { 0 }, in_ln[1] = { in_len }, out_off[1] = { 0 }, out_cp[1] = { cap };
-	uint8_t* d_in = static_cast<uint8_t*>(c->one_in.p); uint8_t* d_out = static_cast<uint8_t*>(c->one_out.p);
+	if (!decompress) {
+		size_t most = format == MSCOMP_LZNT1 ? lznt1_max_compressed_size(in_len) + 2 : format == MSCOMP_XPRESS ? xpress_max_compressed_size(in_len) : xpress_huff_max_compressed_size(in_len);
+		if (most < dev_cap) { dev_cap = most; }
+	} else if (format == MSCOMP_LZNT1) {
+		const size_t most = (in_len / 3 + 1) * 4096; if (most < dev_cap) { dev_cap = most; }
+	} else {
+		const size_t first = in_len * 16 + (1u << 20); if (first < dev_cap) { dev_cap = first; }
+	}
+	if (!c->one_in.reserve(in_len + 64) || !c->one_meta.reserve(64)) { return MSCOMP_MEM_ERROR; }
+	uint8_t* d_in = static_cast<uint8_t*>(c->one_in.p);
 	uint64_t* d_len = static_cast<uint64_t*>(c->one_meta.p); int32_t* d_st = reinterpret_cast<int32_t*>(d_len + 1);
 	if (in_len && hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, c->stream) != hipSuccess) { return MSCOMP_ERRNO; }
-	MSCompStatus s = decompress ? mscomp_amd_decompress_batch(c, format, 1, d_in, in_off, in_ln, d_out, out_off, out_cp, d_len, d_st)
-	                            : mscomp_amd_compress_batch(c, format, 1, d_in, in_off, in_ln, d_out, out_off, out_cp, d_len, d_st);
-	if (s != MSCOMP_OK) { return s; }
 	struct { uint64_t len; int32_t st; int32_t pad; } meta;
-	if (hipMemcpy(&meta, d_len, sizeof meta, hipMemcpyDeviceToHost) != hipSuccess) { return MSCOMP_ERRNO; }
+	for (;;) {
+		if (!c->one_out.reserve(dev_cap + 64)) { return MSCOMP_MEM_ERROR; }
+		mscomp_amd_plan* p = nullptr;
+		MSCompStatus s = tls.plan_for(format, decompress, in_len, dev_cap, &p);
+		if (s != MSCOMP_OK) { return s; }
+		s = mscomp_amd_plan_execute(p, d_in, static_cast<uint8_t*>(c->one_out.p), d_len, d_st);
+		if (s != MSCOMP_OK) { return s; }
+		if (hipMemcpyAsync(&meta, d_len, sizeof meta, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+		    hipStreamSynchronize(c->stream) != hipSuccess) { return MSCOMP_ERRNO; }
+		if (meta.st == MSCOMP_BUF_ERROR && dev_cap < cap) {          // only the staging was too small: decode again with room
+			dev_cap = dev_cap > cap / 16 ? cap : dev_cap * 16;
+			continue;
+		}
+		break;
+	}
 	if (meta.st != MSCOMP_OK) { return (MSCompStatus)meta.st; }
 	size_t copy = (size_t)meta.len;
 	if (!decompress && format == MSCOMP_LZNT1 && cap - copy >= 2) { copy += 2; }    // the uncounted End_of_buffer bytes (lznt1_compress.cpp:270)
-	if (copy && hipMemcpy(out, d_out, copy, hipMemcpyDeviceToHost) != hipSuccess) { return MSCOMP_ERRNO; }
+	if (copy && hipMemcpy(out, c->one_out.p, copy, hipMemcpyDeviceToHost) != hipSuccess) { return MSCOMP_ERRNO; }
 	*out_len = (size_t)meta.len;
 	return MSCOMP_OK;
 }

@@ -304,6 +304,17 @@ MSCompStatus lznt1_deflate_end(mscomp_stream* s)
 	return r;
 }
 
+// The reference's Xpress streaming COMPRESSOR is unfinished: in the default (non-_DEBUG) build xpress_deflate_init returns
+// MSCOMP_MEM_ERROR without touching the stream (xpress_compress.cpp:52-73), xpress_deflate returns MSCOMP_ARG_ERROR (:74-218) and
+// xpress_deflate_end checks the stream and returns MSCOMP_OK (:219-235). A program that links the drop-in and names these symbols
+// must link and see the same statuses.
+MSCompStatus xpress_deflate_init(mscomp_stream*) { return MSCOMP_MEM_ERROR; }
+MSCompStatus xpress_deflate(mscomp_stream*, MSCompFlush) { return MSCOMP_ARG_ERROR; }
+MSCompStatus xpress_deflate_end(mscomp_stream* s)
+{
+	return (!stream_ok(s, MSCOMP_XPRESS, true) || s->state == nullptr) ? MSCOMP_ARG_ERROR : MSCOMP_OK;
+}
+
 #ifndef MSCOMP_AMD_NO_FACADE
 // mscomp.cpp:136-165 with its "copy" codec (:33-47,:60) for MSCOMP_NONE
 MSCompStatus ms_deflate_init(MSCompFormat format, mscomp_stream* s)
@@ -316,7 +327,7 @@ MSCompStatus ms_deflate_init(MSCompFormat format, mscomp_stream* s)
 		s->error[0] = 0; s->warning[0] = 0; s->state = nullptr;
 		return MSCOMP_OK;
 	}
-	if (format == MSCOMP_XPRESS) { return MSCOMP_MEM_ERROR; }  // what the reference's unfinished xpress_deflate_init returns (xpress_compress.cpp:50-75)
+	if (format == MSCOMP_XPRESS) { return xpress_deflate_init(s); }
 	return MSCOMP_ARG_ERROR;                                  // Xpress+Huffman: no entry in the reference's table (mscomp.cpp:141,147)
 }
 MSCompStatus ms_deflate(mscomp_stream* s, MSCompFlush flush)
@@ -330,6 +341,7 @@ MSCompStatus ms_deflate(mscomp_stream* s, MSCompFlush flush)
 		give_out(s, n); take_in(s, n);
 		return (flush == MSCOMP_FINISH && !s->in_avail) ? MSCOMP_STREAM_END : MSCOMP_OK;
 	}
+	if (s->format == MSCOMP_XPRESS) { return xpress_deflate(s, flush); }
 	return MSCOMP_ARG_ERROR;
 }
 MSCompStatus ms_deflate_end(mscomp_stream* s)
@@ -337,6 +349,7 @@ MSCompStatus ms_deflate_end(mscomp_stream* s)
 	if (!s) { return MSCOMP_ARG_ERROR; }
 	if (s->format == MSCOMP_LZNT1) { return lznt1_deflate_end(s); }
 	if (s->format == MSCOMP_NONE) { return stream_ok(s, MSCOMP_NONE) ? MSCOMP_OK : MSCOMP_ARG_ERROR; }
+	if (s->format == MSCOMP_XPRESS) { return xpress_deflate_end(s); }
 	return MSCOMP_ARG_ERROR;
 }
 // mscomp.cpp:167-196; the copy codec initialises and checks its inflate streams as COMPRESSING ones (mscomp.cpp:33,48-59)

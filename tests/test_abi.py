@@ -120,3 +120,43 @@ def test_stream_object_has_the_reference_layout():
     lib.ms_deflate_end.argtypes = [C.POINTER(Stream)]
     assert lib.ms_deflate_init(0, C.byref(s)) == 0 and s.format == 0 and s.compressing and not s.state     # the copy codec needs no GPU
     assert lib.ms_deflate_end(C.byref(s)) == 0
+
+
+def test_xpress_deflate_entry_points_answer_like_the_reference():
+    """include/xpress.h:52-54: the unfinished Xpress streaming compressor. Same statuses as the compiled reference for a fresh stream,
+    a stream with the Xpress format and no state, and one with a (fake) state -- directly and through the ms_deflate* facade. No GPU needed."""
+    import ctypes as C
+    from oracle import loader
+    import ms_compress_amd as m
+
+    class Stream(C.Structure):
+        _fields_ = [("format", C.c_int), ("compressing", C.c_bool), ("in_", C.c_void_p), ("in_avail", C.c_size_t), ("in_total", C.c_size_t),
+                    ("out", C.c_void_p), ("out_avail", C.c_size_t), ("out_total", C.c_size_t), ("error", C.c_char * 256),
+                    ("warning", C.c_char * 256), ("state", C.c_void_p)]
+
+    def answers(lib):
+        res = []
+        for f in (lib.xpress_deflate_init, lib.xpress_deflate_end, lib.ms_deflate_end):
+            f.argtypes = [C.c_void_p]
+        lib.xpress_deflate.argtypes = lib.ms_deflate.argtypes = [C.c_void_p, C.c_int]
+        lib.ms_deflate_init.argtypes = [C.c_int, C.c_void_p]
+        for setup in range(3):
+            s = Stream()
+            if setup >= 1:
+                s.format, s.compressing = 3, True
+            if setup == 2:
+                s.state = 0x1000
+            res.append(lib.xpress_deflate_init(C.byref(s)))
+            res.append((s.format, bool(s.compressing), s.state))          # init must not touch the stream
+            res.append(lib.xpress_deflate(C.byref(s), 0))
+            res.append(lib.xpress_deflate_end(C.byref(s)))
+            res.append(lib.ms_deflate_init(3, C.byref(s)))
+            if setup >= 1:
+                res.append(lib.ms_deflate(C.byref(s), 4))
+                res.append(lib.ms_deflate_end(C.byref(s)))
+        return res
+    ours = answers(m.load_library())
+    assert ours[:5] == [m.MSCOMP_MEM_ERROR, (0, False, None), m.MSCOMP_ARG_ERROR, m.MSCOMP_ARG_ERROR, m.MSCOMP_MEM_ERROR]
+    ref = loader.load_ref()
+    if ref is not None:
+        assert ours == answers(ref)
