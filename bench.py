@@ -1,23 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- input MB/s of the MI355X-native MS-XCA compress path (BASELINE.json metric).
+"""bench.py -- input MB/s of the MI355X-native MS-XCA compress path (BASELINE.json metric), 1 to N GPUs.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE pass of the hot path over one batch of synthetic input that is already resident in HBM:
-  headline workload (BASELINE.json configs[1]): LZNT1, Silesia 'mozilla' (51 220 480 B) as a batch of 12 505 4-KiB chunks.
-With N ranks every rank compresses its own copy of the batch (weak scaling, chunks/files are independent: no data-path
-collective); value = bytes all ranks compressed / max-over-ranks time. Rank 0 prints ONE JSON line with
-`roofline` (dominant kernel: algorithmic bytes per launch / HIP-event kernel time vs the 8 TB/s HBM peak) and
-`cpu_baseline` (the reference's own CPU encoder, oracle/_ref, on this host's cores; a bounded sample).
-The other codecs (BASELINE configs 3 and 4: Xpress 64 KiB units, Xpress+Huffman file mode, full 212 MB corpus) are timed
-after the headline region and reported under "extra" (N=1 only, or with --all).
+With N > 1 and no WORLD_SIZE in the environment the script starts its N ranks itself (torch.distributed.run, one
+process per GPU, rendezvous on 127.0.0.1); launched BY torch.distributed.run it is one of the ranks. A world size other
+than N is an error -- there is no silent one-GPU run of an N-GPU request.
+
+Workload (every N, so that the per-N values form ONE curve): BASELINE.json configs[4] -- the 12-file Silesia(-shaped) set
+replicated 16x (192 files, 3 391 017 280 B), cut into independent units, split over the ranks with
+`sharding.shard_ranges` (contiguous ranges balanced by bytes, no data-path collective: SURVEY.md 8e) -- STRONG scaling:
+the job is fixed, a rank holds 1/N of it in HBM. A "step" is ONE pass of the hot path over the rank's shard, inputs
+resident in HBM. value = bytes of the whole job x K / max-over-ranks time of the K steps (barrier + synchronize on
+both sides). The headline codec is LZNT1 (one unit per file, 4 KiB chunks inside: 827 936 chunks); Xpress (51 824
+independent 64 KiB units) and Xpress+Huffman (one unit per file, 64 KiB chunks with the previous chunk as window) run on
+the same batch right after and are reported under extra.config5, reduced over the ranks the same way.
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel: algorithmic bytes per launch / HIP-event kernel time vs the
+8 TB/s HBM peak; `traffic` from the committed PMC passes of the same command; `secondary` = the pipe that actually limits the
+kernel, from committed SQ counters) and, at N = 1, `cpu_baseline` (the reference's own CPU encoder, oracle/_ref, on this
+host's cores; a bounded sample) for all three codecs. At N = 1 the line also carries BASELINE configs[1..3] one by one
+(extra.single_gpu: mozilla as 12 505 LZNT1 chunks = the round-1 headline, 3 239 Xpress units, Xpress+Huffman file mode)
+and the decompression leg.
 """
 import argparse
 import json
-import re
 import os
+import socket
+import subprocess
 import sys
-import threading
 import time
 
 import numpy as np
@@ -26,98 +37,135 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-DOMINANT = {2: "lznt1_chunk_kernel", 3: "xp_find_kernel", 4: "xp_find_kernel"}
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+REPLICAS = 16                # BASELINE.json configs[4]
+PROFILE_TAG = "r02"
+# the kernel SYMBOL behind the library's timer name of each codec's dominant kernel (template instance included, so that the
+# PMC figures of the Xpress and the Xpress+Huffman match finder are never mixed up)
+SYMBOLS = {
+    (2, "lznt1_chunk_kernel"): "msc::lznt1_chunk4_kernel",
+    (3, "xp_find_kernel"): "msc::xp_find_kernel<8192u, 8192u, 512u, 4096u>",
+    (4, "xp_find_kernel"): "msc::xp_find_kernel<65536u, 0u, 1024u, 8192u>",
+    (3, "xp_fused_kernel"): "msc::xp_fused_kernel",
+}
 
 
-_FILES = {}
+# ---------------------------------------------------------------- launch ----------------------------------------------------------------
+def spawn_ranks(n):
+    """python bench.py --gpus N without torch.distributed.run around it: become the launcher."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n and "--oversubscribe" not in sys.argv:
+        sys.exit("bench.py: --gpus %d asked for, %d visible: refusing to run a smaller job under that name" % (n, have))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-def _file(corpus, i):
-    if i not in _FILES:
-        _FILES[i] = corpus.file_bytes(i)
-    return _FILES[i]
+# ---------------------------------------------------------------- workloads ----------------------------------------------------------------
+class Corpus:
+    """The 12 files on the host (generated once) and on this rank's device."""
+
+    def __init__(self, corpus, dev):
+        import torch
+        self.files = [corpus.file_bytes(i) for i in range(12)]
+        self.flen = np.array([len(f) for f in self.files], np.uint64)
+        self.foff = np.zeros(12, np.uint64); self.foff[1:] = np.cumsum(self.flen)[:-1]
+        self.total = int(self.flen.sum())
+        self.d_files = [torch.from_numpy(f).to(dev) for f in self.files]
+        self.dev = dev
+        self._blob = None
+
+    def blob(self):
+        if self._blob is None:
+            self._blob = np.concatenate(self.files)
+        return self._blob
+
+    def device_range(self, g0, g1):
+        """bytes [g0, g1) of the 16x replicated concatenation, assembled on the device from the 12 resident files"""
+        import torch
+        parts, pos = [], g0
+        while pos < g1:
+            r, o = divmod(pos, self.total)
+            f = int(np.searchsorted(self.foff, o, side="right")) - 1
+            a = o - int(self.foff[f])
+            n = min(int(self.flen[f]) - a, g1 - pos)
+            parts.append(self.d_files[f][a:a + n])
+            pos += n
+        parts.append(torch.zeros(16, dtype=torch.uint8, device=self.dev))
+        return torch.cat(parts)
 
 
-def build_workload(m, corpus, fmt, which):
-    """-> (blob uint8, in_off, in_len, description). Units are independent ms_compress() inputs."""
+def config5_units(cor, fmt):
+    """(offset, length) of every unit of the whole job in the replicated concatenation, and a description"""
+    if fmt == 3:                                   # Xpress: every file cut into independent 64 KiB units (the reference has no chunking of its own)
+        offs, lens = [], []
+        for o, l in zip(cor.foff, cor.flen):
+            s = np.arange(0, int(l), 65536, dtype=np.uint64)
+            offs.append(s + o); lens.append(np.minimum(65536, int(l) - s).astype(np.uint64))
+        uoff, ulen = np.concatenate(offs), np.concatenate(lens)
+        what = "independent 64 KiB units"
+    else:                                          # LZNT1 / Xpress+Huffman: one ms_compress call per file, the codec chunks it
+        uoff, ulen = cor.foff, cor.flen
+        what = "files, one unit each (%s chunks inside)" % ("4 KiB" if fmt == 2 else "64 KiB")
+    off = np.concatenate([uoff + np.uint64(r * cor.total) for r in range(REPLICAS)])
+    ln = np.tile(ulen, REPLICAS)
+    return off, ln, "%dx replicated Silesia-shaped set: %d %s, %d B" % (REPLICAS, len(ln), what, int(ln.sum()))
+
+
+def single_gpu_workload(cor, which):
+    """BASELINE configs[1..3] as round 1 measured them -> (host blob, in_off, in_len, description)"""
     if which == "mozilla":                         # configs[1]: one unit, 12 505 chunks of 4 KiB inside
-        data = _file(corpus, 1)
+        data = cor.files[1]
         return data, np.zeros(1, np.uint64), np.array([len(data)], np.uint64), "mozilla 51220480 B as one unit"
-    files = [_file(corpus, i) for i in range(12)]
-    if "blob" not in _FILES:
-        _FILES["blob"] = np.concatenate(files)
-    blob = _FILES["blob"]
-    flen = np.array([len(f) for f in files], np.uint64)
-    foff = np.zeros(12, np.uint64); foff[1:] = np.cumsum(flen)[:-1]
-    if which == "silesia_files":                   # configs[3]: XH file mode (also LZNT1 per file)
-        return blob, foff, flen, "12 Silesia-shaped files, 211938580 B, one unit per file"
+    if which == "silesia_files":                   # configs[3]: XH file mode
+        return cor.blob(), cor.foff, cor.flen, "12 Silesia-shaped files, 211938580 B, one unit per file"
     offs, lens = [], []                            # configs[2]: every file cut into independent 64 KiB units
-    for o, l in zip(foff, flen):
+    for o, l in zip(cor.foff, cor.flen):
         s = np.arange(0, int(l), 65536, dtype=np.uint64)
         offs.append(s + o); lens.append(np.minimum(65536, int(l) - s).astype(np.uint64))
-    return blob, np.concatenate(offs), np.concatenate(lens), "12 files cut into 3239 independent 64 KiB units, 211938580 B"
+    return cor.blob(), np.concatenate(offs), np.concatenate(lens), "12 files cut into 3239 independent 64 KiB units, 211938580 B"
 
 
 class Job:
-    def __init__(self, m, ctx, fmt, blob, in_off, in_len):
+    """one batch resident in HBM + its plan"""
+
+    def __init__(self, m, ctx, fmt, d_in, in_off, in_len):
         import torch
         self.m, self.ctx, self.fmt = m, ctx, fmt
         self.in_bytes = int(in_len.sum())
-        caps = [m.max_compressed_size(fmt, int(x)) + 2 for x in in_len]
+        caps = np.array([m.max_compressed_size(fmt, int(x)) + 2 for x in in_len], np.uint64)
         out_off, out_total = m.pack_offsets(caps)
         dev = torch.device("cuda", ctx.device)
-        self.d_in = torch.from_numpy(blob).to(dev)
+        self.d_in = d_in if hasattr(d_in, "data_ptr") else torch.from_numpy(d_in).to(dev)
         self.d_out = torch.empty(out_total + 16, dtype=torch.uint8, device=dev)
-        self.d_len = torch.zeros(len(in_len), dtype=torch.int64, device=dev)
-        self.d_st = torch.zeros(len(in_len), dtype=torch.int32, device=dev)
+        self.d_len = torch.zeros(max(1, len(in_len)), dtype=torch.int64, device=dev)
+        self.d_st = torch.zeros(max(1, len(in_len)), dtype=torch.int32, device=dev)
+        self.caps, self.out_off, self.n = caps, out_off, len(in_len)
         self.plan = m.Plan(ctx, fmt, in_off, in_len, out_off, caps)
 
     def step(self):
         self.plan.execute(self.d_in, self.d_out, self.d_len, self.d_st)
 
     def out_bytes(self):
-        assert bool((self.d_st == 0).all().item()), "a unit reported an error status"
-        return int(self.d_len.sum().item())
+        assert bool((self.d_st[: self.n] == 0).all().item()), "a unit reported an error status"
+        return int(self.d_len[: self.n].sum().item())
 
     def close(self):
         self.plan.close()
-
-
-def decompress_leg(m, ctx, fmt, blob, in_off, in_len, desc, steps, sharding):
-    """SURVEY 8f-1: decode on the GPU what the GPU compressor wrote for this workload, check that the input comes back,
-    report decompressed MB/s (HBM-resident, like `value`)."""
-    import torch
-    job = Job(m, ctx, fmt, blob, in_off, in_len)
-    job.step(); torch.cuda.synchronize()
-    comp_len = job.d_len.cpu().numpy().astype(np.uint64)
-    assert bool((job.d_st == 0).all().item())
-    d_back = torch.zeros(len(blob) + 16, dtype=torch.uint8, device=job.d_in.device)
-    caps = [m.max_compressed_size(fmt, int(x)) + 2 for x in in_len]
-    comp_off, _ = m.pack_offsets(caps)
-    plan = m.Plan(ctx, fmt, comp_off, comp_len, in_off, in_len, decompress=True)
-
-    class D:
-        pass
-    d = D(); d.ctx = ctx
-    d.step = lambda: plan.execute(job.d_out, d_back, job.d_len2, job.d_st2)
-    job.d_len2 = torch.zeros_like(job.d_len); job.d_st2 = torch.full_like(job.d_st, -9)
-    dt, prof = timed(d, steps, 1, sharding)
-    ok = bool((job.d_st2 == 0).all().item()) and bool(torch.equal(job.d_len2.cpu(), torch.from_numpy(in_len.astype(np.int64)))) \
-        and bool(torch.equal(d_back[: len(blob)], job.d_in[: len(blob)]))
-    res = {"MB_per_s": round(job.in_bytes * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3), "workload": desc,
-           "round_trip_ok": ok, "kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
-    plan.close(); job.close()
-    return res
+        self.d_in = self.d_out = None
 
 
 def timed(job, steps, warmup, sharding):
+    """EXACTLY `steps` steps between barrier + synchronize on both sides; HIP events around every kernel on its launch stream"""
     import torch
     for _ in range(warmup):
         job.step()
     torch.cuda.synchronize()
     job.ctx.profile_read()                         # drop warm-up records
-    job.ctx.profile_enable(True)                   # HIP events around every kernel, on the stream they are launched on
+    job.ctx.profile_enable(True)
     sharding.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -129,39 +177,59 @@ def timed(job, steps, warmup, sharding):
     return dt, prof
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_pmc_traffic.json: separate rocprofv3
-    --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench workload, FETCH_SIZE doubled per the gfx950 note of the microarch
-    guide). Collected offline -- a live bench run cannot read PMCs -- so it is attached only when the file is present."""
+# ---------------------------------------------------------------- roofline ----------------------------------------------------------------
+def _profile_doc(name):
     try:
-        doc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        for k, v in doc["kernels"].items():
-            # (the library times kernel FAMILIES: lznt1_chunk_kernel covers lznt1_chunk4_kernel, the four-wave variant)
-            if re.sub(r"\d+_kernel$", "_kernel", k.split("<")[0]).endswith(kernel):
-                return v["hbm_bytes_per_launch_corrected"]
+        return json.load(open(os.path.join(ROOT, "profiles", "%s_%s.json" % (PROFILE_TAG, name))))
     except Exception:
-        pass
-    return None
+        return None
 
 
-def roofline(fmt, prof, in_bytes, out_bytes, steps):
-    name = DOMINANT[fmt]
+def pmc_traffic(fmt, timer_name, workload_key):
+    """HBM bytes per launch of the kernel behind `timer_name` for this codec, from the committed PMC passes
+    (profiles/r02_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench command, FETCH_SIZE
+    doubled per the gfx950 note of the microarch guide). Collected offline -- a live run cannot read PMCs -- and keyed by the exact
+    kernel symbol (template arguments included) AND the workload, so it is attached only to the launch it was measured on."""
+    doc = _profile_doc("pmc_traffic")
+    sym = SYMBOLS.get((fmt, timer_name))
+    if not doc or not sym:
+        return None
+    rec = doc.get("workloads", {}).get(workload_key, {}).get(sym)
+    return rec["hbm_bytes_per_launch_corrected"] if rec else None
+
+
+def secondary_bound(fmt, timer_name, workload_key):
+    """What actually limits the kernel (the HBM fraction of these latency / issue-bound integer kernels says little): busiest
+    pipe and wait shares from the committed SQ-counter passes (profiles/r02_sq_counters.json)."""
+    doc = _profile_doc("sq_counters")
+    sym = SYMBOLS.get((fmt, timer_name))
+    if not doc or not sym:
+        return None
+    return doc.get("workloads", {}).get(workload_key, {}).get(sym)
+
+
+def roofline(fmt, prof, in_bytes, out_bytes, steps, workload_key):
     tot_ms = sum(v[0] for v in prof.values())
-    dom = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else name
-    ms, cnt = prof.get(dom, (0.0, 0))
-    per_launch_ms = ms / cnt if cnt else float("nan")
-    launches_per_step = cnt / steps if cnt else 1          # 2 when the batch runs as two halves on two streams (DESIGN 5)
+    if not prof:
+        return None
+    dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
+    ms, cnt = prof[dom]
+    per_launch_ms = ms / cnt
+    launches_per_step = cnt / steps
     # algorithmic bytes (SURVEY.md 8d): 1 B HBM read + CR B HBM write per input byte, for the units one launch processes
     alg = (in_bytes + out_bytes) / launches_per_step
-    ach = alg / (per_launch_ms * 1e-3) / 1e9 if cnt else float("nan")
-    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom),
+    ach = alg / (per_launch_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": SYMBOLS.get((fmt, dom), dom), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(fmt, dom, workload_key),
+            "hbm_read_frac": round(in_bytes / launches_per_step / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "kernel_ms_per_launch": round(per_launch_ms, 4), "launches_per_step": launches_per_step,
             "kernel_share_of_gpu_time": round(ms / tot_ms, 3) if tot_ms else None,
             "algorithmic_bytes_per_launch": int(alg),
+            "secondary": secondary_bound(fmt, dom, workload_key),
             "kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
 
 
+# ---------------------------------------------------------------- CPU baselines ----------------------------------------------------------------
 def _cpu_timed(fn, fmt, units, caps, cores, budget_s):
     """passes and seconds of fn over the units on `cores` C threads (oracle.loader.time_units: no interpreter between the calls)"""
     from oracle import loader
@@ -172,10 +240,10 @@ def _cpu_timed(fn, fmt, units, caps, cores, budget_s):
     return 1 + more, dt
 
 
-def cpu_baseline(fmt, blob, budget_s=12.0):
+def cpu_baseline(fmt, blob, budget_s=10.0):
     """The reference's own CPU encoder (oracle/_ref, compiled from /root/reference) -- or our C port when that file did not
-    travel -- on this host's cores, over a bounded sample of the SAME workload (prefix of the batch, split on 64 KiB / 4 KiB
-    aligned boundaries so that every thread does independent ms_compress calls). Reported baseline, not the target."""
+    travel -- on this host's cores, over a bounded sample of the SAME workload (prefix of the batch, split on 64 KiB-aligned
+    boundaries so that every thread does independent ms_compress calls). Reported baseline, not the target."""
     from oracle import loader
     ref = loader.load_ref()
     kind = "reference" if ref is not None else "port"
@@ -192,8 +260,8 @@ def cpu_baseline(fmt, blob, budget_s=12.0):
 
 
 def cpu_decompress_baseline(fmt, blob, budget_s=3.0):
-    """The reference's CPU decoder beside the GPU decompression leg: the same kind of bounded sample as cpu_baseline (64 KiB units
-    for the Xpress formats, 4 MiB pieces for LZNT1; compressed by the reference, untimed), all host cores, output MB/s."""
+    """The reference's CPU decoder beside the GPU decompression leg: the same kind of bounded sample (64 KiB units for the Xpress
+    formats, 4 MiB pieces for LZNT1; compressed by the reference, untimed), all host cores, output MB/s."""
     from oracle import loader
     ref = loader.load_ref()
     kind = "reference" if ref is not None else "port"
@@ -212,76 +280,134 @@ def cpu_decompress_baseline(fmt, blob, budget_s=3.0):
             "sample": "%d passes over the first %d B of the batch as %d independent ms_decompress calls of %d B" % (passes, sample, len(units), unit)}
 
 
+# ---------------------------------------------------------------- legs ----------------------------------------------------------------
+def decompress_leg(m, ctx, fmt, blob, in_off, in_len, desc, steps, sharding):
+    """SURVEY 8f-1: decode on the GPU what the GPU compressor wrote for this workload, check that the input comes back,
+    report decompressed MB/s (HBM-resident, like `value`)."""
+    import torch
+    job = Job(m, ctx, fmt, blob, in_off, in_len)
+    job.step(); torch.cuda.synchronize()
+    comp_len = job.d_len.cpu().numpy().astype(np.uint64)
+    assert bool((job.d_st == 0).all().item())
+    d_back = torch.zeros(len(blob) + 16, dtype=torch.uint8, device=job.d_in.device)
+    plan = m.Plan(ctx, fmt, job.out_off, comp_len, in_off, in_len, decompress=True)
+    d_len2 = torch.zeros_like(job.d_len); d_st2 = torch.full_like(job.d_st, -9)
+
+    class D:
+        pass
+    d = D(); d.ctx = ctx
+    d.step = lambda: plan.execute(job.d_out, d_back, d_len2, d_st2)
+    dt, prof = timed(d, steps, 1, sharding)
+    ok = bool((d_st2 == 0).all().item()) and bool(torch.equal(d_len2.cpu(), torch.from_numpy(in_len.astype(np.int64)))) \
+        and bool(torch.equal(d_back[: len(blob)], job.d_in[: len(blob)]))
+    res = {"MB_per_s": round(job.in_bytes * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3), "workload": desc,
+           "round_trip_ok": ok, "kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
+    plan.close(); job.close()
+    return res
+
+
+def sharded_leg(m, ctx, cor, fmt, rank, world, steps, warmup, sharding, dev):
+    """One codec over the config-5 job: this rank's contiguous unit range, timed; whole-job figures by MAX / SUM over the ranks."""
+    off, ln, desc = config5_units(cor, fmt)
+    s, e, g0, g1, my_off, my_len = sharding.shard_job(off, ln, world, rank)
+    d_in = cor.device_range(g0, g1)
+    job = Job(m, ctx, fmt, d_in, my_off, my_len)
+    dt, prof = timed(job, steps, warmup, sharding)
+    out_bytes = job.out_bytes()
+    job_dt, job_bytes = sharding.reduce_job(dt, job.in_bytes * steps, device=dev)
+    _, job_out = sharding.reduce_job(0.0, out_bytes, device=dev)
+    assert job_bytes == int(ln.sum()) * steps, "the shards do not cover the job"
+    res = {"MB_per_s": round(job_bytes / job_dt / 1e6, 1), "MiB_per_s": round(job_bytes / job_dt / 2 ** 20, 1), "ms_per_step": round(job_dt / steps * 1e3, 4),
+           "steps": steps, "workload": desc, "units": int(len(ln)), "units_rank0": int(e - s), "bytes_rank0": job.in_bytes,
+           "compression_ratio": round(job_out / int(ln.sum()), 4),
+           "roofline": roofline(fmt, prof, job.in_bytes, out_bytes, steps, "config5_n%d" % world)}
+    job.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--codec", default="lznt1", choices=["lznt1", "xpress", "xpress_huff"])
-    ap.add_argument("--all", action="store_true", help="also time the other codecs (default at N=1)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--replicas", type=int, default=1, help="tile the workload R times per GPU (BASELINE config 5 uses 16x Silesia over 8 GPUs)")
+    ap.add_argument("--codec", default="lznt1", choices=["lznt1", "xpress", "xpress_huff"], help="headline codec")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
+    ap.add_argument("--no-extra", action="store_true", help="headline leg only")
+    ap.add_argument("--oversubscribe", action="store_true", help="TEST ONLY: let the N ranks share the visible GPUs (gloo for the timing reduction); "
+                    "exercises the sharded multi-rank path on a 1-GPU box, the line is marked and is not an N-GPU measurement")
     args = ap.parse_args()
+    want = max(1, args.gpus)
+    if want > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(want)
 
     import torch
     import ms_compress_amd as m
     from ms_compress_amd import corpus, sharding
-    rank, local_rank, world = sharding.init_distributed()
-    assert world == max(1, args.gpus) or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    rank, local_rank, world = sharding.init_distributed("gloo" if args.oversubscribe else None)
+    if world != want:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s); launch with torch.distributed.run --nproc-per-node %d "
+                 "(or let bench.py spawn them: no WORLD_SIZE in the environment)" % (want, world, want))
+    if args.oversubscribe:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    ctx = m.Context(device=local_rank)
-    fmt = m.FORMATS[args.codec]
-    which = {"lznt1": "mozilla", "xpress": "silesia_units64k", "xpress_huff": "silesia_files"}[args.codec]
-    blob, in_off, in_len, desc = build_workload(m, corpus, fmt, which)
-    if args.replicas > 1:
-        R = args.replicas
-        in_off = np.concatenate([in_off + np.uint64(r * len(blob)) for r in range(R)])
-        in_len = np.tile(in_len, R)
-        blob = np.tile(blob, R)
-        desc += " x%d replicas" % R
-    job = Job(m, ctx, fmt, blob, in_off, in_len)
-    dt, prof = timed(job, args.steps, args.warmup, sharding)
-    out_bytes = job.out_bytes()
     dev = torch.device("cuda", local_rank)
-    job_dt, job_bytes = sharding.reduce_job(dt, job.in_bytes * args.steps, device=dev)
+    rdev = None if args.oversubscribe else dev           # where the timing reduction's tensors live (gloo: host)
+    ctx = m.Context(device=local_rank)
+    cor = Corpus(corpus, dev)
+    fmt = m.FORMATS[args.codec]
+    steps2 = max(3, args.steps // 4)
+
+    head = sharded_leg(m, ctx, cor, fmt, rank, world, args.steps, args.warmup, sharding, rdev)
     res = {
         "metric": "input MB/s (%s compress, bit-exact with the reference CPU encoder)" % args.codec,
-        "value": round(job_bytes / job_dt / 1e6, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(job_dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": head["MB_per_s"], "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic" if corpus.source() == "synthetic" else corpus.source(),
-        "config": {"workload": "%s: %s; one %s block per chunk" % (args.codec, desc, {2: "4 KiB", 3: "64 KiB", 4: "64 KiB"}[fmt]),
-                   "bytes_per_step_per_gpu": job.in_bytes, "units_per_gpu": int(len(in_len)), "compression_ratio": round(out_bytes / job.in_bytes, 4),
-                   "parallelism": "replica-per-gpu x%d (independent units, no collective)" % world, "MiB_per_s": round(job_bytes / job_dt / 2 ** 20, 1)},
-        "roofline": roofline(fmt, prof, job.in_bytes, out_bytes, args.steps),
+        "config": {"workload": "BASELINE configs[4], %s leg: %s; one %s block per chunk" % (args.codec, head["workload"], {2: "4 KiB", 3: "64 KiB", 4: "64 KiB"}[fmt]),
+                   "bytes_per_step": cor.total * REPLICAS, "units": head["units"],
+                   "bytes_rank0": head["bytes_rank0"], "compression_ratio": head["compression_ratio"],
+                   "parallelism": "shard-per-gpu x%d (sharding.shard_ranges: contiguous unit ranges balanced by bytes, no collective on the data path)" % world,
+                   "MiB_per_s": head["MiB_per_s"]},
+        "roofline": head["roofline"],
     }
-    job.close()
+    if args.oversubscribe:
+        res["oversubscribed"] = "TEST RUN: %d ranks shared %d GPU(s); not an %d-GPU measurement" % (world, torch.cuda.device_count(), world)
     if rank == 0 and world == 1 and not args.no_cpu:
-        res["cpu_baseline"] = cpu_baseline(fmt, blob)
-    if world == 1 or args.all:
-        extra = {}
+        res["cpu_baseline"] = cpu_baseline(fmt, cor.blob())
+    extra = {}
+    if not args.no_extra:
+        c5 = {}
+        for codec in ("lznt1", "xpress", "xpress_huff"):
+            if codec != args.codec:
+                c5[codec] = sharded_leg(m, ctx, cor, m.FORMATS[codec], rank, world, steps2, 1, sharding, rdev)
+                if rank == 0 and world == 1 and not args.no_cpu:
+                    c5[codec]["cpu_baseline"] = cpu_baseline(m.FORMATS[codec], cor.blob())
+        extra["config5"] = c5
+    if world == 1 and not args.no_extra:
+        single = {}
         for codec, wl in (("lznt1", "mozilla"), ("xpress", "silesia_units64k"), ("xpress_huff", "silesia_files")):
-            if codec == args.codec:
-                continue
             f2 = m.FORMATS[codec]
-            b2, o2, l2, d2 = build_workload(m, corpus, f2, wl)
+            b2, o2, l2, d2 = single_gpu_workload(cor, wl)
             j2 = Job(m, ctx, f2, b2, o2, l2)
-            t2, p2 = timed(j2, max(3, args.steps // 4), 1, sharding)
+            n2 = args.steps if codec == "lznt1" else steps2
+            t2, p2 = timed(j2, n2, 3 if codec == "lznt1" else 1, sharding)
             ob = j2.out_bytes()
-            steps2 = max(3, args.steps // 4)
-            extra[codec] = {"MB_per_s": round(j2.in_bytes * steps2 / t2 / 1e6, 1), "ms_per_step": round(t2 / steps2 * 1e3, 3),
-                            "workload": d2, "compression_ratio": round(ob / j2.in_bytes, 4), "roofline": roofline(f2, p2, j2.in_bytes, ob, steps2)}
+            single[codec] = {"MB_per_s": round(j2.in_bytes * n2 / t2 / 1e6, 1), "ms_per_step": round(t2 / n2 * 1e3, 4), "steps": n2,
+                             "workload": d2, "compression_ratio": round(ob / j2.in_bytes, 4), "roofline": roofline(f2, p2, j2.in_bytes, ob, n2, "single_gpu")}
             j2.close()
+        extra["single_gpu"] = single
         dec = {}
         for codec, wl in (("lznt1", "mozilla"), ("xpress", "silesia_units64k"), ("xpress_huff", "silesia_units64k")):
             f2 = m.FORMATS[codec]
-            b2, o2, l2, d2 = build_workload(m, corpus, f2, wl)
+            b2, o2, l2, d2 = single_gpu_workload(cor, wl)
             dec[codec] = decompress_leg(m, ctx, f2, b2, o2, l2, d2, 3, sharding)
-            if rank == 0 and not args.no_cpu:
+            if not args.no_cpu:
                 dec[codec]["cpu_baseline"] = cpu_decompress_baseline(f2, b2)
         extra["decompress"] = dec
+    if extra:
         res["extra"] = extra
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:
         torch.distributed.destroy_process_group()

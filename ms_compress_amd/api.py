@@ -237,6 +237,23 @@ class Plan:
             pass
 
 
+def compact_batch(ctx, out_off, out_cap, d_out, d_out_len):
+    """mscomp_amd_compact_batch: the outputs of an executed batch packed back to back, in unit order, on the
+    device. Returns (d_packed uint8 tensor, d_packed_off int64 tensor of n + 1 offsets); enqueued on the ctx stream."""
+    import torch
+    out_off = np.ascontiguousarray(out_off, dtype=np.uint64)
+    out_cap = np.ascontiguousarray(out_cap, dtype=np.uint64)
+    n = len(out_off)
+    dev = torch.device("cuda", ctx.device)
+    d_packed = torch.empty(int(out_cap.sum()) + 16, dtype=torch.uint8, device=dev)
+    d_poff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    st = ctx.lib.mscomp_amd_compact_batch(ctx._h, n, C.c_void_p(d_out.data_ptr()), out_off.ctypes.data, out_cap.ctypes.data,
+                                          C.c_void_p(d_out_len.data_ptr()), C.c_void_p(d_packed.data_ptr()), C.c_void_p(d_poff.data_ptr()))
+    if st != MSCOMP_OK:
+        raise MSCompError(st, "mscomp_amd_compact_batch")
+    return d_packed, d_poff
+
+
 def decompress_units(fmt, units, capacities, ctx=None):
     """Decompress a list of independent compressed buffers on the GPU (each exactly as one ms_decompress call would, with
     *out_len = capacities[i] on entry). Returns (list of bytes, or None where the status is not MSCOMP_OK; list of status)."""
@@ -282,9 +299,3 @@ def compress_units(fmt, units, ctx=None, capacities=None, decompress=False):
     return res, [int(x) for x in h_st[: len(units)]]
 
 
-def format_supported(fmt):
-    """True when the loaded library implements the codec (all three do; kept for staged bring-up/testing)."""
-    return int(fmt) in SUPPORTED
-
-
-SUPPORTED = {MSCOMP_LZNT1, MSCOMP_XPRESS, MSCOMP_XPRESS_HUFF}

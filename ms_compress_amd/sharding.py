@@ -28,6 +28,19 @@ def shard_ranges(lengths, world):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
+def shard_job(unit_off, unit_len, world, rank):
+    """This rank's share of a job whose units lie back to back (ascending offsets) in one global byte range: units [s, e), the
+    global bytes [g0, g1) it has to hold in HBM, and the units' offsets relative to g0. An empty share gives s == e, g0 == g1."""
+    unit_off = np.asarray(unit_off, dtype=np.uint64)
+    unit_len = np.asarray(unit_len, dtype=np.uint64)
+    s, e = shard_ranges(unit_len, world)[rank]
+    if e == s:
+        return s, e, 0, 0, unit_off[s:e], unit_len[s:e]
+    g0 = int(unit_off[s])
+    g1 = int(unit_off[e - 1] + unit_len[e - 1])
+    return s, e, g0, g1, unit_off[s:e] - np.uint64(g0), unit_len[s:e]
+
+
 def dist_env():
     """(rank, local_rank, world) from the torch.distributed.run environment (1 process when absent)."""
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))

@@ -24,6 +24,50 @@ def test_shard_ranges_cover_and_balance():
     assert shard_ranges([10, 20], 4)[-1][1] == 2                  # fewer units than ranks: empty ranges allowed
 
 
+def test_shard_job_covers_config5_for_every_codec():
+    """bench.py's split of BASELINE configs[4]: every unit in exactly one rank's contiguous range, local offsets inside the bytes
+    the rank holds, byte totals add up, balance within one unit (64 KiB units) or one file (file units)"""
+    from ms_compress_amd import corpus
+    from ms_compress_amd.sharding import shard_job
+    flen = np.array(corpus.SIZES, np.uint64)
+    foff = np.zeros(12, np.uint64); foff[1:] = np.cumsum(flen)[:-1]
+    xo = np.concatenate([np.arange(0, int(l), 65536, dtype=np.uint64) + o for o, l in zip(foff, flen)])
+    xl = np.concatenate([np.minimum(65536, int(l) - np.arange(0, int(l), 65536)).astype(np.uint64) for l in flen])
+    for uoff, ulen in ((foff, flen), (xo, xl)):
+        off = np.concatenate([uoff + np.uint64(r * corpus.TOTAL) for r in range(16)])
+        ln = np.tile(ulen, 16)
+        for world in (1, 2, 3, 4, 8):
+            nxt, per = 0, []
+            for rank in range(world):
+                s, e, g0, g1, mo, ml = shard_job(off, ln, world, rank)
+                assert s == nxt and e >= s
+                nxt = e
+                per.append(int(ml.sum()))
+                if e > s:
+                    assert int(mo[0]) == 0 and int(mo[-1] + ml[-1]) == g1 - g0 and g0 == int(off[s])
+                    assert np.array_equal(mo + np.uint64(g0), off[s:e])
+            assert nxt == len(ln) and sum(per) == 3391017280
+            assert max(per) - min(per) <= 2 * int(ulen.max())
+
+
+def test_bench_refuses_an_n_gpu_run_without_n_gpus():
+    """python bench.py --gpus 2 where fewer than 2 GPUs are visible: loud failure, never a one-GPU line under that name"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "refusing" in r.stderr and not r.stdout.strip()
+    # launched by a launcher with the wrong world size: also refused
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but the launcher started 1 rank" in r.stderr and not r.stdout.strip()
+
+
 def _worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -34,7 +78,9 @@ def _worker(rank, world, port, q):
     import random
     rnd = random.Random(3)
     units = [bytes(rnd.getrandbits(8) & 0x3F for _ in range(rnd.randint(0, 9000))) for _ in range(37)]
-    s, e = sharding.shard_ranges([len(u) for u in units], w)[r]
+    lens = [len(u) for u in units]
+    s, e, g0, g1, mo, ml = sharding.shard_job(np.concatenate([[0], np.cumsum(lens)[:-1]]), lens, w, r)
+    assert (e - s, int(ml.sum())) == (len(units[s:e]), sum(lens[s:e]))
     mine = [loader.oracle_compress(2, u)[1] for u in units[s:e]]
     sharding.barrier()
     t, b = sharding.reduce_job(1.0 + rank, sum(len(u) for u in units[s:e]))
