@@ -181,6 +181,9 @@ int          mscomp_amd_profile_read(mscomp_amd_ctx* ctx, const char** names, do
  * found by the HIP hash-chain match finder. max_off = 0x2000 (Xpress) / 0xFFFF with clip=1 (Xpress+Huffman). */
 MSCompStatus mscomp_amd_debug_xpress_matches(mscomp_amd_ctx* ctx, const uint8_t* d_in, size_t in_len, uint32_t max_off, int clip,
                                              uint16_t* h_len3, uint16_t* h_off);
+/* Stage-level test hook: the code lengths HuffmanEncoder<15,512>::CreateCodes (include/mscomp/HuffmanEncoder.h:58-107, the heap build with
+ * its > 15-bit rescale loop) gives for n histograms of 512 counts; h_counts (n x 512 uint32) and h_lens (n x 512 bytes) are host arrays. */
+MSCompStatus mscomp_amd_debug_huff_lengths(mscomp_amd_ctx* ctx, const uint32_t* h_counts, size_t n, uint8_t* h_lens);
 /* Test hook: the Xpress parse/emit stage has two bit-identical kernels (one wave per unit; four
  * or sixteen waves per unit with speculative segments). 0 = chosen by batch size (default), 1 / 2 / 3 = force. Process-wide. */
 void         mscomp_amd_debug_set_xpress_emit(int mode);

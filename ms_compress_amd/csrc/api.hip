@@ -571,6 +571,19 @@ MSCompStatus mscomp_amd_debug_xpress_matches(mscomp_amd_ctx* c, const uint8_t* d
 	return ok ? MSCOMP_OK : MSCOMP_ERRNO;
 }
 
+// Stage-level test hook: HuffmanEncoder<15,512>::CreateCodes (HuffmanEncoder.h:58-107) for n histograms of 512 counts (host arrays)
+MSCompStatus mscomp_amd_debug_huff_lengths(mscomp_amd_ctx* c, const uint32_t* h_counts, size_t n, uint8_t* h_lens)
+{
+	if (!c || (n && (!h_counts || !h_lens)) || n > 0x100000u) { return MSCOMP_ARG_ERROR; }
+	if (!n) { return MSCOMP_OK; }
+	DeviceGuard g(c->device);
+	if (!g.ok || !c->counts.reserve(n * 2048) || !c->lens.reserve(n * 512)) { return MSCOMP_MEM_ERROR; }
+	bool ok = hipMemcpyAsync(c->counts.p, h_counts, n * 2048, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+	if (ok) { launch_xh_huff_debug(c->stream, static_cast<const uint32_t*>(c->counts.p), static_cast<uint8_t*>(c->lens.p), (uint32_t)n); }
+	ok = ok && hipMemcpyAsync(h_lens, c->lens.p, n * 512, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+	return ok ? MSCOMP_OK : MSCOMP_ERRNO;
+}
+
 // Test hook: which Xpress parse/emit kernel runs (0 = chosen by batch size, 1 = one wave per unit, 2 = four waves per unit).
 void mscomp_amd_debug_set_xpress_emit(int mode) { set_xpress_emit_mode(mode); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 // ... and which LZNT1 chunk kernel (0 = default, 1 = one wave per chunk, 2 = four waves per chunk).

@@ -30,6 +30,7 @@ void launch_xh_parse(hipStream_t st, const uint8_t* d_in, const BatchTables& bt,
                      u64* tokbits, uint32_t* counts, uint32_t* extra);
 void launch_xh_huff(hipStream_t st, const BatchTables& bt, const uint32_t* counts, const uint32_t* extra, uint8_t* lens, uint16_t* codes,
                     uint32_t* chunk_size, uint32_t* fb_list, uint32_t* fb_count, uint32_t* fbflag);
+void launch_xh_huff_debug(hipStream_t st, const uint32_t* counts, uint8_t* lens, uint32_t n);
 void launch_xh_fallback(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint32_t* fb_list, const uint32_t* fb_count,
                         uint32_t blocks, u64* tokbits, uint8_t* lens, uint16_t* codes, uint32_t* chunk_size);
 void launch_xh_encode(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* mlen3, const uint16_t* moff,

@@ -7,8 +7,8 @@
 //                      ballot masks; histogram by LDS atomics. The reference's private intermediate byte buffer is not
 //                      reproduced: tokens stay as (token-start bit mask, per-position len-3 / offset).
 //   xh_huff_kernel     HuffmanEncoder<15,512>::CreateCodes (/root/reference/include/mscomp/HuffmanEncoder.h:58-127):
-//                      the bzip2-style heap is simulated operation for operation (tie-breaking defines the lengths) by
-//                      one lane in LDS, depths / size test (xh_calc_compressed_len :181-188) / canonical codes (:109-123)
+//                      the bzip2-style heap is simulated operation for operation (tie-breaking defines the lengths) in
+//                      LDS, every sift by the whole wave in one round trip, depths / size test (xh_calc_compressed_len :181-188) / canonical codes (:109-123)
 //                      by the whole wave; flags chunks that need the fallback (:274, :310).
 //   xh_fallback_kernel xh_compress_no_matching + CreateCodesSlow (:155-180, HuffmanEncoder.h:129-226): literals only,
 //                      package-merge lengths (packages = per-symbol multiplicity vectors in an LDS pool).
@@ -291,41 +291,67 @@ struct HuffLds {
 	uint32_t flag;
 };
 
-// HEAP_PUSH / HEAP_POP (HuffmanEncoder.h:31-55), executed by ONE lane. Keys are compared on the weight only, exactly
-// like the reference (`weights[x] < weights[heap[j>>1]]`); carrying the weight inside the heap entry makes every sift
-// level a single LDS read (the two children of a node are one aligned 16-byte read). Entries behind the last one hold the
-// largest weight, so "no child" / "no right child" need no index test: such a child never wins and always stops the sift
-// (the child index is clamped to the pair 514/515, which is never occupied).
+// HEAP_PUSH / HEAP_POP (HuffmanEncoder.h:31-55) by the WHOLE wave, one LDS round trip per sift instead of one per level.
+// The reference's order of operations (and with it every tie-break) is kept, because both sifts move along a path that does
+// not depend on the item being sifted:
+//   push at slot j: the path is j's ancestors j>>1, j>>2, ...; lane l reads ancestor l, the item passes every ancestor with a
+//       larger weight (`weights[x] < weights[heap[j>>1]]`; the weights of the ancestors fall towards the root, so these
+//       are the first m of them), lanes 1..m move their ancestor one level down, lane 0 drops the item at j>>m.
+//   pop: the last entry t goes to the root and sinks along the "smaller child" path (right child only if STRICTLY
+//       smaller, :48), which is a property of the heap alone: every lane compares the two children of 4 nodes, four ballots
+//       give the choice at every inner node, the scalar unit follows the 8 choices down to the leaf level F; the path is
+//       F>>8, F>>7, ..., F. Lane l reads path node l; t passes every node whose weight is not larger
+//       (`weights[t] < weights[heap[j]]` stops, :49; the weights grow along the path), lanes 1..m-1 move their node one
+//       level up, lane 0 drops t at path node m-1.
+// Entries behind the last one hold the largest weight, so "no child" needs no index test: such a child never wins a
+// comparison against a real entry and always stops the sift. Keys are compared on the weight only, exactly like the reference.
+// The DS instructions of a wave execute in program order, so "read t, overwrite its slot, read the children" needs no wait in
+// between -- only the compiler has to keep the order (HH_ORDER: no instruction, a scheduling fence).
+// (One lane replaying the heap level by level: 3.1 ms for the 3 239 chunks of the bench corpus; this: 1.4 ms, bound by
+// instruction issue -- 13 single-purpose waves per CU, ~200 instructions per merge step.)
 #define HH_SENT 0xFFFFFFFFu
-__device__ __forceinline__ void hh_push(HuffLds& h, uint32_t& hl, uint2 e)
+#define HH_ORDER() asm volatile("" ::: "memory")
+__device__ __forceinline__ void hh_push(HuffLds& h, uint32_t hl_new, uint2 e, uint32_t lane)     // hl_new = slot of the new entry (heap length after the push)
 {
-	uint32_t j = ++hl;
-	for (;;) {
-		const uint2 par = h.heap[j >> 1];
-		if (!(e.x < par.x)) { break; }
-		h.heap[j] = par; j >>= 1;
-	}
-	h.heap[j] = e;
+	const uint32_t a = hl_new >> lane;                             // lane l: ancestor l (0 = the sentinel in front of the heap, weight 0)
+	uint2 par = make_uint2(0u, 0u);
+	if (lane >= 1u && lane <= 9u) { par = h.heap[a]; }
+	const u64 up = __ballot(lane >= 1u && lane <= 9u && e.x < par.x) >> 1;
+	const uint32_t m = (uint32_t)__builtin_ctzll(~up);             // ancestors passed (heap[0] has weight 0: never passed)
+	if (lane >= 1u && lane <= m) { h.heap[hl_new >> (lane - 1u)] = par; }
+	if (lane == 0u) { h.heap[hl_new >> m] = e; }
+	HH_ORDER();
 }
-__device__ __forceinline__ uint2 hh_pop(HuffLds& h, uint32_t& hl)
+__device__ __forceinline__ uint2 hh_pop(HuffLds& h, uint32_t hl_old, uint32_t lane)               // hl_old = heap length before the pop
 {
-	const uint2 top = h.heap[1], t = h.heap[hl];
-	h.heap[hl] = make_uint2(HH_SENT, 0); --hl;
+	const uint2 top = h.heap[1], t = h.heap[hl_old];               // (all lanes read the same two entries: broadcast)
+	HH_ORDER();
+	if (lane == 0u) { h.heap[hl_old] = make_uint2(HH_SENT, 0u); }
+	HH_ORDER();
+	// the smaller child of every inner node: node i = 64 q + lane reads its children 2 i, 2 i + 1 (one 16-byte aligned pair)
+	u64 mask[4];
+	uint4 ch[4];
+	#pragma unroll
+	for (uint32_t q = 0; q < 4u; ++q) { ch[q] = *reinterpret_cast<const uint4*>(&h.heap[2u * (64u * q + lane)]); }
+	#pragma unroll
+	for (uint32_t q = 0; q < 4u; ++q) { mask[q] = __ballot(ch[q].z < ch[q].x); }
 	uint32_t i = 1;
-	for (;;) {
-		uint32_t j = i << 1;
-		j = j < 514u ? j : 514u;
-		const uint4 ch = *reinterpret_cast<const uint4*>(&h.heap[j]);    // children j and j+1 (j is even: 16 B aligned)
-		const bool right = ch.z < ch.x;
-		const uint32_t cw = right ? ch.z : ch.x, cn = right ? ch.w : ch.y;
-		if (t.x < cw) { break; }
-		h.heap[i] = make_uint2(cw, cn); i = j + (right ? 1u : 0u);
-	}
-	h.heap[i] = t;
+	#pragma unroll
+	for (int s = 0; s < 6; ++s) { i = 2u * i + (uint32_t)((mask[0] >> i) & 1u); }          // levels 0..5: nodes 1..63
+	i = 2u * i + (uint32_t)((mask[1] >> (i - 64u)) & 1u);                                   // level 6: nodes 64..127
+	{ const u64 mk = i < 192u ? mask[2] : mask[3]; i = 2u * i + (uint32_t)((mk >> (i & 63u)) & 1u); }   // level 7: nodes 128..255
+	const uint32_t F = i;                                          // 256..511: the path's node on the leaf level
+	uint2 k = make_uint2(HH_SENT, 0u);
+	if (lane >= 1u && lane <= 8u) { k = h.heap[F >> (8u - lane)]; }
+	const u64 stop = __ballot(lane >= 1u && lane <= 8u && t.x < k.x);
+	const uint32_t m = stop ? (uint32_t)__builtin_ctzll(stop) : 9u;   // t comes to rest on level m - 1
+	if (lane >= 1u && lane < m) { h.heap[F >> (9u - lane)] = k; }
+	if (lane == 0u) { h.heap[F >> (9u - m)] = t; }
+	HH_ORDER();
 	return top;
 }
 
-// CreateCodes lengths from h.cnt -> h.lens (whole wave enters; lane 0 runs the heap)
+// CreateCodes lengths from h.cnt -> h.lens (one wave)
 __device__ void huff_lengths_fast(HuffLds& h, uint32_t lane)
 {
 	for (uint32_t i = lane; i < 512u; i += 64u) { const uint32_t c = h.cnt[i]; h.wleaf[i] = (c ? c : 1u) << 8; }   // :69
@@ -334,18 +360,18 @@ __device__ void huff_lengths_fast(HuffLds& h, uint32_t lane)
 		for (uint32_t i = lane; i < 1024u; i += 64u) { h.parent[i] = 0; }
 		for (uint32_t i = lane; i < 516u; i += 64u) { h.heap[i] = i ? make_uint2(HH_SENT, 0) : make_uint2(0, 0); }
 		__syncthreads();
-		if (lane == 0) {
-			uint32_t hl = 0;
-			for (uint32_t i = 1; i <= 512u; ++i) { hh_push(h, hl, make_uint2(h.wleaf[i - 1u], i)); }
-			uint32_t nn = 512;
-			while (hl > 1) {
-				const uint2 ea = hh_pop(h, hl), eb = hh_pop(h, hl);
-				const uint32_t wa = ea.x, wb = eb.x;
-				const uint32_t da = wa & 0xFFu, db = wb & 0xFFu;
-				++nn; h.parent[ea.y] = (uint16_t)nn; h.parent[eb.y] = (uint16_t)nn;
-				const uint32_t wn = ((wa & ~0xFFu) + (wb & ~0xFFu)) | (1u + (da > db ? da : db));
-				hh_push(h, hl, make_uint2(wn, nn));
-			}
+		for (uint32_t i = 1; i <= 512u; ++i) { hh_push(h, i, make_uint2(h.wleaf[i - 1u], i), lane); }   // :74
+		uint32_t hl = 512, nn = 512;
+		while (hl > 1u) {                                           // :78-85
+			const uint2 ea = hh_pop(h, hl, lane); --hl;
+			const uint2 eb = hh_pop(h, hl, lane); --hl;
+			const uint32_t wa = ea.x, wb = eb.x;
+			const uint32_t da = wa & 0xFFu, db = wb & 0xFFu;
+			++nn;
+			if (lane == 0u) { h.parent[ea.y] = (uint16_t)nn; h.parent[eb.y] = (uint16_t)nn; }
+			const uint32_t wn = ((wa & ~0xFFu) + (wb & ~0xFFu)) | (1u + (da > db ? da : db));
+			++hl;
+			hh_push(h, hl, make_uint2(wn, nn), lane);
 		}
 		__syncthreads();
 		bool too_long = false;
@@ -416,6 +442,21 @@ __global__ __launch_bounds__(64) void xh_huff_kernel(BatchTables bt, const uint3
 	__syncthreads();
 	huff_store(h, lane, lens_out + (u64)lc * 512u, codes_out + (u64)lc * 512u);
 	if (lane == 0) { chunk_size[lc] = 256u + comp; fbflag[lc] = 0; }
+}
+
+// Stage-level test hook: code lengths of HuffmanEncoder<15,512>::CreateCodes for histograms given directly (one wave each)
+__global__ __launch_bounds__(64) void xh_huff_debug_kernel(const uint32_t* __restrict__ counts, uint8_t* __restrict__ lens_out)
+{
+	__shared__ HuffLds h;
+	const uint32_t lane = threadIdx.x;
+	for (uint32_t i = lane; i < 512u; i += 64u) { h.cnt[i] = counts[(u64)blockIdx.x * 512u + i]; }
+	__syncthreads();
+	huff_lengths_fast(h, lane);
+	reinterpret_cast<uint2*>(lens_out + (u64)blockIdx.x * 512u)[lane] = reinterpret_cast<const uint2*>(h.lens)[lane];
+}
+void launch_xh_huff_debug(hipStream_t st, const uint32_t* counts, uint8_t* lens, uint32_t n)
+{
+	if (n) { hipLaunchKernelGGL(xh_huff_debug_kernel, dim3(n), dim3(64), 0, st, counts, lens); }
 }
 
 // ===================================================================================================================

@@ -78,3 +78,39 @@ def decode_streams(fmt, compress, seed=5, n_corrupt=60):
             b[i] = rnd.choice((b[i] ^ (1 << rnd.randrange(8)), rnd.getrandbits(8), 0, 0xFF))
         out.append((bytes(b), len(d) + rnd.choice((0, 0, 100, 5000))))
     return out
+
+
+def huff_histograms(n=240, seed=11):
+    """512-bin symbol histograms for the Huffman builder (HuffmanEncoder<15,512>::CreateCodes): sparse / tiny counts (ties everywhere),
+    geometric counts (trees deeper than 15: the rescale loop runs 1-3 times), flat literal-heavy chunks with EOS, Zipf-shaped counts
+    with a match-symbol tail like real chunks, all-zero but one, all equal."""
+    rnd = random.Random(seed)
+    out = []
+    for case in range(n):
+        kind = case % 8
+        if kind == 0:
+            c = [rnd.randint(0, 3) * rnd.randint(0, 300) for _ in range(512)]
+        elif kind == 1:
+            c = [int(2 ** rnd.uniform(0, 16)) if rnd.random() < 0.3 else 0 for _ in range(512)]
+        elif kind == 2:
+            c = [rnd.randint(200, 300) for _ in range(256)] + [0] * 256
+            c[256] = 1
+        elif kind == 3:
+            c = [1 if rnd.random() < 0.05 else 0 for _ in range(512)]
+        elif kind == 4:
+            c = [int(40000 / (1 + i) ** rnd.uniform(0.8, 1.6)) for i in range(256)]
+            rnd.shuffle(c)
+            c += [int(3000 / (1 + (i % 16)) / (1 + i // 16)) if rnd.random() < 0.7 else 0 for i in range(256)]
+        elif kind == 5:
+            c = [0] * 512
+            c[rnd.randrange(512)] = rnd.randint(1, 65536)
+        elif kind == 6:
+            v = rnd.randint(0, 5)
+            c = [v] * 512
+        else:
+            c = [int(1.6 ** (i % 24)) if i % 3 == 0 else 0 for i in range(512)]         # Fibonacci-like growth: very deep tree
+            rnd.shuffle(c)
+        if sum(c) == 0 and kind != 6:
+            c[0] = 1
+        out.append(c)
+    return out

@@ -313,3 +313,33 @@ def test_one_shot_calls_from_several_host_threads(oracle, gpu_ctx):
     for t in th:
         t.join()
     assert not errors, errors
+
+
+def test_huffman_builder_stage(oracle, gpu_ctx):
+    """Stage-level parity of the Huffman builder (xh_huff_kernel's heap, HuffmanEncoder.h:58-107): code lengths for histograms given
+    directly -- against the oracle for every case and against the digests the reference's own header left in the fixture. A tie-break
+    or rescale regression shows up here as "histogram i, symbol s", not as a differing chunk digest."""
+    import ctypes as C
+    import hashlib
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "huff_lengths.json")))
+    hs = cases.huff_histograms()
+    rnd = __import__("random").Random(77)
+    more = [[rnd.randint(0, 2) * int(2 ** rnd.uniform(0, 14)) for _ in range(512)] for _ in range(400)]      # oracle-only cases
+    allc = np.asarray(hs + more, dtype=np.uint32)
+    lens = np.zeros((len(allc), 512), dtype=np.uint8)
+    st = gpu_ctx.lib.mscomp_amd_debug_huff_lengths(gpu_ctx._h, allc.ctypes.data, len(allc), lens.ctypes.data)
+    assert st == 0
+    lib = oracle.load_oracle()
+    deep = 0
+    for i in range(len(allc)):
+        want = np.zeros(512, dtype=np.uint8)
+        lib.orc_huff_lengths(allc[i].ctypes.data, want.ctypes.data)
+        if not np.array_equal(lens[i], want):
+            s = int(np.nonzero(lens[i] != want)[0][0])
+            raise AssertionError("histogram %d: symbol %d got length %d, CreateCodes gives %d" % (i, s, lens[i][s], want[s]))
+        deep += int(want.max() == 15)
+    assert deep > 20                                                  # the > 15-bit rescale loop was exercised
+    for i in range(len(hs)):
+        assert hashlib.sha256(lens[i].tobytes()).hexdigest()[:16] == gold["sha256_16_per_case"][i], i

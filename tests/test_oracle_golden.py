@@ -126,3 +126,22 @@ def test_decoders_golden(oracle, fmt):
         h.update(st.to_bytes(4, "little", signed=True)); h.update(len(out).to_bytes(8, "little")); h.update(out)
         asked += 1
     assert asked == g["asked"] and h.hexdigest() == g["sha256"]
+
+
+def test_oracle_huffman_lengths_match_the_reference_fixture(oracle):
+    """orc_huff_lengths (the restated CreateCodes) against the digest oracle/_ref/huff_ref (the reference's own header) left in
+    tests/golden/huff_lengths.json for the seeded histograms -- the rescale loop and heavy ties included."""
+    import hashlib
+    import numpy as np
+    import cases
+    gold = json.load(open(os.path.join(G, "huff_lengths.json")))
+    lib = oracle.load_oracle()
+    hs = cases.huff_histograms()
+    assert len(hs) == gold["cases"]
+    allh = hashlib.sha256()
+    for i, c in enumerate(hs):
+        a = np.asarray(c, dtype=np.uint32); lens = np.zeros(512, dtype=np.uint8)
+        lib.orc_huff_lengths(a.ctypes.data, lens.ctypes.data)
+        assert hashlib.sha256(lens.tobytes()).hexdigest()[:16] == gold["sha256_16_per_case"][i], i
+        allh.update(lens.tobytes())
+    assert allh.hexdigest() == gold["sha256_all"]
