@@ -187,6 +187,10 @@ MSCompStatus mscomp_amd_debug_huff_lengths(mscomp_amd_ctx* ctx, const uint32_t* 
 /* Test hook: the Xpress parse/emit stage has two bit-identical kernels (one wave per unit; four
  * or sixteen waves per unit with speculative segments). 0 = chosen by batch size (default), 1 / 2 / 3 = force. Process-wide. */
 void         mscomp_amd_debug_set_xpress_emit(int mode);
+/* Test hook: the Xpress-family match finder evaluates every position (1 = default) or runs lazily (0: Find only where a greedy parse can
+ * start a token, csrc/xlazy.hip; Xpress: units up to 64 KiB; exact but slower); the parse kernels get the same answers on
+ * every path they walk. Process-wide. */
+void         mscomp_amd_debug_set_finder(int mode);
 /* Test hook: the LZNT1 chunk stage has two bit-identical kernels (one wave / four waves per 4 KiB chunk). 0 = default, 1 / 2 = force. */
 void         mscomp_amd_debug_set_lznt1(int mode);
 /* Test hook: LZNT1 decompression finds the chunk headers by walking speculated chains per 48 KiB segment of the input; a segment

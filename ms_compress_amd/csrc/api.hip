@@ -24,6 +24,7 @@ namespace {
 // time, so a plain counter) and a process-wide one for the test hooks that switch kernels (atomic: any thread may call them
 // while other threads execute plans).
 static std::atomic<uint64_t> g_mode_epoch{1};
+static std::atomic<int> g_finder_mode{1};              // 1 = Find for every position (default), 0 = the lazy finder of xlazy.hip (experimental: exact, slower -- DESIGN 5)
 struct DevBuf {
 	void* p = nullptr; size_t cap = 0;
 	uint64_t* epoch = nullptr;                         // the owning context's epoch (null for plan-owned tables)
@@ -74,7 +75,7 @@ struct mscomp_amd_plan {
 	MSCompFormat format = MSCOMP_NONE;
 	bool decompress = false;
 	uint32_t n_units = 0, n_chunks = 0;
-	uint64_t total_in = 0;
+	uint64_t total_in = 0, max_unit = 0;
 	DevBuf tables;                                     // in_off | out_off | chunk_prefix
 	DevBuf tokpre;                                     // decompression by tokens: first token slot | first candidate slot of every unit (2 x (n_units + 1) u64)
 	uint32_t xhc_slots = 0;                            // candidate chunk slots of the batch
@@ -237,6 +238,7 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 		if (decompress && in_len[i] > 0xFFFFF000u) { delete p; return MSCOMP_ARG_ERROR; }   // offsets inside a unit are 32-bit (4 GiB - 4096 at most)
 		chunks += chunks_of(format, decompress, in_len[i]);
 		total += in_len[i];
+		if (in_len[i] > p->max_unit) { p->max_unit = in_len[i]; }
 		if (chunks > 0x7FFFFFF0u) { delete p; return MSCOMP_ARG_ERROR; }
 	}
 	h_cp[n_units] = (uint32_t)chunks;
@@ -412,7 +414,9 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 		uint16_t* links = static_cast<uint16_t*>(c->links.p); uint16_t* lasthead = static_cast<uint16_t*>(c->lasthead.p);
 		uint16_t* mlen3 = static_cast<uint16_t*>(c->mlen3.p); uint16_t* moff = static_cast<uint16_t*>(c->moff.p);
 		{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
-		{ KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0x2000u, 0); }
+		// the lazy finder stages a whole unit in LDS: units of at most 64 KiB (one Xpress stream each); longer streams keep the tiled finder
+		if (g_finder_mode.load(std::memory_order_relaxed) != 1 && p->max_unit <= 65536u) { KernelTimer t(c, "xp_lazy_kernel"); launch_xp_lazy(st, d_in, p->bt, links, lasthead, mlen3, moff, 0, 0u, p->n_chunks); }
+		else { KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0x2000u, 0); }
 		{ KernelTimer t(c, "xpress_emit_kernel"); launch_xpress_emit(st, d_in, p->bt, mlen3, moff, xpress_win_bufs(c, p->n_chunks), d_out, d_out_len, d_status); }
 		break;
 	}
@@ -424,7 +428,8 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 		uint16_t* codes = static_cast<uint16_t*>(c->codes.p); uint32_t* fbflag = static_cast<uint32_t*>(c->fbflag.p);
 		uint32_t* fb_count = static_cast<uint32_t*>(c->fb_list.p); uint32_t* fb_list = fb_count + 16;
 		{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
-		{ KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0xFFFFu, 1); }
+		if (g_finder_mode.load(std::memory_order_relaxed) != 1) { KernelTimer t(c, "xp_lazy_kernel"); launch_xp_lazy(st, d_in, p->bt, links, lasthead, mlen3, moff, 1, 0u, p->n_chunks); }
+		else { KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0xFFFFu, 1); }
 		{ KernelTimer t(c, "xh_parse_kernel"); launch_xh_parse(st, d_in, p->bt, mlen3, moff, tokbits, counts, extra); }
 		{ KernelTimer t(c, "xh_huff_kernel"); launch_xh_huff(st, p->bt, counts, extra, lens, codes, slot_size, fb_list, fb_count, fbflag); }
 		{ KernelTimer t(c, "xh_fallback_kernel"); launch_xh_fallback(st, d_in, p->bt, fb_list, fb_count, XH_FB_BLOCKS, tokbits, lens, codes, slot_size); }
@@ -595,6 +600,7 @@ uint32_t mscomp_amd_debug_lzd_walked(mscomp_amd_ctx* c)
 	return lzd_read_walked();
 }
 
+void mscomp_amd_debug_set_finder(int mode) { g_finder_mode.store(mode, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 void mscomp_amd_debug_set_lznt1(int mode) { set_lznt1_mode(mode); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 
 // Hardware self-check (see util.hip): lanes whose returning LDS atomic was NOT served in lane order, summed over

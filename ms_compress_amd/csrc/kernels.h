@@ -25,6 +25,13 @@ struct XpressWinBufs { u64* wtok; u64* wmat; uint32_t* wfar; uint32_t* wecur; ui
 void launch_xpress_emit(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* mlen3, const uint16_t* moff,
                         const XpressWinBufs& wb, uint8_t* d_out, u64* d_out_len, int32_t* d_status);
 
+// ---- the lazy finder (xlazy.hip): Find only where a greedy parse can start a token; fills the same arrays as launch_xp_find for a
+// superset of the true token starts and clears the offsets of all other positions. xh != 0: 0xFFFF window + chunk clipping
+// (any unit); xh == 0: 0x2000 window, every unit at most 64 KiB ----
+void launch_xp_lazy(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead,
+                    uint16_t* mlen3, uint16_t* moff, int xh, uint32_t chunk_base, uint32_t chunk_count);
+void launch_xp_links_range(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead, uint32_t chunk_base, uint32_t chunk_count);
+
 // ---- Xpress+Huffman chunk pipeline (xhuff.hip) ----
 void launch_xh_parse(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* mlen3, const uint16_t* moff,
                      u64* tokbits, uint32_t* counts, uint32_t* extra);

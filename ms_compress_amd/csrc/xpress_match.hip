@@ -73,14 +73,14 @@ __device__ __forceinline__ uint32_t first_diff16(const uint4 x) { return first_n
 // receives exactly the most recent earlier position with its hash: the chain link of XpressDictionary.h:120-135.
 // No conflict detection, no head gather/scatter pairs: 8 exchanges in flight, links leave as coalesced u16 stores.
 __global__ __launch_bounds__(1024) void xp_links_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
-                                                      uint16_t* __restrict__ links, uint16_t* __restrict__ lasthead)
+                                                      uint16_t* __restrict__ links, uint16_t* __restrict__ lasthead, uint32_t chunk_base)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	uint32_t* const s_head = reinterpret_cast<uint32_t*>(smem);
 	uint16_t* const s_hash = reinterpret_cast<uint16_t*>(smem + XL_HASH_OFF);
 
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-	const uint32_t lc = blockIdx.x;
+	const uint32_t lc = chunk_base + blockIdx.x;
 	const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, lc);
 	const uint32_t k = lc - bt.chunk_prefix[u];
 	const u64 n = bt.in_len[u];
@@ -327,13 +327,17 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 #endif
 }
 
-void launch_xp_links(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead)
+void launch_xp_links_range(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead, uint32_t chunk_base, uint32_t chunk_count)
 {
-	if (bt.n_chunks == 0) { return; }
+	if (chunk_count == 0) { return; }
 	const uint32_t lds = XL_LDS_BYTES;
 	static bool attr_set = false;
 	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_links_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-	hipLaunchKernelGGL(xp_links_kernel, dim3(bt.n_chunks), dim3(1024), lds, st, d_in, bt, links, lasthead);
+	hipLaunchKernelGGL(xp_links_kernel, dim3(chunk_count), dim3(1024), lds, st, d_in, bt, links, lasthead, chunk_base);
+}
+void launch_xp_links(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead)
+{
+	launch_xp_links_range(st, d_in, bt, links, lasthead, 0u, bt.n_chunks);
 }
 // tile = positions per block: 4096 for Xpress (4 blocks/CU), 8192 for Xpress+Huffman (the 64 KiB window is re-staged
 // half as often; 72 KiB of LDS, still 2 blocks/CU)

@@ -343,3 +343,25 @@ def test_huffman_builder_stage(oracle, gpu_ctx):
     assert deep > 20                                                  # the > 15-bit rescale loop was exercised
     for i in range(len(hs)):
         assert hashlib.sha256(lens[i].tobytes()).hexdigest()[:16] == gold["sha256_16_per_case"][i], i
+
+
+@pytest.mark.parametrize("fmt", [3, 4])
+def test_lazy_finder_gives_the_same_bytes(oracle, gpu_ctx, fmt):
+    """csrc/xlazy.hip (Find only where a greedy parse can start a token: speculative 64-byte segments + continuation walks) against the
+    oracle on the edge families, the mixed buffer (100 000 zeros: matches longer than 8 KiB and the lagging-Fill resume points of Xpress)
+    and corpus slices. The all-positions finder is the default; this keeps the experimental one exact."""
+    import ms_compress_amd as m
+    from ms_compress_amd import corpus
+    lib = gpu_ctx.lib
+    units = cases.edge_cases()[::3] + [cases.mixed_buffer()[i:i + 65536] for i in range(0, 300000, 65536)]
+    units += [corpus.file_bytes(i, 300_000).tobytes()[o:o + 65536] for i in (1, 3, 9) for o in (0, 65536, 200000)]
+    if fmt == 4:
+        units += [cases.mixed_buffer(), corpus.file_bytes(1, 400_000).tobytes()]          # multi-chunk units: windows reach into the previous chunk
+    lib.mscomp_amd_debug_set_finder(0)
+    try:
+        got, st = m.compress_units(fmt, units, ctx=gpu_ctx)
+    finally:
+        lib.mscomp_amd_debug_set_finder(1)
+    for i, (u, g, s) in enumerate(zip(units, got, st)):
+        es, exp = oracle.oracle_compress(fmt, u)
+        assert s == 0 and g == exp, "unit %d (%d bytes)" % (i, len(u))
