@@ -365,3 +365,79 @@ def test_lazy_finder_gives_the_same_bytes(oracle, gpu_ctx, fmt):
     for i, (u, g, s) in enumerate(zip(units, got, st)):
         es, exp = oracle.oracle_compress(fmt, u)
         assert s == 0 and g == exp, "unit %d (%d bytes)" % (i, len(u))
+
+
+def _lznt1_tokens(chunk_image):
+    """(position, length, offset) of every token of ONE compressed LZNT1 chunk image (lznt1_decompress.cpp:37-121); offset 0 = literal"""
+    hdr = chunk_image[0] | (chunk_image[1] << 8)
+    body = chunk_image[2:2 + (hdr & 0xFFF) + 1]
+    if not hdr & 0x8000:
+        return None                                          # stored raw
+    toks, ip, op = [], 0, 0
+    while ip < len(body):
+        flags = body[ip]; ip += 1
+        for i in range(8):
+            if ip >= len(body):
+                break
+            if not (flags >> i) & 1:
+                toks.append((op, 1, 0)); ip += 1; op += 1
+                continue
+            shift = 12 if op <= 16 else 12 - ((op - 1).bit_length() - 4)
+            t = body[ip] | (body[ip + 1] << 8); ip += 2
+            toks.append((op, (t & ((1 << shift) - 1)) + 3, (t >> shift) + 1))
+            op += toks[-1][1]
+    return toks
+
+
+def test_lznt1_find_stage(oracle, gpu_ctx):
+    """Stage-level parity of LZNT1Dictionary::Find (LZNT1Dictionary.h:114-143: longest match, OLDEST candidate on ties) as the HIP chunk
+    kernel evaluates it -- lazily, at token starts: every token the GPU emitted for a 4 KiB chunk against the oracle's per-position
+    match table (orc_lznt1_match_table). A tie-break regression is reported as chunk / position / (length, offset), not as a digest."""
+    import ctypes as C
+    import ms_compress_amd as m
+    from ms_compress_amd import corpus
+    rnd = __import__("random").Random(41)
+    chunks = []
+    for i in range(12):
+        data = corpus.file_bytes(i, 600_000).tobytes()
+        chunks += [data[o:o + 4096] for o in (0, 4096 * 37, 4096 * 101)]
+    chunks += [cases.family(k, n, rnd) for k in ("two", "words", "lz", "run") for n in (4096, 3000, 517)]
+    chunks += [bytes((j * 7 + (j // 5)) & 0x3 for j in range(4096)), (b"abcde" * 1000)[:4096], (b"abc" * 2000)[:4096]]   # many equal-length candidates
+    got, st = m.compress_units(2, chunks, ctx=gpu_ctx)
+    lib = oracle.load_oracle()
+    checked = matches = 0
+    for ci, (data, comp) in enumerate(zip(chunks, got)):
+        toks = _lznt1_tokens(comp)
+        if toks is None:
+            continue
+        n = len(data)
+        ln = np.zeros(n, dtype=np.uint16); off = np.zeros(n, dtype=np.uint16)
+        lib.orc_lznt1_match_table(data, n, ln.ctypes.data, off.ctypes.data)
+        for pos, l, o in toks:
+            want = (int(ln[pos]), int(off[pos])) if ln[pos] >= 3 else (1, 0)
+            assert (l, o) == want, "chunk %d position %d: GPU token (len %d, off %d), Find gives (len %d, off %d)" % (ci, pos, l, o, want[0], want[1])
+            checked += 1; matches += o != 0
+        assert sum(t[1] for t in toks) == n
+    assert checked > 20000 and matches > 5000
+
+
+@pytest.mark.parametrize("fmt", [2, 3, 4])
+def test_one_shot_with_a_terabyte_of_capacity(oracle, gpu_ctx, fmt):
+    """*out_len = 1 << 40 is legal in the reference (the capacity of a buffer the caller says it has): ms_compress / ms_decompress must
+    answer what they answer with an exact capacity, not MSCOMP_MEM_ERROR from an attempt to mirror the capacity in HBM."""
+    import ctypes as C
+    import ms_compress_amd as m
+    lib = m.load_library()
+    for data in (cases.mixed_buffer()[:150000], b"", b"a", bytes(300000), cases.family("lz", 70000, __import__("random").Random(3))):
+        want = oracle.oracle_compress(fmt, data)[1]
+        out = C.create_string_buffer(len(want) + 64)
+        n = C.c_size_t(1 << 40)
+        assert lib.ms_compress(fmt, data, len(data), out, C.byref(n)) == 0
+        assert n.value == len(want) and out.raw[: n.value] == want
+        back = C.create_string_buffer(len(data) + 64)
+        n = C.c_size_t(1 << 40)
+        est, exp = oracle.oracle_decompress(fmt, want, len(data) + 64)
+        st = lib.ms_decompress(fmt, want, len(want), back, C.byref(n))
+        # (the reference refuses its own compression of the empty buffer, FF FF FF FF, as Xpress input: xpress_decompress.cpp:414-417)
+        assert st == est and (st != 0 or (n.value == len(data) and back.raw[: n.value] == data)), (fmt, len(data), st, est)
+        assert st == 0 or (fmt == 3 and len(data) == 0)
