@@ -51,6 +51,9 @@ SYMBOLS = {
 }
 
 
+CODEC_OF = {2: "lznt1", 3: "xpress", 4: "xpress_huff"}
+
+
 # ---------------------------------------------------------------- launch ----------------------------------------------------------------
 def spawn_ranks(n):
     """python bench.py --gpus N without torch.distributed.run around it: become the launcher."""
@@ -195,7 +198,7 @@ def pmc_traffic(fmt, timer_name, workload_key):
     sym = SYMBOLS.get((fmt, timer_name))
     if not doc or not sym:
         return None
-    rec = doc.get("workloads", {}).get(workload_key, {}).get(sym)
+    rec = doc.get("by_codec", {}).get(workload_key, {}).get(CODEC_OF[fmt], {}).get(sym)
     return rec["hbm_bytes_per_launch_corrected"] if rec else None
 
 
@@ -206,7 +209,8 @@ def secondary_bound(fmt, timer_name, workload_key):
     sym = SYMBOLS.get((fmt, timer_name))
     if not doc or not sym:
         return None
-    return doc.get("workloads", {}).get(workload_key, {}).get(sym)
+    rec = doc.get("workloads", {}).get("single_gpu", {}).get(sym)       # (SQ counters are collected on the single-GPU legs: shares, not totals)
+    return rec["derived"] if rec and rec.get("codec") == CODEC_OF[fmt] else None
 
 
 def roofline(fmt, prof, in_bytes, out_bytes, steps, workload_key):

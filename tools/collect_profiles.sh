@@ -1,17 +1,38 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): the default bench line, the same command under rocprofv3 --kernel-trace --stats,
-# and two separate PMC passes (FETCH_SIZE / WRITE_SIZE) for the HBM traffic. Output: gpurun_out/prof_<tag>/, which
-# tools/update_profiles.py condenses into profiles/.
-#   usage: bash tools/collect_profiles.sh r01e
+# Run on the GPU box (through gpurun): everything profiles/<tag>_* is made of. Output: gpurun_out/prof_<tag>/, condensed by
+# tools/update_profiles.py into profiles/.
+#   usage: bash tools/collect_profiles.sh r02 [quick]
+#  1. the default bench line;
+#  2. rocprofv3 --kernel-trace --stats of the HEADLINE command (bench.py --no-extra: every launch of the dominant kernel is the
+#     headline workload, so its average duration is comparable with the HIP-event figure of the line) and of the full default command;
+#  3. HBM traffic: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (TCC counters do not fit one pass), per leg (tools/gpu_leg.py);
+#  4. SQ counters of the single-GPU legs in two passes of 8 (issue / wait shares, instruction mix, LDS pipe, conflicts).
 set -u
 TAG=${1:-run}
+QUICK=${2:-}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 D=$R/gpurun_out/prof_$TAG
 mkdir -p $D
 cd /tmp && export TMPDIR=/tmp
 cd $R
 python bench.py 2> $D/bench.err | tail -1 > $D/bench.json
-rocprofv3 --kernel-trace --stats -d $D -o kt -- python bench.py --steps 3 --warmup 1 --no-cpu 2> $D/kt.err | tail -1 > $D/bench_under_rocprof.json
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $D -o fetch -- python bench.py --steps 3 --warmup 1 --no-cpu > $D/fetch.out 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $D -o write -- python bench.py --steps 3 --warmup 1 --no-cpu > $D/write.out 2>&1
-ls -la $D | head -30
+rocprofv3 --kernel-trace --stats --output-format csv -d $D -o kt_head -- python bench.py --no-extra --no-cpu --steps 5 --warmup 1 2> $D/kt_head.err | tail -1 > $D/bench_headline_under_rocprof.json
+[ -n "$QUICK" ] || rocprofv3 --kernel-trace --stats --output-format csv -d $D -o kt_full -- python bench.py --no-cpu --steps 4 --warmup 1 2> $D/kt_full.err | tail -1 > $D/bench_full_under_rocprof.json
+LEGS="config5:lznt1 config5:xpress config5:xpress_huff single:lznt1 single:xpress single:xpress_huff"
+[ -n "$QUICK" ] && LEGS="config5:lznt1"
+for leg in $LEGS; do
+  t=${leg/:/_}
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $D -o fetch_$t -- python tools/gpu_leg.py $leg 3 > $D/fetch_$t.out 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $D -o write_$t -- python tools/gpu_leg.py $leg 3 > $D/write_$t.out 2>&1
+done
+SQA="SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS"
+SQB="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS"
+SLEGS="single:lznt1 single:xpress single:xpress_huff"
+[ -n "$QUICK" ] && SLEGS="single:lznt1"
+for leg in $SLEGS; do
+  t=${leg/:/_}
+  rocprofv3 --kernel-trace --pmc $SQA --output-format csv -d $D -o sqa_$t -- python tools/gpu_leg.py $leg 3 > $D/sqa_$t.out 2>&1
+  rocprofv3 --kernel-trace --pmc $SQB --output-format csv -d $D -o sqb_$t -- python tools/gpu_leg.py $leg 3 > $D/sqb_$t.out 2>&1
+done
+find $D -name "*.csv" | head -60
+du -sh $D

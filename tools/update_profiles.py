@@ -1,33 +1,80 @@
-"""Copy the summaries of a gpurun_out/prof_* directory (rocprofv3 kernel trace db, FETCH/WRITE PMC csv, bench JSON) into profiles/.
-usage: python tools/update_profiles.py gpurun_out/prof_r01d r01"""
-import csv, collections, json, os, shutil, subprocess, sys
+"""Condense a gpurun_out/prof_<tag> directory (tools/collect_profiles.sh) into the tracked profiles/<tag>_* files.
+usage: python tools/update_profiles.py gpurun_out/prof_r02 r02"""
+import collections, csv, glob, json, os, shutil, sys
 src, tag = sys.argv[1], sys.argv[2]
-open("profiles/%s_kernel_stats.txt" % tag, "w").write(subprocess.run([sys.executable, "tools/rocpd_summary.py", os.path.join(src, "kt_results.db")], capture_output=True, text=True, check=True).stdout)
-shutil.copy(os.path.join(src, "bench.json"), "profiles/%s_bench.json" % tag)
-shutil.copy(os.path.join(src, "bench_under_rocprof.json"), "profiles/%s_bench_under_rocprof.json" % tag)
-out = {}
-for f, c in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(os.path.join(src, "%s_counter_collection.csv" % f))):
-        if r["Counter_Name"] == c:
-            k = r["Kernel_Name"].replace("void ", "").split("(")[0]
-            if "msc::" in k:
-                agg[k].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        out.setdefault(k, {})[c + "_KB_per_launch"] = round(sum(v) / len(v), 2)
-        out[k]["launches_" + c] = len(v)
-for k, v in out.items():
-    # gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section)
-    v["hbm_bytes_per_launch_corrected"] = int(v.get("FETCH_SIZE_KB_per_launch", 0) * 1024 * 2 + v.get("WRITE_SIZE_KB_per_launch", 0) * 1024)
-doc = {"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --steps 3 --warmup 1 --no-cpu ; "
-              "counters are KB; FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE uncalibrated",
-       "workloads": "lznt1: mozilla 51220480 B; xpress: 3239 x 64 KiB units (211938580 B); xpress_huff: 12 files (211938580 B); decompression (lzd_* / xpd / xhd kernels): what the compressor wrote for mozilla (lznt1) and for the 3239 units (xpress, xpress_huff)", "kernels": out}
-json.dump(doc, open("profiles/%s_pmc_traffic.json" % tag, "w"), indent=1)
-r = json.load(open("profiles/%s_bench.json" % tag))
-print(r["value"], r["roofline"]["frac"], r["roofline"]["traffic"], r["cpu_baseline"]["value"])
-for k, v in r["extra"].items():
-    if k == "decompress":
-        for c, d in v.items():
-            print("decompress", c, d["MB_per_s"], d["round_trip_ok"], d["kernels_ms_per_step"])
-    else:
-        print(k, v["MB_per_s"], v["roofline"]["frac"], v["roofline"]["kernels_ms_per_step"])
+P = lambda name: os.path.join("profiles", "%s_%s" % (tag, name))
+short = lambda k: k.replace("void ", "").split("(")[0]
+
+
+def stats_table(path, title):
+    rows = list(csv.DictReader(open(path)))
+    out = ["# %s" % title, "# %-70s %8s %14s %12s %7s" % ("kernel", "calls", "avg_us", "total_ms", "share")]
+    for r in rows:
+        if "msc::" in r["Name"]:
+            out.append("%-72s %8s %14.2f %12.3f %6.2f%%" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, float(r["Percentage"])))
+    return "\n".join(out) + "\n"
+
+
+def per_kernel(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        if "msc::" in k:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: (sum(x) / len(x), len(x)) for c, x in v.items()} for k, v in agg.items()}
+
+
+shutil.copy(os.path.join(src, "bench.json"), P("bench.json"))
+for f in ("bench_headline_under_rocprof.json", "bench_full_under_rocprof.json"):
+    if os.path.exists(os.path.join(src, f)) and os.path.getsize(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), P(f))
+txt = stats_table(os.path.join(src, "kt_head_kernel_stats.csv"),
+                  "rocprofv3 --kernel-trace --stats -- python bench.py --no-extra --no-cpu --steps 5 --warmup 1   (the headline leg alone: LZNT1 over BASELINE configs[4])")
+if os.path.exists(os.path.join(src, "kt_full_kernel_stats.csv")):
+    txt += "\n" + stats_table(os.path.join(src, "kt_full_kernel_stats.csv"),
+                              "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --steps 4 --warmup 1   (all legs: a kernel's launches mix workloads)")
+open(P("kernel_stats.txt"), "w").write(txt)
+
+WL = {"config5": "config5_n1", "single": "single_gpu"}
+traffic = {}
+for f in sorted(glob.glob(os.path.join(src, "fetch_*_counter_collection.csv"))):
+    leg = os.path.basename(f)[len("fetch_"):-len("_counter_collection.csv")]
+    kind, codec = leg.split("_", 1)
+    fe, wr = per_kernel(f), per_kernel(f.replace("fetch_", "write_"))
+    for k in fe:
+        rec = {"codec": codec, "FETCH_SIZE_KB_per_launch": round(fe[k]["FETCH_SIZE"][0], 2), "launches_FETCH_SIZE": fe[k]["FETCH_SIZE"][1],
+               "WRITE_SIZE_KB_per_launch": round(wr.get(k, {}).get("WRITE_SIZE", (0, 0))[0], 2), "launches_WRITE_SIZE": wr.get(k, {}).get("WRITE_SIZE", (0, 0))[1]}
+        # gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section)
+        rec["hbm_bytes_per_launch_corrected"] = int(rec["FETCH_SIZE_KB_per_launch"] * 1024 * 2 + rec["WRITE_SIZE_KB_per_launch"] * 1024)
+        traffic.setdefault(WL[kind], {}).setdefault(codec, {})[k] = rec
+flat = {w: {k: r for c in v.values() for k, r in c.items() if k not in ("msc::scan_tiles_kernel", "msc::scan_add_kernel", "msc::scan_tile_sums_kernel", "msc::finalize_units_kernel")
+            or True} for w, v in traffic.items()}
+json.dump({"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python tools/gpu_leg.py <leg> 3 (one bench.py leg per run, so every launch of a kernel "
+                  "belongs to one workload); counters are KB; FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); WRITE_SIZE uncalibrated. "
+                  "Kernels that several codecs share (xp_links_kernel, scan / finalize) appear under the codec that ran them; bench.py looks a kernel up by workload + codec.",
+           "workload_keys": {"config5_n1": "BASELINE configs[4] on one GPU: 16x replicated corpus, 3391017280 B", "single_gpu": "BASELINE configs[1..3]: mozilla 51220480 B (lznt1), 3239 x 64 KiB units (xpress), 12 files (xpress_huff), 211938580 B"},
+           "by_codec": traffic, "workloads": {w: {k: r for c in v.values() for k, r in c.items()} for w, v in traffic.items()}}, open(P("pmc_traffic.json"), "w"), indent=1)
+
+sq = {}
+for f in sorted(glob.glob(os.path.join(src, "sqa_*_counter_collection.csv"))):
+    leg = os.path.basename(f)[len("sqa_"):-len("_counter_collection.csv")]
+    kind, codec = leg.split("_", 1)
+    a, b = per_kernel(f), per_kernel(f.replace("sqa_", "sqb_"))
+    for k in a:
+        raw = {c: round(v[0]) for c, v in a[k].items()}
+        raw.update({c: round(v[0]) for c, v in b.get(k, {}).items()})
+        wc = max(1, raw.get("SQ_WAVE_CYCLES", 1)); act = max(1, raw.get("SQ_ACTIVE_INST_ANY", 1)); idx = max(1, raw.get("SQ_LDS_IDX_ACTIVE", 1))
+        d = {"wave_time_waiting_frac": round(raw.get("SQ_WAIT_ANY", 0) / wc, 3), "wave_time_issue_stalled_frac": round(raw.get("SQ_WAIT_INST_ANY", 0) / wc, 3),
+             "wave_time_issuing_frac": round(act / wc, 3),
+             "issue_mix": {"valu": round(raw.get("SQ_ACTIVE_INST_VALU", 0) / act, 3), "salu": round(raw.get("SQ_ACTIVE_INST_SCA", 0) / act, 3), "lds": round(raw.get("SQ_ACTIVE_INST_LDS", 0) / act, 3)},
+             "lds_pipe_busy_frac": round(raw.get("SQ_LDS_IDX_ACTIVE", 0) / max(1, raw.get("SQ_BUSY_CU_CYCLES", 1)), 3),
+             "lds_bank_conflict_share": round(raw.get("SQ_LDS_BANK_CONFLICT", 0) / idx, 3), "lds_unaligned_stall_share": round(raw.get("SQ_LDS_UNALIGNED_STALL", 0) / idx, 4),
+             "lds_cycles_per_lds_instruction": round(idx / max(1, raw.get("SQ_INSTS_LDS", 1)), 2)}
+        d["bound"] = "lds-pipe" if d["lds_pipe_busy_frac"] >= 0.4 else ("issue" if d["wave_time_issue_stalled_frac"] + d["wave_time_issuing_frac"] >= 0.6 else "latency (waves parked in s_waitcnt / barriers)")
+        sq.setdefault(WL[kind], {})[k] = {"codec": codec, "derived": d, "per_launch": raw}
+json.dump({"how": "rocprofv3 --kernel-trace --pmc <8 SQ counters> -- python tools/gpu_leg.py single:<codec> 3, two passes (A: SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY "
+                  "SQ_ACTIVE_INST_ANY/_VALU/_SCA/_LDS; B: SQ_INSTS_VALU/_SALU/_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS). "
+                  "Averages per launch. wave-time fractions are shares of SQ_WAVE_CYCLES (WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES); lds_pipe_busy = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES.",
+           "workloads": sq}, open(P("sq_counters.json"), "w"), indent=1)
+r = json.load(open(P("bench.json")))
+print(r["value"], r["roofline"]["frac"], r["roofline"]["traffic"], r["roofline"].get("secondary", {}) and r["roofline"]["secondary"].get("derived", {}).get("bound"))
