@@ -76,6 +76,7 @@ struct mscomp_amd_plan {
 	bool decompress = false;
 	uint32_t n_units = 0, n_chunks = 0;
 	uint64_t total_in = 0, max_unit = 0;
+	bool no_graph = false;                             // one-shot plans run with changing buffer addresses: a captured graph would be re-captured every time
 	DevBuf tables;                                     // in_off | out_off | chunk_prefix
 	DevBuf tokpre;                                     // decompression by tokens: first token slot | first candidate slot of every unit (2 x (n_units + 1) u64)
 	uint32_t xhc_slots = 0;                            // candidate chunk slots of the batch
@@ -455,7 +456,7 @@ MSCompStatus mscomp_amd_plan_execute(mscomp_amd_plan* p, const uint8_t* d_in, ui
 	// A plan that is executed repeatedly replays its 4-9 launches as one hipGraph (the gaps between the launches are
 	// ~3 % of an LZNT1 pass). Not while profiling (the per-kernel events are not part of the graph), not on the first
 	// execution (one-time function attributes are set there).
-	if (!no_graph && !c->profiling && p->executions >= 2 && p->n_units) {
+	if (!no_graph && !p->no_graph && !c->profiling && p->executions >= 2 && p->n_units) {
 		const uint64_t mode_now = g_mode_epoch.load(std::memory_order_acquire);
 		const bool same = p->gexec && p->g_epoch == c->epoch && p->g_mode == mode_now && p->g_args[0] == d_in && p->g_args[1] == d_out &&
 		                  p->g_args[2] == d_out_len && p->g_args[3] == d_status;
@@ -621,6 +622,10 @@ namespace {
 // upload once and gets the captured hipGraph from its second call on.
 struct OneShotTls {
 	mscomp_amd_ctx* ctx = nullptr;
+	hipStream_t exec = nullptr, h2d = nullptr, d2h = nullptr;   // non-blocking streams: kernels, uploads, downloads
+	std::vector<hipEvent_t> ev;                         // two per slice of a pipelined call
+	uint64_t* h_len = nullptr; int32_t* h_st = nullptr; size_t h_cap = 0;   // pinned: per-slice results
+	DevBuf d_meta;
 	struct Entry { MSCompFormat format; bool decompress; uint64_t in_len, out_cap; mscomp_amd_plan* plan; uint64_t used; };
 	std::vector<Entry> plans;
 	uint64_t tick = 0;
@@ -629,6 +634,24 @@ struct OneShotTls {
 		for (auto& e : plans) { mscomp_amd_plan_destroy(e.plan); }
 		plans.clear();
 		if (ctx) { mscomp_amd_ctx_destroy(ctx); ctx = nullptr; }
+		for (auto e : ev) { (void)hipEventDestroy(e); }
+		ev.clear();
+		if (h_len) { (void)hipHostFree(h_len); h_len = nullptr; h_st = nullptr; h_cap = 0; }
+		d_meta.release();
+		if (exec) { (void)hipStreamDestroy(exec); exec = nullptr; }
+		if (h2d) { (void)hipStreamDestroy(h2d); h2d = nullptr; }
+		if (d2h) { (void)hipStreamDestroy(d2h); d2h = nullptr; }
+	}
+	bool slices(size_t n)                               // events, pinned result slots and device result slots for n slices
+	{
+		while (ev.size() < 2 * n) { hipEvent_t e = nullptr; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { return false; } ev.push_back(e); }
+		if (h_cap < n) {
+			if (h_len) { (void)hipHostFree(h_len); h_len = nullptr; h_cap = 0; }
+			void* q = nullptr;
+			if (hipHostMalloc(&q, n * 16, hipHostMallocDefault) != hipSuccess) { return false; }
+			h_len = static_cast<uint64_t*>(q); h_st = reinterpret_cast<int32_t*>(h_len + n); h_cap = n;
+		}
+		return d_meta.reserve(n * 16);
 	}
 	~OneShotTls() { drop(); }
 	MSCompStatus plan_for(MSCompFormat f, bool dec, uint64_t in_len, uint64_t out_cap, mscomp_amd_plan** out)
@@ -640,6 +663,7 @@ struct OneShotTls {
 		mscomp_amd_plan* p = nullptr;
 		const MSCompStatus s = plan_create_impl(ctx, f, dec, 1, &z, &in_len, &z, &out_cap, &p);
 		if (s != MSCOMP_OK) { return s; }
+		p->no_graph = true;
 		if (plans.size() >= 8) {
 			size_t lru = 0;
 			for (size_t i = 1; i < plans.size(); ++i) { if (plans[i].used < plans[lru].used) { lru = i; } }
@@ -654,6 +678,69 @@ struct OneShotTls {
 
 } // namespace
 
+// one large host buffer through the GPU with the link busy in both directions while the kernels run. LZNT1 chunks
+// are independent and the output is their concatenation (lznt1_compress.cpp:262), so the buffer is cut into slices of 1024 chunks:
+// slice k + 1 is on its way up (stream h2d) and slice k - 1 on its way down (stream d2h) while slice k is compressed (the
+// context's stream); a slice's place in the caller's output is known once the sizes of the slices before it are back (16 bytes per
+// slice into pinned memory). The caller's buffers are page-locked for the duration of the call when the runtime allows it
+// (hipHostRegister: uploads and downloads then really overlap; measured on the MI355X box: 85 MB both ways at once 0.92 ms pinned,
+// 1.7 ms pageable); without it the copies still work.
+// Slices of about 24 MiB (6 144 chunks: three rounds of the chunk kernel's 2 048 resident blocks; with 4 MiB slices the kernels ran at a
+// third of their batch rate and the call took 4.9 instead of 2.7 ms), equal in size, at least two.
+static const size_t ONE_SLICE = (getenv("MSCOMP_AMD_ONE_SLICE_MB") ? (size_t)atoi(getenv("MSCOMP_AMD_ONE_SLICE_MB")) : 24u) << 20;
+static MSCompStatus lznt1_compress_pipelined(OneShotTls& tls, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len)
+{
+	mscomp_amd_ctx* c = tls.ctx;
+	const size_t cap = *out_len;
+	const size_t ns = (in_len + ONE_SLICE / 2) / ONE_SLICE < 2 ? 2 : (in_len + ONE_SLICE / 2) / ONE_SLICE;
+	const size_t SL = ((in_len + ns - 1) / ns + 4095) & ~(size_t)4095;          // bytes per slice: whole chunks
+	const size_t scap = (lznt1_max_compressed_size(SL) + 2 + 15) & ~(size_t)15;
+	if (!tls.slices(ns) || !c->one_in.reserve(in_len + 64) || !c->one_out.reserve(ns * scap + 64)) { return MSCOMP_MEM_ERROR; }
+	uint8_t* d_in = static_cast<uint8_t*>(c->one_in.p); uint8_t* d_out = static_cast<uint8_t*>(c->one_out.p);
+	uint64_t* d_len = static_cast<uint64_t*>(tls.d_meta.p); int32_t* d_st = reinterpret_cast<int32_t*>(d_len + ns);
+	const size_t most = lznt1_max_compressed_size(in_len) + 2, out_span = cap < most ? cap : most;
+	const bool reg_in = hipHostRegister(const_cast<uint8_t*>(in), in_len, hipHostRegisterDefault) == hipSuccess;
+	const bool reg_out = out_span && hipHostRegister(out, out_span, hipHostRegisterDefault) == hipSuccess;
+	(void)hipGetLastError();
+	MSCompStatus rs = MSCOMP_OK;
+	for (size_t k = 0; k < ns && rs == MSCOMP_OK; ++k) {
+		const size_t o = k * SL, len = in_len - o < SL ? in_len - o : SL;
+		if (hipMemcpyAsync(d_in + o, in + o, len, hipMemcpyHostToDevice, tls.h2d) != hipSuccess || hipEventRecord(tls.ev[2 * k], tls.h2d) != hipSuccess) { rs = MSCOMP_ERRNO; }
+	}
+	for (size_t k = 0; k < ns && rs == MSCOMP_OK; ++k) {
+		const size_t o = k * SL, len = in_len - o < SL ? in_len - o : SL;
+		mscomp_amd_plan* p = nullptr;
+		rs = tls.plan_for(MSCOMP_LZNT1, false, len, scap, &p);
+		if (rs != MSCOMP_OK) { break; }
+		if (hipStreamWaitEvent(tls.exec, tls.ev[2 * k], 0) != hipSuccess) { rs = MSCOMP_ERRNO; break; }
+		rs = mscomp_amd_plan_execute(p, d_in + o, d_out + k * scap, d_len + k, d_st + k);
+		if (rs != MSCOMP_OK) { break; }
+		if (hipMemcpyAsync(tls.h_len + k, d_len + k, 8, hipMemcpyDeviceToHost, tls.exec) != hipSuccess ||
+		    hipMemcpyAsync(tls.h_st + k, d_st + k, 4, hipMemcpyDeviceToHost, tls.exec) != hipSuccess ||
+		    hipEventRecord(tls.ev[2 * k + 1], tls.exec) != hipSuccess) { rs = MSCOMP_ERRNO; }
+	}
+	size_t total = 0;
+	bool fits = true;
+	for (size_t k = 0; k < ns && rs == MSCOMP_OK; ++k) {
+		if (hipEventSynchronize(tls.ev[2 * k + 1]) != hipSuccess) { rs = MSCOMP_ERRNO; break; }
+		if (tls.h_st[k] != MSCOMP_OK) { rs = (MSCompStatus)tls.h_st[k]; break; }
+		const size_t len = (size_t)tls.h_len[k];
+		if (fits && total + len <= cap) {
+			if (len && hipMemcpyAsync(out + total, d_out + k * scap, len, hipMemcpyDeviceToHost, tls.d2h) != hipSuccess) { rs = MSCOMP_ERRNO; }
+		} else { fits = false; }                                    // MSCOMP_BUF_ERROR (lznt1_compress.cpp:251,267): nothing behind the capacity is written
+		total += len;
+	}
+	(void)hipStreamSynchronize(tls.h2d); (void)hipStreamSynchronize(tls.exec);
+	if (hipStreamSynchronize(tls.d2h) != hipSuccess && rs == MSCOMP_OK) { rs = MSCOMP_ERRNO; }
+	if (reg_in) { (void)hipHostUnregister(const_cast<uint8_t*>(in)); }
+	if (reg_out) { (void)hipHostUnregister(out); }
+	if (rs != MSCOMP_OK) { return rs; }
+	if (!fits) { return MSCOMP_BUF_ERROR; }
+	if (cap - total >= 2) { out[total] = 0; out[total + 1] = 0; }   // the uncounted End_of_buffer bytes (lznt1_compress.cpp:270)
+	*out_len = total;
+	return MSCOMP_OK;
+}
+
 static MSCompStatus one_shot(MSCompFormat format, bool decompress, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len)
 {
 	if (!out_len || (in_len && !in) || (*out_len && !out)) { return MSCOMP_ARG_ERROR; }
@@ -661,10 +748,15 @@ static MSCompStatus one_shot(MSCompFormat format, bool decompress, const uint8_t
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess) { return MSCOMP_ERRNO; }   // no GPU / no HIP runtime: fail loudly, never fall back
 	if (tls.ctx && tls.ctx->device != dev) { tls.drop(); }
-	if (!tls.ctx) { MSCompStatus s = mscomp_amd_ctx_create(dev, nullptr, &tls.ctx); if (s != MSCOMP_OK) { return s; } }
+	if (!tls.ctx) {
+		if (hipStreamCreateWithFlags(&tls.exec, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&tls.h2d, hipStreamNonBlocking) != hipSuccess ||
+		    hipStreamCreateWithFlags(&tls.d2h, hipStreamNonBlocking) != hipSuccess) { tls.drop(); return MSCOMP_ERRNO; }
+		MSCompStatus s = mscomp_amd_ctx_create(dev, tls.exec, &tls.ctx); if (s != MSCOMP_OK) { tls.drop(); return s; }
+	}
 	mscomp_amd_ctx* c = tls.ctx;
 	DeviceGuard g(c->device);
 	const size_t cap = *out_len;
+	if (!decompress && format == MSCOMP_LZNT1 && in_len >= ONE_SLICE + ONE_SLICE / 2) { return lznt1_compress_pipelined(tls, in, in_len, out, out_len); }
 	// The device copy of the output is sized by what the format can PRODUCE, never by a generous caller capacity (legal in the
 	// reference: *out_len = 1 << 40 must not become a hipMalloc of a terabyte). Compression: at most ms_max_compressed_size (+ the
 	// two uncounted LZNT1 End_of_buffer bytes), and a unit that fits that bound gets the status and bytes it would get with any larger

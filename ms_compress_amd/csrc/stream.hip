@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 namespace {
 
@@ -25,7 +26,15 @@ struct DeflateState {                       // what lznt1_compress.cpp:32-40 kee
 	uint8_t out[CHUNK + 2];
 	size_t out_pos = 0, out_avail = 0;
 	uint8_t* scratch = nullptr; size_t scratch_cap = 0;      // host staging of a batch's output
+	// Look-ahead: when the caller's window forces chunk-by-chunk hand-over, the whole chunks that follow in the caller's input are
+	// compressed in the SAME GPU call (up to AHEAD of them) and kept with a copy of their input; a later chunk is served from here
+	// when its 4096 input bytes are still the ones that were compressed. Nothing the caller can observe changes: the stream's
+	// pointers and counters move exactly as if every chunk had been compressed when the reference compresses it.
+	std::vector<uint8_t> ah_in, ah_img;
+	std::vector<uint32_t> ah_off;                            // image k = ah_img[ah_off[k], ah_off[k + 1])
+	size_t ah_next = 0;
 };
+const size_t AHEAD = 256;
 
 bool stream_ok(const mscomp_stream* s, MSCompFormat f, bool compressing = true)     // CHECK_STREAM (internal.h:481)
 {
@@ -52,11 +61,28 @@ MSCompStatus gpu_images(DeflateState* st, const uint8_t* in, size_t n, uint8_t**
 
 // lznt1_compress_chunk_write (:95-131): one chunk of n <= 4096 bytes; goes to the caller's window when header + n bytes are sure to
 // fit, else through the state's buffer
-MSCompStatus write_chunk(mscomp_stream* s, DeflateState* st, const uint8_t* in, size_t n)
+// `following` = bytes of caller input that lie behind the chunk at `in` (0 when the chunk comes from the state's buffer)
+MSCompStatus write_chunk(mscomp_stream* s, DeflateState* st, const uint8_t* in, size_t n, size_t following = 0)
 {
 	uint8_t* img; size_t len;
-	const MSCompStatus r = gpu_images(st, in, n, &img, &len);
-	if (r != MSCOMP_OK) { return r; }
+	if (n == CHUNK && st->ah_next + 1 < st->ah_off.size() && memcmp(in, st->ah_in.data() + st->ah_next * CHUNK, CHUNK) == 0) {
+		img = st->ah_img.data() + st->ah_off[st->ah_next]; len = st->ah_off[st->ah_next + 1] - st->ah_off[st->ah_next];
+		++st->ah_next;
+	} else {
+		st->ah_off.clear(); st->ah_next = 0;
+		size_t k = n == CHUNK ? 1 + following / CHUNK : 1;
+		if (k > AHEAD) { k = AHEAD; }
+		const MSCompStatus r = gpu_images(st, in, k > 1 ? k * CHUNK : n, &img, &len);
+		if (r != MSCOMP_OK) { return r; }
+		if (k > 1) {                                         // keep all k images (an image says how long it is: header & 0xFFF + 3)
+			st->ah_in.assign(in, in + k * CHUNK);
+			st->ah_img.assign(img, img + len);
+			st->ah_off.assign(1, 0u);
+			size_t o = 0;
+			for (size_t i = 0; i < k; ++i) { o += (((size_t)st->ah_img[o] | ((size_t)st->ah_img[o + 1] << 8)) & 0x0FFFu) + 3; st->ah_off.push_back((uint32_t)o); }
+			img = st->ah_img.data(); len = st->ah_off[1]; st->ah_next = 1;
+		}
+	}
 	if (s->out_avail >= n + 2) { memcpy(s->out, img, len); give_out(s, len); return MSCOMP_OK; }
 	memcpy(st->out, img, len);
 	const size_t copy = len < s->out_avail ? len : s->out_avail;
@@ -73,12 +99,47 @@ struct InflateState {                       // lznt1_decompress.cpp:27-34: one p
 	size_t in_needed = 0, in_avail = 0;
 	uint8_t out[CHUNK];
 	size_t out_pos = 0, out_avail = 0;
+	// Look-ahead, as on the compressing side: the complete compressed chunks that follow in the caller's input are decoded in the same
+	// GPU call (when they all decode to 4096 bytes, i.e. their boundaries in the output are known) and served later if their bytes
+	// are still the same.
+	std::vector<uint8_t> ah_in, ah_out;
+	std::vector<uint32_t> ah_off;                            // compressed chunk k = ah_in[ah_off[k], ah_off[k + 1]), its bytes = ah_out[4096 k ...)
+	size_t ah_next = 0;
 };
 uint32_t rd16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 
 // one complete chunk (header included) -> its bytes, decoded on the GPU against the 4096-byte limit; any failure is DATA_ERROR (:160-166)
-MSCompStatus gpu_chunk(const uint8_t* chunk, size_t in_size, uint8_t* out, size_t* out_size)
+MSCompStatus gpu_chunk(InflateState* st, const uint8_t* chunk, size_t in_size, size_t following, uint8_t* out, size_t* out_size)
 {
+	if (st->ah_next + 1 < st->ah_off.size() && st->ah_off[st->ah_next + 1] - st->ah_off[st->ah_next] == in_size &&
+	    memcmp(chunk, st->ah_in.data() + st->ah_off[st->ah_next], in_size) == 0) {
+		memcpy(out, st->ah_out.data() + st->ah_next * CHUNK, CHUNK);
+		*out_size = CHUNK; ++st->ah_next;
+		return MSCOMP_OK;
+	}
+	st->ah_off.clear(); st->ah_next = 0;
+	{	// complete, well-formed compressed chunks behind this one
+		size_t k = 1, used = in_size;
+		while (k < AHEAD && following - (used - in_size) >= 2) {
+			const uint32_t h = rd16(chunk + used);
+			const size_t sz = (h & 0x0FFFu) + 3;
+			if (h == 0 || (h & 0xF000u) != 0xB000u || sz > following - (used - in_size)) { break; }
+			used += sz; ++k;
+		}
+		if (k >= 2) {
+			st->ah_out.resize(k * CHUNK);
+			size_t len = k * CHUNK;
+			if (lznt1_decompress(chunk, used, st->ah_out.data(), &len) == MSCOMP_OK && len == k * CHUNK) {   // every chunk gave 4096 bytes: boundaries known
+				st->ah_in.assign(chunk, chunk + used);
+				st->ah_off.assign(1, 0u);
+				size_t o = 0;
+				for (size_t i = 0; i < k; ++i) { o += (rd16(st->ah_in.data() + o) & 0x0FFFu) + 3; st->ah_off.push_back((uint32_t)o); }
+				memcpy(out, st->ah_out.data(), CHUNK);
+				*out_size = CHUNK; st->ah_next = 1;
+				return MSCOMP_OK;
+			}
+		}
+	}
 	size_t len = CHUNK;
 	const MSCompStatus r = lznt1_decompress(chunk, in_size, out, &len);
 	if (r == MSCOMP_ERRNO || r == MSCOMP_MEM_ERROR) { return r; }
@@ -90,6 +151,7 @@ MSCompStatus gpu_chunk(const uint8_t* chunk, size_t in_size, uint8_t* out, size_
 // lznt1_decompress_chunk_read (:122-209): the chunk at `in` (*in_len bytes are there); on return *in_len = bytes of it that were used
 MSCompStatus read_chunk(mscomp_stream* s, InflateState* st, const uint8_t* in, size_t* in_len)
 {
+	const size_t have = *in_len;                                     // (caller input: everything that is there; state buffer: the chunk only)
 	const uint32_t header = rd16(in);
 	if (header == 0) {                                               // :128-134
 		if (s->in_avail + st->in_avail != 2) { return MSCOMP_DATA_ERROR; }
@@ -107,14 +169,14 @@ MSCompStatus read_chunk(mscomp_stream* s, InflateState* st, const uint8_t* in, s
 	if (header & 0x8000u) {
 		size_t out_size = 0;
 		if (s->out_avail < CHUNK) {                                  // through the state's buffer (:155-172)
-			const MSCompStatus r = gpu_chunk(in, in_size, st->out, &out_size);
+			const MSCompStatus r = gpu_chunk(st, in, in_size, in != st->in ? have - in_size : 0, st->out, &out_size);
 			if (r != MSCOMP_OK) { return r; }
 			const size_t copy = out_size < s->out_avail ? out_size : s->out_avail;
 			memcpy(s->out, st->out, copy);
 			st->out_pos = copy; st->out_avail = out_size - copy;
 			give_out(s, copy);
 		} else {                                                     // straight into the caller's window (:175-188)
-			const MSCompStatus r = gpu_chunk(in, in_size, s->out, &out_size);
+			const MSCompStatus r = gpu_chunk(st, in, in_size, in != st->in ? have - in_size : 0, s->out, &out_size);
 			if (r != MSCOMP_OK) { return r; }
 			give_out(s, out_size);
 		}
@@ -266,7 +328,7 @@ MSCompStatus lznt1_deflate(mscomp_stream* s, MSCompFlush flush)
 		const size_t sure = s->out_avail / (CHUNK + 2);
 		if (sure < k) { k = sure; }
 		if (k == 0) {
-			if ((r = write_chunk(s, st, s->in, CHUNK)) != MSCOMP_OK) { return r; }
+			if ((r = write_chunk(s, st, s->in, CHUNK, s->in_avail - CHUNK)) != MSCOMP_OK) { return r; }
 			take_in(s, CHUNK);
 			continue;
 		}

@@ -174,3 +174,34 @@ def test_lznt1_inflate_matches_reference_call_by_call(oracle, gpu_ctx):
             assert got[0] == want[0] and got[2] == want[2]
             n_cmp += 1
     assert n_cmp >= 200
+
+
+def test_deflate_look_ahead_notices_changed_input(oracle, gpu_ctx):
+    """The streaming compressor compresses the chunks that FOLLOW the one it has to hand over piecewise in the same GPU call and keeps
+    them; the caller owns its buffer between calls and may put other bytes there. Same calls on the reference and on us, with the input
+    behind the consumed part rewritten between two calls: same trace, same output."""
+    import ms_compress_amd as m
+    ref = oracle.load_ref()
+    if ref is None:
+        pytest.skip("compiled reference not available")
+    rnd = random.Random(9)
+    a = cases.family("lz", 40000, rnd); b = cases.family("words", 40000, rnd)
+
+    def run(lib):
+        for f in (lib.ms_deflate_init, lib.ms_deflate, lib.ms_deflate_end):
+            f.restype = C.c_int
+        lib.ms_deflate_init.argtypes = [C.c_int, C.POINTER(Stream)]; lib.ms_deflate.argtypes = [C.POINTER(Stream), C.c_int]; lib.ms_deflate_end.argtypes = [C.POINTER(Stream)]
+        s = Stream(); assert lib.ms_deflate_init(2, C.byref(s)) == 0
+        inbuf = C.create_string_buffer(a, len(a)); outbuf = C.create_string_buffer(200000)
+        ipos = opos = 0; trace = []
+        for i in range(4000):
+            if i == 3:                                               # after three calls: everything not yet consumed becomes other data
+                C.memmove(C.addressof(inbuf) + ipos, b[ipos:], len(a) - ipos)
+            s.in_ = C.addressof(inbuf) + ipos; s.in_avail = len(a) - ipos; s.out = C.addressof(outbuf) + opos; s.out_avail = 300
+            st = lib.ms_deflate(C.byref(s), FINISH)
+            ipos += (len(a) - ipos) - s.in_avail; opos += 300 - s.out_avail
+            trace.append((st, ipos, opos))
+            if st != 0:
+                break
+        return outbuf.raw[:opos], trace, lib.ms_deflate_end(C.byref(s))
+    assert run(m.load_library()) == run(ref)
