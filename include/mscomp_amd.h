@@ -105,7 +105,14 @@ MSCompStatus xpress_deflate(mscomp_stream* stream, MSCompFlush flush);
 MSCompStatus xpress_deflate_end(mscomp_stream* stream);
 /* ... and its streaming decompressor: ms_inflate_init / ms_inflate / ms_inflate_end (include/mscomp.h:174,198,213, src/mscomp.cpp:167-196;
  * MSCOMP_NONE and MSCOMP_LZNT1) and lznt1_inflate_init / lznt1_inflate / lznt1_inflate_end (include/lznt1.h:59-61,
- * src/lznt1_decompress.cpp:210-290). Every chunk is decoded on the GPU; xpress_inflate is not offloaded. */
+ * src/lznt1_decompress.cpp:210-290). Every chunk is decoded on the GPU. */
+/* xpress_inflate_init / xpress_inflate / xpress_inflate_end (include/xpress.h:56-58, src/xpress_decompress.cpp:45-403) are NOT offloaded (one
+ * stream is a serial token chain, handed over piecewise): the symbols exist so that programs naming them link; xpress_inflate_init -- and
+ * ms_inflate_init(MSCOMP_XPRESS) -- returns MSCOMP_MEM_ERROR without touching the stream, the other two MSCOMP_ARG_ERROR. Build with
+ * -DMSCOMP_AMD_NO_XPRESS_INFLATE and keep the reference's xpress_decompress.cpp in the link where streaming Xpress decompression is needed. */
+MSCompStatus xpress_inflate_init(mscomp_stream* stream);
+MSCompStatus xpress_inflate(mscomp_stream* stream);
+MSCompStatus xpress_inflate_end(mscomp_stream* stream);
 MSCompStatus ms_inflate_init(MSCompFormat format, mscomp_stream* stream);
 MSCompStatus ms_inflate(mscomp_stream* stream);
 MSCompStatus ms_inflate_end(mscomp_stream* stream);

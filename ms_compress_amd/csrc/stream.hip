@@ -377,6 +377,18 @@ MSCompStatus xpress_deflate_end(mscomp_stream* s)
 	return (!stream_ok(s, MSCOMP_XPRESS, true) || s->state == nullptr) ? MSCOMP_ARG_ERROR : MSCOMP_OK;
 }
 
+// The Xpress streaming DECOMPRESSOR (include/xpress.h:56-58, xpress_decompress.cpp:45-403) is not offloaded: one Xpress stream is a
+// serial chain of tokens and the streaming calls hand it over a few bytes at a time -- nothing for a GPU. The three symbols exist so
+// that a program naming them links against the drop-in; the init call answers MSCOMP_MEM_ERROR (the status the reference's own
+// unfinished streaming entry point uses, xpress_compress.cpp:72) and leaves the stream untouched, so a caller falls into its error
+// path at once instead of decoding nothing. A caller that needs streaming Xpress decompression keeps the reference's
+// src/xpress_decompress.cpp in its link and builds this library with -DMSCOMP_AMD_NO_XPRESS_INFLATE.
+#ifndef MSCOMP_AMD_NO_XPRESS_INFLATE
+MSCompStatus xpress_inflate_init(mscomp_stream*) { return MSCOMP_MEM_ERROR; }
+MSCompStatus xpress_inflate(mscomp_stream*) { return MSCOMP_ARG_ERROR; }
+MSCompStatus xpress_inflate_end(mscomp_stream*) { return MSCOMP_ARG_ERROR; }
+#endif
+
 #ifndef MSCOMP_AMD_NO_FACADE
 // mscomp.cpp:136-165 with its "copy" codec (:33-47,:60) for MSCOMP_NONE
 MSCompStatus ms_deflate_init(MSCompFormat format, mscomp_stream* s)
@@ -419,7 +431,10 @@ MSCompStatus ms_inflate_init(MSCompFormat format, mscomp_stream* s)
 {
 	if (format == MSCOMP_LZNT1) { return lznt1_inflate_init(s); }
 	if (format == MSCOMP_NONE) { return ms_deflate_init(MSCOMP_NONE, s); }
-	return MSCOMP_ARG_ERROR;                                  // Xpress: not offloaded (keep the reference's xpress_inflate); Xpress+Huffman: none in the reference
+#ifndef MSCOMP_AMD_NO_XPRESS_INFLATE
+	if (format == MSCOMP_XPRESS) { return xpress_inflate_init(s); }   // not offloaded: MSCOMP_MEM_ERROR (see above)
+#endif
+	return MSCOMP_ARG_ERROR;                                  // Xpress+Huffman: none in the reference either (mscomp.cpp:172,178)
 }
 MSCompStatus ms_inflate(mscomp_stream* s)
 {

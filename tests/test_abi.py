@@ -160,3 +160,19 @@ def test_xpress_deflate_entry_points_answer_like_the_reference():
     ref = loader.load_ref()
     if ref is not None:
         assert ours == answers(ref)
+
+
+def test_every_c_symbol_of_the_reference_is_exported():
+    """A program linked against libMSCompression must link against the drop-in: every C-linkage function the compiled reference exports
+    (include/mscomp.h, lznt1.h, xpress.h, xpress_huff.h) is exported by libmscomp_amd.so as well (C++-mangled internals aside)."""
+    import subprocess
+    ref = os.path.join(ROOT, "oracle", "_ref", "libMSCompression.so")
+    if not os.path.exists(ref):
+        pytest.skip("compiled reference not available")
+
+    def syms(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T"}
+    want = {s for s in syms(ref) if not s.startswith("_Z") and not s.startswith("_")}
+    ours = syms(os.path.join(ROOT, "ms_compress_amd", "libmscomp_amd.so"))
+    assert len(want) >= 25 and not (want - ours), sorted(want - ours)
