@@ -1023,6 +1023,10 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 			else { n_ = 1; while (x_ >= S.lims[n_]) { ++n_; } \
 				if (n_ > r_) { sym = 0xFFFFu; } else { XHD_SKIP(n_) const uint32_t s_ = S.poss[n_] + ((x_ - S.lims[n_ - 1u]) >> (15u - n_)); sym = s_ >= 512u ? 0xFFFFu : S.syms[s_]; } } }
 		while (prod < 65536u || !XHD_MASK_ZERO()) {
+			// a chunk of an encoder ends with its 65536th byte and an empty bit buffer; what still has bits then runs on in the reference
+			// (:87) -- possibly to the end of the buffer. A candidate is not followed there: it counts as "not a chunk", and a buffer
+			// whose chain does not close without it goes to the serial walk, which follows the reference to the letter.
+			if (!writing && prod >= 65536u) { status = -3; break; }
 			uint32_t sym;
 			XHD_DECODE(sym)
 			if (sym < 0x100u) {
@@ -1055,7 +1059,8 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 				XHD_SKIP(ob)
 				if (off > op && off - op > reach) { reach = off - op; }   // :120 is judged when the chunk's place in the output is known
 				op += len; prod = prod + len < prod ? 0xFFFFFFFFu : prod + len;
-				while (len > LZT_MAXLEN) { XHD_EMIT(off | (LZT_MAXLEN << 16)) len -= LZT_MAXLEN; }
+				if (writing) { while (len > LZT_MAXLEN) { XHD_EMIT(off | (LZT_MAXLEN << 16)) len -= LZT_MAXLEN; } }
+				else if (len > LZT_MAXLEN) { nt += (len - 1u) / LZT_MAXLEN; len = LZT_MAXLEN; }   // only counted: a candidate that is no chunk may "hold" gigabyte matches
 				XHD_EMIT(off | (len << 16))
 			}
 		}
@@ -1138,6 +1143,7 @@ __global__ __launch_bounds__(64) void lz_copy_kernel(BatchTables bt, const u64* 
 	const uint32_t lane = threadIdx.x, u = blockIdx.x;
 	if (d_status[u] != 0) { return; }
 	const u64 total = d_out_len[u], nt = ntok[u];
+	if (total >= (256u << 10)) { return; }                               // large units: lz_copy_block_kernel
 	const uint32_t* __restrict__ mytok = tok + tok_prefix[u];
 	uint8_t* dst = d_out + bt.out_off[u];
 	u64 t = 0, tpos = 0;                                                 // next token to place, its output offset
@@ -1208,6 +1214,199 @@ __global__ __launch_bounds__(64) void lz_copy_kernel(BatchTables bt, const u64* 
 	}
 }
 
+
+// ---- the same for a LARGE unit: one block of 1024 threads, 8 KiB of output at a time -------------------------------------------------
+// lz_copy_kernel walks the output of a unit with one wave (0.4 GB/s: 539 of the 665 ms the 12 files of the bench corpus took as 12 buffers).
+// Here a tile of 8192 output bytes is resolved by the whole block: the tokens that start in the tile are placed 1024 at a time (block scan
+// of their lengths), every byte finds its token (start bits + a per-word "last start so far" from a block max-scan) and its source one
+// match offset back -- in the last 64 KiB of output, kept in an LDS ring (offsets reach at most 65535 back: resolved), or inside the tile
+// (a pointer); pointers are then jumped (ptr = ptr[ptr], at most 13 rounds, usually 2-4) until every byte has its value. One word per byte
+// holds "value" or "pointer", so a racing read sees one or the other, both of which are right.
+#define LZB_T    8192u
+#ifndef LZB_NT
+#define LZB_NT   1024u
+#endif
+#define LZB_RING 73728u                                            // 65536 + LZB_T, a multiple of LZB_T: a tile never wraps
+#define LZB_MIN  (256u << 10)                                      // units with at least this much output take the block kernel
+struct LzbLds {
+	__attribute__((aligned(16))) uint8_t ring[LZB_RING];
+	uint32_t info[LZB_T];                                          // token word at its start position; later: 0x80000000 | value, or the in-tile source
+	uint32_t bm[LZB_T / 32u];
+	uint32_t last[LZB_T / 32u];                                    // highest token start in the words before this one (LZB_T = none in this tile)
+	uint32_t wsum[16];
+	uint32_t carry[4];                                             // tpos (2 words), token running at the tile start: its position relative to the tile (biased), its word
+	uint32_t tokbuf[LZB_T];                                        // the next LZB_T tokens of the unit (a tile cannot start more): fetched while the tile before is resolved
+};
+
+#ifdef LZB_PROFILE
+__device__ unsigned long long g_lzb_prof[8];
+extern "C" void mscomp_amd_debug_lzb_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lzb_prof), 64); unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lzb_prof), z, 64); }
+#define LZB_TM(i) { const unsigned long long t_ = __builtin_readcyclecounter(); if (tid == 0) { atomicAdd(&g_lzb_prof[i], t_ - lzb_prev); } lzb_prev = t_; }
+#define LZB_CN(i, v) { if (tid == 0) { atomicAdd(&g_lzb_prof[i], (unsigned long long)(v)); } }
+#else
+#define LZB_TM(i)
+#define LZB_CN(i, v)
+#endif
+__global__ __launch_bounds__(LZB_NT) void lz_copy_block_kernel(BatchTables bt, const u64* __restrict__ tok_prefix, const uint32_t* __restrict__ tok,
+                                                              const u64* __restrict__ ntok, const u64* __restrict__ d_out_len, const int32_t* __restrict__ d_status,
+                                                              uint8_t* __restrict__ d_out)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lzb_smem[];
+	LzbLds& L = *reinterpret_cast<LzbLds*>(lzb_smem);
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, u = blockIdx.x;
+	if (d_status[u] != 0) { return; }
+	const u64 total = d_out_len[u], nt = ntok[u];
+	if (total < LZB_MIN) { return; }
+	const uint32_t* __restrict__ mytok = tok + tok_prefix[u];
+	uint8_t* __restrict__ dst = d_out + bt.out_off[u];
+	u64 t = 0, tpos = 0;                                             // next token to place, its output offset (uniform)
+	uint32_t run_w = 0x80000000u;                                    // the token running at the tile start
+	uint32_t rbase = 0;                                              // the tile's place in the ring (w0 mod LZB_RING)
+	uint32_t pre[LZB_T / LZB_NT];                                    // tokens t + r * 1024 + tid, on their way from HBM
+	#pragma unroll
+	for (uint32_t r = 0; r < LZB_T / LZB_NT; ++r) { const u64 ti = (u64)r * LZB_NT + tid; pre[r] = ti < nt ? mytok[ti] : 0x80000000u; }
+#ifdef LZB_PROFILE
+	unsigned long long lzb_prev = __builtin_readcyclecounter();
+#endif
+	for (u64 w0 = 0; w0 < total; w0 += LZB_T) {
+		const uint32_t wlen = total - w0 < LZB_T ? (uint32_t)(total - w0) : LZB_T;
+		LZB_CN(6, 1)
+		if (tid < LZB_T / 32u) { L.bm[tid] = 0; }
+		if (tid == 0) { L.carry[0] = 0; L.carry[3] = 0; }
+		#pragma unroll
+		for (uint32_t r = 0; r < LZB_T / LZB_NT; ++r) { L.tokbuf[r * LZB_NT + tid] = pre[r]; }
+		__syncthreads();
+		// ---- the tokens that start in this tile: a tile cannot start more than LZB_T, thread j looks at tokens 8 j .. 8 j + 7 of the buffer ----
+		if (t < nt && tpos < w0 + wlen) {
+			constexpr uint32_t TPT = LZB_T / LZB_NT;                     // tokens per thread
+			uint32_t w[TPT], len[TPT], sum = 0;
+			#pragma unroll
+			for (uint32_t r = 0; r < TPT; ++r) {
+				w[r] = L.tokbuf[tid * TPT + r];
+				len[r] = (t + tid * TPT + r < nt) ? ((w[r] & 0x80000000u) ? 1u : (w[r] >> 16) & 0x7FFFu) : 0u;
+				sum += len[r];
+			}
+			const uint32_t incl = wave_incl_scan_add_u32(sum);
+			if (lane == 63u) { L.wsum[wv] = incl; }
+			__syncthreads();
+			uint32_t base = 0;
+			for (uint32_t k = 0; k < wv; ++k) { base += L.wsum[k]; }
+			u64 p = tpos + base + incl - sum;
+			uint32_t cnt = 0; u64 after = 0;
+			uint32_t accw = 0xFFFFFFFFu, accb = 0;                        // start bits of my tokens, collected per 32-position word (8 atomics on a shared word cost 15 000 cycles per tile)
+			#pragma unroll
+			for (uint32_t r = 0; r < TPT; ++r) {
+				if (t + tid * TPT + r < nt && p < w0 + wlen) {
+					const uint32_t q = (uint32_t)(p - w0);
+					L.info[q] = w[r];
+					if ((q >> 5) != accw) { if (accb) { atomicOr(&L.bm[accw], accb); } accw = q >> 5; accb = 0; }
+					accb |= 1u << (q & 31u);
+					++cnt; after = p + len[r];
+				}
+				p += len[r];
+			}
+			if (accb) { atomicOr(&L.bm[accw], accb); }
+			// the tokens placed are a prefix of the buffer; the end of the last one is where the next token starts
+			if (cnt) { atomicAdd(&L.carry[3], cnt); atomicMax(&L.carry[0], (uint32_t)(after - w0)); }
+			__syncthreads();
+			const uint32_t placed = L.carry[3];
+			if (placed) { t += placed; tpos = w0 + L.carry[0]; }
+		}
+		__syncthreads();
+		#pragma unroll
+		for (uint32_t r = 0; r < LZB_T / LZB_NT; ++r) { const u64 ti = t + (u64)r * LZB_NT + tid; pre[r] = ti < nt ? mytok[ti] : 0x80000000u; }   // (for the next tile)
+		__syncthreads();
+		LZB_TM(0)
+		// ---- per 32-position word: the highest token start before it (block max-scan over 256 words) ----
+		if (tid < LZB_T / 32u) {
+			const uint32_t wd = L.bm[tid];
+			const uint32_t hi = wd ? tid * 32u + 31u - (uint32_t)__builtin_clz(wd) + 1u : 0u;      // biased by 1: 0 = no start in this word
+			const uint32_t incl = wave_incl_scan_max(hi);
+			if (lane == 63u) { L.wsum[wv] = incl; }
+			L.last[tid] = incl;                                         // (inclusive for now)
+		}
+		__syncthreads();
+		if (tid < LZB_T / 32u) {
+			uint32_t before = 0;
+			for (uint32_t k = 0; k < wv; ++k) { before = before > L.wsum[k] ? before : L.wsum[k]; }
+			const uint32_t incl = L.last[tid] > before ? L.last[tid] : before;
+			const uint32_t mine = L.bm[tid] ? tid * 32u + 31u - (uint32_t)__builtin_clz(L.bm[tid]) + 1u : 0u;
+			// exclusive: the maximum over the words before this one
+			const uint32_t prev_lane = (uint32_t)__shfl_up((int)incl, 1, 64);
+			uint32_t excl = lane ? prev_lane : before;
+			(void)mine;
+			L.wsum[4u + 0u] = 0;                                        // (keeps the slot initialised)
+			L.last[tid] = excl;                                         // biased start position, 0 = none before this word in the tile
+			if (tid == LZB_T / 32u - 1u) { L.carry[2] = incl; }        // the last start of the tile (biased; 0 = none)
+		}
+		__syncthreads();
+		LZB_TM(1)
+		// ---- bytes: value, or where in the tile the value comes from (32-bit, relative to the tile) ----
+		uint32_t myw[LZB_T / LZB_NT];
+		#pragma unroll
+		for (uint32_t r = 0; r < LZB_T / LZB_NT; ++r) {
+			const uint32_t q = r * LZB_NT + tid;
+			uint32_t word = 0x80000000u;
+			if (q < wlen) {
+				const uint32_t bits = L.bm[q >> 5] & (0xFFFFFFFFu >> (31u - (q & 31u)));
+				const uint32_t sb = bits ? (q & ~31u) + 32u - (uint32_t)__builtin_clz(bits) : L.last[q >> 5];   // biased start of my token (0: it runs since before the tile)
+				const uint32_t inf = sb ? L.info[sb - 1u] : run_w;
+				if (inf & 0x80000000u) { word = 0x80000000u | (inf & 0xFFu); }
+				else {
+					const int32_t rel = (int32_t)q - (int32_t)(inf & 0xFFFFu);     // one offset back: the same byte
+					if (rel >= 0) { word = (uint32_t)rel; }
+					else { const int32_t ri = (int32_t)rbase + rel; word = 0x80000000u | L.ring[ri < 0 ? ri + (int32_t)LZB_RING : ri]; }
+				}
+			}
+			myw[r] = word;
+		}
+		// the token running when the next tile begins
+		const uint32_t lastb = L.carry[2];
+		if (lastb) { run_w = L.info[lastb - 1u]; }
+		__syncthreads();
+		#pragma unroll
+		for (uint32_t r = 0; r < LZB_T / LZB_NT; ++r) { L.info[r * LZB_NT + tid] = myw[r]; }
+		__syncthreads();
+		LZB_TM(2)
+		for (;;) {
+			LZB_CN(7, 1)
+			bool open = false;
+			#pragma unroll
+			for (uint32_t r = 0; r < LZB_T / LZB_NT; ++r) {
+				const uint32_t q = r * LZB_NT + tid;
+				uint32_t mine = myw[r];
+				if (!(mine & 0x80000000u)) {
+					const uint32_t tw = __hip_atomic_load(&L.info[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					mine = tw;                                              // its value, or where IT looks
+					myw[r] = mine;
+					__hip_atomic_store(&L.info[q], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					open |= !(mine & 0x80000000u);
+				}
+			}
+			if (!__syncthreads_or(open ? 1 : 0)) { break; }
+		}
+		LZB_TM(3)
+		// ---- the tile: into the ring and out ----
+		#pragma unroll
+		for (uint32_t r = 0; r < LZB_T / LZB_NT; ++r) { const uint32_t q = r * LZB_NT + tid; if (q < wlen) { L.ring[rbase + q] = (uint8_t)myw[r]; } }
+		__syncthreads();
+		{
+			uint8_t* __restrict__ o = dst + w0;
+			const uint8_t* src = L.ring + rbase;
+			uint32_t head = (uint32_t)((4u - ((uintptr_t)o & 3u)) & 3u);
+			if (head > wlen) { head = wlen; }
+			if (tid < head) { o[tid] = src[tid]; }
+			const uint32_t body = (wlen - head) >> 2;
+			uint32_t* __restrict__ o32 = reinterpret_cast<uint32_t*>(o + head);
+			for (uint32_t k = tid; k < body; k += LZB_NT) { o32[k] = lds_ld32(src, head + k * 4u); }
+			for (uint32_t k = head + body * 4u + tid; k < wlen; k += LZB_NT) { o[k] = src[k]; }
+		}
+		rbase += LZB_T; if (rbase >= LZB_RING) { rbase -= LZB_RING; }
+		__syncthreads();
+		LZB_TM(4)
+	}
+}
+
 void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
                                    const u64* cand_prefix, uint32_t n_slots, const XhcBufs& xb,
                                    uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase)
@@ -1220,7 +1419,13 @@ void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const Ba
 	case 2: hipLaunchKernelGGL(xhc_chain_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, cand_prefix, xb, ntok, d_out_len, d_status); break;
 	case 3: hipLaunchKernelGGL(xhc_parse_kernel<2>, dim3(n_slots), dim3(64), 0, st, d_in, bt, tok_prefix, cand_prefix, xb, tok); break;
 	case 4: hipLaunchKernelGGL(xhd_parse_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, tok_prefix, tok, ntok, d_out_len, d_status, xb.mode); break;
-	default: hipLaunchKernelGGL(lz_copy_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out); break;
+	default: {
+		static bool attr_set = false;
+		if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_copy_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzbLds)); attr_set = true; }
+		hipLaunchKernelGGL(lz_copy_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out);
+		hipLaunchKernelGGL(lz_copy_block_kernel, dim3(bt.n_units), dim3(LZB_NT), sizeof(LzbLds), st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out);
+		break;
+	}
 	}
 }
 
