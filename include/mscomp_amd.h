@@ -194,6 +194,12 @@ MSCompStatus mscomp_amd_debug_huff_lengths(mscomp_amd_ctx* ctx, const uint32_t* 
 /* Test hook: the Xpress parse/emit stage has two bit-identical kernels (one wave per unit; four
  * or sixteen waves per unit with speculative segments). 0 = chosen by batch size (default), 1 / 2 / 3 = force. Process-wide. */
 void         mscomp_amd_debug_set_xpress_emit(int mode);
+/* The reference has two LZNT1 dictionaries, chosen when it is BUILT (/root/reference/include/mscomp/config.h:83-88): the default one and,
+ * with -DMSCOMP_WITH_LZNT1_SA_DICT, a suffix-array one (/root/reference/include/mscomp/LZNT1Dictionary_SA.h) whose matches have the same
+ * lengths but other offsets -- so the compressed bytes differ. A deployment that replaces such a build selects the same flavour here
+ * (process-wide; or by MSCOMP_AMD_LZNT1_SA_DICT=1 in the environment when the library loads). Decompression is not affected. */
+void         mscomp_amd_set_lznt1_sa_dict(int on);
+int          mscomp_amd_get_lznt1_sa_dict(void);
 /* Test hook: the Xpress-family match finder evaluates every position (1 = default) or runs lazily (0: Find only where a greedy parse can
  * start a token, csrc/xlazy.hip; Xpress: units up to 64 KiB; exact but slower); the parse kernels get the same answers on
  * every path they walk. Process-wide. */

@@ -24,6 +24,8 @@ namespace {
 // time, so a plain counter) and a process-wide one for the test hooks that switch kernels (atomic: any thread may call them
 // while other threads execute plans).
 static std::atomic<uint64_t> g_mode_epoch{1};
+static int lznt1_sa_env() { const char* e = getenv("MSCOMP_AMD_LZNT1_SA_DICT"); return (e && *e && *e != '0') ? 1 : 0; }
+static std::atomic<int> g_lznt1_sa{lznt1_sa_env()};    // 1 = LZNT1 compresses with the suffix-array dictionary flavour (lznt1_sa.hip; the reference's MSCOMP_WITH_LZNT1_SA_DICT build)
 static std::atomic<int> g_finder_mode{1};              // 1 = Find for every position (default), 0 = the lazy finder of xlazy.hip (experimental: exact, slower -- DESIGN 5)
 struct DevBuf {
 	void* p = nullptr; size_t cap = 0;
@@ -405,7 +407,8 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 	switch (p->format) {
 	case MSCOMP_LZNT1: {
 		uint8_t* slots = static_cast<uint8_t*>(c->slots.p);
-		{ KernelTimer t(c, "lznt1_chunk_kernel"); launch_lznt1_chunks(st, d_in, p->bt, slots, slot_size); }
+		if (g_lznt1_sa.load(std::memory_order_relaxed)) { KernelTimer t(c, "lznt1_sa_chunk_kernel"); launch_lznt1_sa_chunks(st, d_in, p->bt, slots, slot_size); }
+		else { KernelTimer t(c, "lznt1_chunk_kernel"); launch_lznt1_chunks(st, d_in, p->bt, slots, slot_size); }
 		{ KernelTimer t(c, "scan_sizes"); launch_scan_sizes(st, slot_size, prefix, p->n_chunks, tile_sums); }
 		{ KernelTimer t(c, "concat_slots_kernel"); launch_concat_slots(st, slots, LZNT1_SLOT, slot_size, prefix, p->bt, d_out); }
 		{ KernelTimer t(c, "finalize_units_kernel"); launch_finalize_units(st, prefix, p->bt, d_out, d_out_len, d_status, 1); }
@@ -601,6 +604,8 @@ uint32_t mscomp_amd_debug_lzd_walked(mscomp_amd_ctx* c)
 	return lzd_read_walked();
 }
 
+void mscomp_amd_set_lznt1_sa_dict(int on) { g_lznt1_sa.store(on ? 1 : 0, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
+int  mscomp_amd_get_lznt1_sa_dict(void) { return g_lznt1_sa.load(std::memory_order_relaxed); }
 void mscomp_amd_debug_set_finder(int mode) { g_finder_mode.store(mode, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 void mscomp_amd_debug_set_lznt1(int mode) { set_lznt1_mode(mode); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 

@@ -8,6 +8,7 @@ namespace msc {
 #define LZNT1_SLOT 4352u     // scratch bytes per 4 KiB chunk image (2 B header + <=4096 B payload + emit slack)
 void set_lznt1_mode(int mode);
 void launch_lznt1_chunks(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* slots, uint32_t* slot_size);
+void launch_lznt1_sa_chunks(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* slots, uint32_t* slot_size);   // lznt1_sa.hip: the suffix-array dictionary flavour
 
 // ---- Xpress / Xpress+Huffman match finder (xpress_match.hip) ----
 // links: u16 per position (64 KiB "link chunks", chunk-major), lasthead: 32768 u16 per link chunk,

@@ -23,7 +23,8 @@ def build(force=False):
     so = os.path.join(HERE, "liboracle.so")
     src = os.path.join(HERE, "mscomp_oracle.c")
     need = force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)
-    need_ref = os.path.isdir("/root/reference/src") and not os.path.exists(os.path.join(HERE, "_ref", "libMSCompression.so"))
+    need_ref = os.path.isdir("/root/reference/src") and not (os.path.exists(os.path.join(HERE, "_ref", "libMSCompression.so")) and
+                                                             os.path.exists(os.path.join(HERE, "_ref", "libMSCompression_sa.so")))
     if need or need_ref:
         subprocess.run(["make", "-C", HERE, "all"], check=True, stdout=subprocess.DEVNULL)
 
@@ -42,6 +43,8 @@ def load_oracle():
         lib.orc_last_undefined.restype = C.c_int
         lib.orc_max_compressed_size.argtypes = [C.c_int, C.c_size_t]
         lib.orc_max_compressed_size.restype = C.c_size_t
+        lib.orc_set_lznt1_sa_dict.argtypes = [C.c_int]
+        lib.orc_set_lznt1_sa_dict.restype = None
         lib.orc_huff_lengths.argtypes = [C.c_void_p, C.c_void_p]
         lib.orc_huff_lengths_slow.argtypes = [C.c_void_p, C.c_void_p]
         lib.orc_lznt1_match_table.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
@@ -70,6 +73,42 @@ def load_ref():
         lib.ms_max_compressed_size.restype = C.c_size_t
         _ref = lib
     return _ref
+
+
+_ref_sa = None
+
+
+def load_ref_sa():
+    """The reference compiled with MSCOMP_WITH_LZNT1_SA_DICT (its suffix-array LZNT1 flavour), or None."""
+    global _ref_sa
+    if _ref_sa is None:
+        so = os.path.join(HERE, "_ref", "libMSCompression_sa.so")
+        if not os.path.exists(so):
+            return None
+        lib = C.CDLL(so)
+        lib.ms_compress.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
+        lib.ms_compress.restype = C.c_int
+        lib.ms_max_compressed_size.argtypes = [C.c_int, C.c_size_t]
+        lib.ms_max_compressed_size.restype = C.c_size_t
+        _ref_sa = lib
+    return _ref_sa
+
+
+def oracle_compress_sa(data, cap=None):
+    """LZNT1 with the suffix-array dictionary flavour (orc_set_lznt1_sa_dict around one orc_compress call)."""
+    lib = load_oracle()
+    lib.orc_set_lznt1_sa_dict(1)
+    try:
+        return oracle_compress(LZNT1, data, cap)
+    finally:
+        lib.orc_set_lznt1_sa_dict(0)
+
+
+def ref_compress_sa(data, cap=None):
+    lib = load_ref_sa()
+    if cap is None:
+        cap = lib.ms_max_compressed_size(LZNT1, len(data))
+    return _one_shot(lib.ms_compress, LZNT1, data, cap)
 
 
 def _one_shot(fn, fmt, data, cap):

@@ -73,6 +73,80 @@ static unsigned lznt1_find(const lznt1_dict* d, const uint8_t* c, unsigned p, un
 	return best;
 }
 
+
+/* ---- LZNT1, suffix-array dictionary flavour (the reference built with MSCOMP_WITH_LZNT1_SA_DICT: include/mscomp/LZNT1Dictionary_SA.h) ----
+ * Same chunk loop, another Find: the longest match is taken from the two LEXICOGRAPHIC neighbours of the position's suffix that start
+ * earlier -- the nearest one before it in suffix-array order, the nearest one after it -- the one before winning ties (:424-476), so the
+ * length is the same "optimal" one but the offset differs from the default dictionary (which takes the OLDEST candidate of that length).
+ * Restated with a plain construction (prefix doubling with qsort, brute-force LCP): the suffix array of a string is unique -- a suffix
+ * that is a prefix of another sorts first (:360, the theoretical terminator) -- so SA-IS (:49-354) and this give the same arrays. */
+static int orc_lznt1_sa = 0;
+void orc_set_lznt1_sa_dict(int on) { orc_lznt1_sa = on; }
+typedef struct { int16_t sa[4096], inv[4096], lcp[4096]; unsigned n; } lznt1_sa_dict;
+static const uint32_t* sa_key_for_sort;
+static int sa_cmp(const void* a, const void* b)
+{
+	const uint32_t ka = sa_key_for_sort[*(const int16_t*)a], kb = sa_key_for_sort[*(const int16_t*)b];
+	return ka < kb ? -1 : ka > kb;
+}
+static void lznt1_sa_fill(lznt1_sa_dict* d, const uint8_t* c, unsigned n)        /* Fill (:404-419) */
+{
+	static __thread uint32_t key[4096];
+	static __thread uint16_t rank[4096], nr[4096];
+	d->n = n;
+	if (n <= 3) { return; }
+	for (unsigned i = 0; i < n; ++i) { rank[i] = (uint16_t)(c[i] + 1u); d->sa[i] = (int16_t)i; }
+	for (unsigned k = 1;; k <<= 1) {
+		for (unsigned i = 0; i < n; ++i) { key[i] = ((uint32_t)rank[i] << 13) | (i + k < n ? rank[i + k] : 0u); }
+		sa_key_for_sort = key;
+		qsort(d->sa, n, sizeof(int16_t), sa_cmp);
+		unsigned r = 1; nr[d->sa[0]] = 1;
+		for (unsigned i = 1; i < n; ++i) { if (key[d->sa[i]] != key[d->sa[i - 1]]) { ++r; } nr[d->sa[i]] = (uint16_t)r; }
+		memcpy(rank, nr, n * sizeof(uint16_t));
+		if (r == n || k >= n) { break; }
+	}
+	for (unsigned i = 0; i < n; ++i) { d->inv[d->sa[i]] = (int16_t)i; }
+	d->lcp[0] = 0;
+	for (unsigned i = 1; i < n; ++i) {                                               /* calc_lcp (:361-384) gives exactly these values */
+		const unsigned a = (unsigned)d->sa[i - 1], b = (unsigned)d->sa[i], m = n - (a > b ? a : b);
+		unsigned l = 0;
+		while (l < m && c[a + l] == c[b + l]) { ++l; }
+		d->lcp[i] = (int16_t)l;
+	}
+}
+static unsigned lznt1_sa_find(const lznt1_sa_dict* d, unsigned pos, unsigned max_len, unsigned* off)   /* Find (:424-476) */
+{
+	if (max_len < 3 || pos == 0) { return 0; }
+	const int si = d->inv[pos], n = (int)d->n;
+	int len = 2, found = 0;
+	int min_lcp = d->lcp[si];
+	if (min_lcp > 2) {
+		if ((unsigned)d->sa[si - 1] < pos) { len = min_lcp; found = d->sa[si - 1]; }
+		else {
+			for (int i = si - 2; i >= 0; --i) {
+				const int l = d->lcp[i + 1];
+				if (l < min_lcp) { if (l <= 2) { break; } min_lcp = l; }
+				if ((unsigned)d->sa[i] < pos) { len = min_lcp; found = d->sa[i]; break; }
+			}
+		}
+	}
+	if (si != n - 1) {
+		min_lcp = d->lcp[si + 1];
+		if (min_lcp > len) {
+			if ((unsigned)d->sa[si + 1] < pos) { len = min_lcp; found = d->sa[si + 1]; }
+			else {
+				for (int i = si + 2; i < n; ++i) {
+					const int l = d->lcp[i];
+					if (l < min_lcp) { if (l <= len) { break; } min_lcp = l; }
+					if ((unsigned)d->sa[i] < pos) { len = min_lcp; found = d->sa[i]; break; }
+				}
+			}
+		}
+	}
+	if (len > 2) { *off = pos - (unsigned)found; return (unsigned)len > max_len ? max_len : (unsigned)len; }
+	return 0;
+}
+
 /* position-dependent split of the 16-bit match token (lznt1_compress.cpp:51,66): a pure function of pos */
 static inline void lznt1_split(unsigned pos, unsigned* shift, unsigned* mask3)
 {
@@ -86,13 +160,16 @@ static inline void lznt1_split(unsigned pos, unsigned* shift, unsigned* mask3)
 static unsigned lznt1_chunk(lznt1_dict* d, const uint8_t* c, unsigned n, uint8_t* out)
 {
 	unsigned pos = 0, o = 0;
-	lznt1_fill(d, c, n);
+	static __thread lznt1_sa_dict sd;
+	const int sa = orc_lznt1_sa;
+	if (sa) { lznt1_sa_fill(&sd, c, n); } else { lznt1_fill(d, c, n); }
 	while (pos < n) {
 		uint8_t grp[16]; unsigned g = 0, flags = 0, i;
 		for (i = 0; i < 8 && pos < n; ++i) {
 			unsigned shift, mask3, off = 0;
 			lznt1_split(pos, &shift, &mask3);
-			const unsigned rem = n - pos, len = lznt1_find(d, c, pos, rem < mask3 ? rem : mask3, &off);
+			const unsigned rem = n - pos, ml = rem < mask3 ? rem : mask3;
+			const unsigned len = sa ? lznt1_sa_find(&sd, pos, ml, &off) : lznt1_find(d, c, pos, ml, &off);
 			if (len >= 3) { put16(grp + g, ((off - 1) << shift) | (len - 3)); g += 2; flags |= 1u << i; pos += len; }
 			else { grp[g++] = c[pos++]; }
 		}

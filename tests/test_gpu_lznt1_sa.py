@@ -1,0 +1,78 @@
+"""GPU (MI355X): LZNT1 with the suffix-array dictionary flavour (csrc/lznt1_sa.hip) -- byte-exact against the oracle's
+restatement of LZNT1Dictionary_SA.h and against tests/golden/lznt1_sa.json, written by the reference compiled with
+-DMSCOMP_WITH_LZNT1_SA_DICT (tools/make_golden_sa.py)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+sha = lambda b: hashlib.sha256(b).hexdigest()
+
+
+@pytest.fixture()
+def sa_mode(gpu_ctx):
+    lib = gpu_ctx.lib
+    assert lib.mscomp_amd_get_lznt1_sa_dict() == 0
+    lib.mscomp_amd_set_lznt1_sa_dict(1)
+    yield gpu_ctx
+    lib.mscomp_amd_set_lznt1_sa_dict(0)
+
+
+def test_edge_families_and_adversarial_chunks(oracle, sa_mode):
+    import ms_compress_amd as m
+    units = list(cases.edge_cases())
+    rng = np.random.default_rng(17)
+    for period in (1, 2, 3, 5, 64, 65, 1023, 2048):      # long repeats: the doubling rounds run to the end, LCPs of thousands, deep stacks
+        base = rng.integers(0, 256, period, dtype=np.uint8)
+        units.append(np.tile(base, 9000 // period + 1)[:9000].tobytes())
+    units += [bytes(rng.choice(np.frombuffer(b"abc", np.uint8), int(n))) for n in rng.integers(4, 9000, 40)]   # many equal-length candidates: the tie rules
+    units.append(cases.mixed_buffer())
+    got, st = m.compress_units(2, units, ctx=sa_mode)
+    differ = 0
+    for i, (u, g, s) in enumerate(zip(units, got, st)):
+        es, exp = oracle.oracle_compress_sa(bytes(u))
+        assert es == 0 and s == 0 and g == exp, "unit %d (%d bytes): GPU bytes differ from the suffix-array oracle" % (i, len(u))
+        differ += exp != oracle.oracle_compress(2, bytes(u))[1]
+    assert differ > 20                                   # the flavour is a different byte stream, not the default one by another name
+    g = json.load(open(os.path.join(G, "lznt1_sa.json")))["edge_families"]
+    h = hashlib.sha256()
+    for o in got[:g["units"]]:
+        h.update(len(o).to_bytes(8, "little")); h.update(o)
+    assert h.hexdigest() == g["sha256"]
+
+
+def test_corpus_golden_and_round_trip(sa_mode):
+    import ms_compress_amd as m
+    from ms_compress_amd import corpus
+    g = json.load(open(os.path.join(G, "lznt1_sa.json")))
+    names = corpus.NAMES + ["mixed_buffer"]
+    units = [corpus.file_bytes(i, g["corpus"][n]["input_len"]).tobytes() for i, n in enumerate(corpus.NAMES)] + [cases.mixed_buffer()]
+    got, st = m.compress_units(2, units, ctx=sa_mode)
+    for n, o, s in zip(names, got, st):
+        assert s == 0 and len(o) == g["corpus"][n]["len"] and sha(o) == g["corpus"][n]["sha256"], n
+    back, st = m.decompress_units(2, got, [len(u) for u in units], ctx=sa_mode)
+    assert all(s == 0 for s in st) and all(b == u for b, u in zip(back, units))
+    for name, k in g["kat"].items():
+        data = bytes.fromhex(k["input_hex"]) if k["input_hex"] is not None else {"abc*100": b"abc" * 100, "zeros4097": bytes(4097)}[name]
+        out, st = m.compress_units(2, [data], ctx=sa_mode)
+        assert st[0] == 0 and out[0].hex() == k["hex"], name
+
+
+def test_switching_back_replays_the_default_flavour(oracle, gpu_ctx):
+    """the switch is process-wide and plans notice it (mode epoch): same plan shape, other bytes, and back."""
+    import ms_compress_amd as m
+    u = [bytes(np.random.default_rng(3).choice(np.frombuffer(b"abc", np.uint8), 30000))]
+    a, _ = m.compress_units(2, u, ctx=gpu_ctx)
+    gpu_ctx.lib.mscomp_amd_set_lznt1_sa_dict(1)
+    try:
+        b, _ = m.compress_units(2, u, ctx=gpu_ctx)
+    finally:
+        gpu_ctx.lib.mscomp_amd_set_lznt1_sa_dict(0)
+    c, _ = m.compress_units(2, u, ctx=gpu_ctx)
+    assert a[0] == c[0] == oracle.oracle_compress(2, u[0])[1] and b[0] == oracle.oracle_compress_sa(u[0])[1] and a[0] != b[0]

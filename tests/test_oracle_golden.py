@@ -145,3 +145,30 @@ def test_oracle_huffman_lengths_match_the_reference_fixture(oracle):
         assert hashlib.sha256(lens.tobytes()).hexdigest()[:16] == gold["sha256_16_per_case"][i], i
         allh.update(lens.tobytes())
     assert allh.hexdigest() == gold["sha256_all"]
+
+
+def test_lznt1_sa_dictionary_flavour_golden(oracle):
+    """the oracle's suffix-array dictionary (LZNT1Dictionary_SA.h:404-476 restated) against what the reference BUILT WITH
+    MSCOMP_WITH_LZNT1_SA_DICT wrote (tests/golden/lznt1_sa.json, tools/make_golden_sa.py); the default decoder reads it back."""
+    from ms_compress_amd import corpus
+    g = json.load(open(os.path.join(G, "lznt1_sa.json")))
+    assert any(k["differs_from_default"] for k in g["kat"].values())
+    for name, k in g["kat"].items():
+        data = bytes.fromhex(k["input_hex"]) if k["input_hex"] is not None else {"abc*100": b"abc" * 100, "zeros4097": bytes(4097)}[name]
+        st, out = oracle.oracle_compress_sa(data)
+        assert st == 0 and out.hex() == k["hex"], name
+        assert (out != oracle.oracle_compress(2, data)[1]) == k["differs_from_default"]
+    for i, name in enumerate(corpus.NAMES):
+        e = g["corpus"][name]
+        data = corpus.file_bytes(i, e["input_len"]).tobytes()
+        assert sha(data) == e["input_sha256"]
+        st, out = oracle.oracle_compress_sa(data)
+        assert st == 0 and len(out) == e["len"] and sha(out) == e["sha256"], name
+        st, back = oracle.oracle_decompress(2, out, len(data))
+        assert st == 0 and back == data
+    h = hashlib.sha256(); tot = 0
+    for u in cases.edge_cases():
+        st, out = oracle.oracle_compress_sa(u)
+        assert st == 0
+        h.update(len(out).to_bytes(8, "little")); h.update(out); tot += len(out)
+    assert tot == g["edge_families"]["total_len"] and h.hexdigest() == g["edge_families"]["sha256"]

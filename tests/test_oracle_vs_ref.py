@@ -111,3 +111,19 @@ def test_threaded_cpu_baseline_driver(oracle, ref):
         assert (st == 0).all() and [int(x) for x in ln] == [len(u) for u in units]
         dt, st, ln = oracle.time_units(None, fmt, units, caps, 2, 1)                 # the oracle's own compressor
         assert (st == 0).all() and [int(x) for x in ln] == [len(c) for c in comp]
+
+
+def test_lznt1_sa_dictionary_flavour(oracle):
+    """the oracle's suffix-array dictionary against the reference compiled with -DMSCOMP_WITH_LZNT1_SA_DICT (oracle/_ref/libMSCompression_sa.so)"""
+    if oracle.load_ref_sa() is None:
+        pytest.skip("oracle/_ref/libMSCompression_sa.so not built")
+    from ms_compress_amd import corpus
+    units = cases.edge_cases() + [cases.mixed_buffer()] + [corpus.file_bytes(i, 200_000).tobytes() for i in range(12)]
+    rng = random.Random(11)
+    units += [bytes(rng.choice(b"abc") for _ in range(rng.randint(4, 5000))) for _ in range(60)]
+    for data in units:
+        assert oracle.oracle_compress_sa(data) == oracle.ref_compress_sa(data), len(data)
+    data = cases.mixed_buffer()[:20000]
+    full = oracle.ref_compress_sa(data)[1]
+    for cap in (len(full), len(full) - 1, 300):
+        assert oracle.oracle_compress_sa(data, cap=cap)[0] == oracle.ref_compress_sa(data, cap=cap)[0]
