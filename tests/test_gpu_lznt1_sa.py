@@ -76,3 +76,17 @@ def test_switching_back_replays_the_default_flavour(oracle, gpu_ctx):
         gpu_ctx.lib.mscomp_amd_set_lznt1_sa_dict(0)
     c, _ = m.compress_units(2, u, ctx=gpu_ctx)
     assert a[0] == c[0] == oracle.oracle_compress(2, u[0])[1] and b[0] == oracle.oracle_compress_sa(u[0])[1] and a[0] != b[0]
+
+
+def test_host_pointer_one_shot_calls(oracle, sa_mode):
+    """ms_compress with host pointers (mscomp.h; the thread's cached plans notice the switch), small and sliced (> 48 MiB: uploads, kernels and
+    downloads on three streams, csrc/api.hip lznt1_compress_pipelined): the flavour's bytes through the drop-in entry point itself."""
+    import ms_compress_amd as m
+    from ms_compress_amd import corpus
+    small = bytes(np.random.default_rng(4).choice(np.frombuffer(b"abc", np.uint8), 50000))
+    out = m.compress(2, small)                                 # (raises MSCompError on a status other than MSCOMP_OK)
+    assert out == oracle.oracle_compress_sa(small)[1] and out != oracle.oracle_compress(2, small)[1]
+    big = corpus.file_bytes(1).tobytes()                       # mozilla, 51 220 480 B
+    g = json.load(open(os.path.join(G, "corpus_full.json")))["mozilla"]
+    out = m.compress(2, big)
+    assert len(out) == g["lznt1_sa"]["len"] and sha(out) == g["lznt1_sa"]["sha256"]

@@ -78,3 +78,42 @@ def test_config5_replicated_corpus(gpu_ctx, fmt):
         assert np.array_equal(lens[r * nu:(r + 1) * nu], lens[:nu]), r
         assert int(poff[(r + 1) * nu]) - int(poff[r * nu]) == span
         assert bool(torch.equal(d_packed[int(poff[r * nu]): int(poff[r * nu]) + span], d_packed[:span])), r
+
+
+def test_lznt1_sa_dictionary_flavour_full_files(gpu_ctx):
+    """SURVEY.md 8f-4 at full size: all 12 files (211 938 580 B, 51 747 chunks) through csrc/lznt1_sa.hip against what the reference built
+    with -DMSCOMP_WITH_LZNT1_SA_DICT wrote (corpus_full.json "lznt1_sa"): same lengths as the default flavour, other bytes."""
+    import time
+    import torch
+    import ms_compress_amd as m
+    from ms_compress_amd import corpus
+    files = [corpus.file_bytes(i) for i in range(12)]
+    flen = np.array([len(f) for f in files], dtype=np.uint64)
+    foff = np.zeros(12, dtype=np.uint64); foff[1:] = np.cumsum(flen)[:-1]
+    dev = torch.device("cuda", gpu_ctx.device)
+    d_in = torch.cat([torch.from_numpy(np.concatenate(files)).to(dev), torch.zeros(16, dtype=torch.uint8, device=dev)])
+    caps = np.array([m.max_compressed_size(2, int(x)) + 2 for x in flen], dtype=np.uint64)
+    out_off, out_total = m.pack_offsets(caps)
+    d_out = torch.empty(out_total + 16, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(12, dtype=torch.int64, device=dev)
+    d_st = torch.full((12,), -9, dtype=torch.int32, device=dev)
+    gpu_ctx.lib.mscomp_amd_set_lznt1_sa_dict(1)
+    try:
+        plan = m.Plan(gpu_ctx, 2, foff, flen, out_off, caps)
+        plan.execute(d_in, d_out, d_len, d_st)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        plan.execute(d_in, d_out, d_len, d_st)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        plan.close()
+    finally:
+        gpu_ctx.lib.mscomp_amd_set_lznt1_sa_dict(0)
+    print("lznt1 suffix-array flavour: %.1f ms for %d B = %.2f GB/s" % (dt * 1e3, int(flen.sum()), int(flen.sum()) / dt / 1e9))
+    assert bool((d_st == 0).all().item())
+    lens = d_len.cpu().numpy()
+    out = d_out.cpu().numpy()
+    for i, name in enumerate(corpus.NAMES):
+        g = GOLD[name]["lznt1_sa"]
+        assert int(lens[i]) == g["len"] and g["sha256"] != GOLD[name]["lznt1"]["sha256"]
+        assert hashlib.sha256(out[int(out_off[i]): int(out_off[i]) + int(lens[i])].tobytes()).hexdigest() == g["sha256"], name

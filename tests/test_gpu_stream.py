@@ -205,3 +205,33 @@ def test_deflate_look_ahead_notices_changed_input(oracle, gpu_ctx):
                 break
         return outbuf.raw[:opos], trace, lib.ms_deflate_end(C.byref(s))
     assert run(m.load_library()) == run(ref)
+
+
+def test_lznt1_deflate_under_the_suffix_array_flavour(oracle, gpu_ctx):
+    """SURVEY.md 8f-4 through the streaming compressor: with mscomp_amd_set_lznt1_sa_dict(1) the calls match the reference BUILT WITH
+    -DMSCOMP_WITH_LZNT1_SA_DICT call by call (status, bytes taken / given, output), and without MSCOMP_FLUSH the stream is that build's
+    one-shot output -- not the default flavour's."""
+    import ms_compress_amd as m
+    ref = oracle.load_ref_sa()
+    if ref is None:
+        pytest.skip("oracle/_ref/libMSCompression_sa.so not built")
+    mine = m.load_library()
+    rnd = random.Random(21)
+    datas = [cases.family("words", 4096, rnd), cases.family("lz", 12289, rnd), bytes(rnd.choice(b"abc") for _ in range(30000)),
+             cases.mixed_buffer()[95000:95000 + 120000]]
+    mine.mscomp_amd_set_lznt1_sa_dict(1)
+    try:
+        n_cmp = 0
+        for data in datas:
+            for steps, tail in plans(rnd, len(data)):
+                want = drive(ref, 2, data, steps, tail)
+                got = drive(mine, 2, data, steps, tail)
+                assert got[1] == want[1], (len(data), steps[:4], tail)
+                assert got[0] == want[0] and got[2] == want[2]
+                n_cmp += 1
+        assert n_cmp >= 40
+        data = datas[2]
+        out, _, end = drive(mine, 2, data, [(7000, 3000, NO_FLUSH)] * 10, 5000)
+        assert end == 0 and out == oracle.oracle_compress_sa(data)[1] and out != oracle.oracle_compress(2, data)[1]
+    finally:
+        mine.mscomp_amd_set_lznt1_sa_dict(0)
