@@ -401,6 +401,18 @@ def main():
                              "workload": d2, "compression_ratio": round(ob / j2.in_bytes, 4), "roofline": roofline(f2, p2, j2.in_bytes, ob, n2, "single_gpu")}
             j2.close()
         extra["single_gpu"] = single
+        # the suffix-array dictionary flavour of LZNT1 (csrc/lznt1_sa.hip) on the 12 files; HIP events per kernel as everywhere
+        b2, o2, l2, d2 = single_gpu_workload(cor, "silesia_files")
+        ctx.lib.mscomp_amd_set_lznt1_sa_dict(1)
+        try:
+            j2 = Job(m, ctx, m.FORMATS["lznt1"], b2, o2, l2)
+            t2, p2 = timed(j2, steps2, 1, sharding)
+            extra["lznt1_sa_dict"] = {"MB_per_s": round(j2.in_bytes * steps2 / t2 / 1e6, 1), "ms_per_step": round(t2 / steps2 * 1e3, 4), "steps": steps2, "workload": d2,
+                                      "compression_ratio": round(j2.out_bytes() / j2.in_bytes, 4),
+                                      "kernels_ms_per_step": {k: round(v[0] / steps2, 4) for k, v in p2.items()}}
+            j2.close()
+        finally:
+            ctx.lib.mscomp_amd_set_lznt1_sa_dict(0)
         dec = {}
         for codec, wl in (("lznt1", "mozilla"), ("xpress", "silesia_units64k"), ("xpress_huff", "silesia_units64k")):
             f2 = m.FORMATS[codec]

@@ -200,6 +200,9 @@ void         mscomp_amd_debug_set_xpress_emit(int mode);
  * (process-wide; or by MSCOMP_AMD_LZNT1_SA_DICT=1 in the environment when the library loads). Decompression is not affected. */
 void         mscomp_amd_set_lznt1_sa_dict(int on);
 int          mscomp_amd_get_lznt1_sa_dict(void);
+/* Test hook: Xpress decompression has two bit-identical paths: 0 = default (32-bit tokens, a flag word per step, then the copy kernels that
+ * Xpress+Huffman uses), 1 = one wave per stream taking a token per step and moving the bytes itself (round 1's kernel). Process-wide. */
+void         mscomp_amd_debug_set_xpress_decoder(int mode);
 /* Test hook: the Xpress-family match finder evaluates every position (1 = default) or runs lazily (0: Find only where a greedy parse can
  * start a token, csrc/xlazy.hip; Xpress: units up to 64 KiB; exact but slower); the parse kernels get the same answers on
  * every path they walk. Process-wide. */

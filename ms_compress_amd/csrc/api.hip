@@ -26,6 +26,7 @@ namespace {
 static std::atomic<uint64_t> g_mode_epoch{1};
 static int lznt1_sa_env() { const char* e = getenv("MSCOMP_AMD_LZNT1_SA_DICT"); return (e && *e && *e != '0') ? 1 : 0; }
 static std::atomic<int> g_lznt1_sa{lznt1_sa_env()};    // 1 = LZNT1 compresses with the suffix-array dictionary flavour (lznt1_sa.hip; the reference's MSCOMP_WITH_LZNT1_SA_DICT build)
+static std::atomic<int> g_xpd_mode{0};                 // Xpress decompression: 0 = tokens a flag word at a time + copy kernels (default), 1 = xpd_kernel (a token at a time, bytes in the same wave)
 static std::atomic<int> g_finder_mode{1};              // 1 = Find for every position (default), 0 = the lazy finder of xlazy.hip (experimental: exact, slower -- DESIGN 5)
 struct DevBuf {
 	void* p = nullptr; size_t cap = 0;
@@ -283,6 +284,20 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 			if (okd && (hipMemcpyAsync(p->tokpre.p, tp.data(), tp.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
 			            hipStreamSynchronize(c->stream) != hipSuccess)) { p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_ERRNO; }
 		}
+		if (okd && format == MSCOMP_XPRESS) {
+			// a token takes at least one input byte and gives at least one output byte; a match one more token per 32766 bytes
+			std::vector<uint64_t> tp(n_units + 1);
+			uint64_t slots = 0;
+			for (size_t i = 0; i < n_units; ++i) {
+				tp[i] = slots;
+				const uint64_t by_in = in_len[i] + out_cap[i] / 32766u + 1, cnt = out_cap[i] < by_in ? out_cap[i] : by_in;
+				slots += cnt + 64;
+			}
+			tp[n_units] = slots;
+			okd = p->tokpre.reserve(tp.size() * 8) && c->dz_tok.reserve(slots * 4 + 256) && c->dz_ntok.reserve((n_units + 1) * 8);
+			if (okd && (hipMemcpyAsync(p->tokpre.p, tp.data(), tp.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+			            hipStreamSynchronize(c->stream) != hipSuccess)) { p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_ERRNO; }
+		}
 		if (!okd) { p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_MEM_ERROR; }
 		*out = p;
 		return MSCOMP_OK;
@@ -378,7 +393,10 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 			return MSCOMP_OK;
 		}
 		case MSCOMP_XPRESS: {
-			KernelTimer t(c, "xpd_kernel"); launch_xpress_decompress(st, d_in, p->bt, d_out, d_out_len, d_status);
+			if (g_xpd_mode.load(std::memory_order_relaxed) == 1) { KernelTimer t(c, "xpd_kernel"); launch_xpress_decompress(st, d_in, p->bt, d_out, d_out_len, d_status); return MSCOMP_OK; }
+			const u64* tp = static_cast<const u64*>(p->tokpre.p); uint32_t* tok = static_cast<uint32_t*>(c->dz_tok.p); u64* ntok = static_cast<u64*>(c->dz_ntok.p);
+			static const char* const names[3] = {"xpt_parse_kernel", "lz_copy_kernel", "lz_copy_block_kernel"};
+			for (int ph = 0; ph < 3; ++ph) { KernelTimer t(c, names[ph]); launch_xpress_decompress_tokens(st, d_in, p->bt, tp, tok, ntok, d_out, d_out_len, d_status, ph); }
 			return MSCOMP_OK;
 		}
 		case MSCOMP_XPRESS_HUFF: {
@@ -606,6 +624,7 @@ uint32_t mscomp_amd_debug_lzd_walked(mscomp_amd_ctx* c)
 
 void mscomp_amd_set_lznt1_sa_dict(int on) { g_lznt1_sa.store(on ? 1 : 0, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 int  mscomp_amd_get_lznt1_sa_dict(void) { return g_lznt1_sa.load(std::memory_order_relaxed); }
+void mscomp_amd_debug_set_xpress_decoder(int mode) { g_xpd_mode.store(mode, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 void mscomp_amd_debug_set_finder(int mode) { g_finder_mode.store(mode, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 void mscomp_amd_debug_set_lznt1(int mode) { set_lznt1_mode(mode); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 

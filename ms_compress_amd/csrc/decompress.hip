@@ -715,6 +715,161 @@ void launch_xpress_decompress(hipStream_t st, const uint8_t* d_in, const BatchTa
 	hipLaunchKernelGGL(xpd_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, d_out, d_out_len, d_status);
 }
 
+// ---- the same stream as TOKENS, a flag word at a time ---------------------------------------------------------------------------------
+// xpd_kernel above takes one token per step (and moves its bytes): 450 cycles per token, 3.7 s for one 51 MB stream. But where the 32 tokens
+// of a flag word start is known at once unless a match carries extra length bytes: a literal takes 1 byte, a match 2, so token r starts
+// r + (matches before r) bytes behind the flag word, and only a match whose 3-bit length field is 7 (a match of 10 bytes or more) takes more.
+// So lane r reads token r. Such a match takes its length from a nibble, two nibbles to a byte that the first of the two brings along: the
+// tokens behind it move by one, and by one more behind a nibble of 15 with its length byte -- found by a short iteration (below). Only the
+// longer forms (a match of 280 bytes or more) stop the lanes: the tokens before it are decoded, checked (READ_SYMBOL's and the copy's tests, :62-107 / :442-455, with the
+// output offset from a wave scan of the lengths) and written as 32-bit tokens together, that match is decoded by all lanes as one, and
+// the rest of the flag word goes the same way from behind it.
+// The bytes are produced afterwards by lz_copy_kernel / lz_copy_block_kernel, as for Xpress+Huffman. Status and length are those of the
+// serial walk: the first token, in order, that fails decides.
+#define XPT_INB 1024u
+#define LZT_MAXLEN 32766u                                       // longest match a 32-bit token holds (15 bits); longer ones are cut into pieces
+__global__ __launch_bounds__(64) void xpt_parse_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, const u64* __restrict__ tok_prefix, uint32_t* __restrict__ tok,
+                                                      u64* __restrict__ ntok, u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t s_in[2u * XPT_INB];
+	const uint32_t lane = threadIdx.x, u = blockIdx.x;
+	const uint32_t n = (uint32_t)bt.in_len[u];
+	const u64 cap = bt.out_cap[u];
+	const uint8_t* src = d_in + bt.in_off[u];
+	uint32_t* __restrict__ mytok = tok + tok_prefix[u];
+	if (n < 5u) {                                                        // :414-418
+		bool ok = n == 0;
+		if (n == 4u) { ok = ((uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24)) != 0xFFFFFFFFu; }
+		if (lane == 0) { d_status[u] = ok ? 0 : -3; d_out_len[u] = 0; ntok[u] = 0; }
+		return;
+	}
+	// input ring as in xpd_kernel (two blocks of 1024 bytes); the block after the newest one is already on its way from HBM, in registers
+	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
+	const uint8_t* ab = src - a0;
+	const uint32_t endq = a0 + n;
+	uint32_t loaded = 0;
+	uint4 nxt = lane * 16u < endq ? *reinterpret_cast<const uint4*>(ab + lane * 16u) : make_uint4(0, 0, 0, 0);
+	#define XPT_BLOCK() { __syncthreads(); *reinterpret_cast<uint4*>(s_in + (loaded & 1u) * XPT_INB + lane * 16u) = nxt; ++loaded; \
+		{ const u64 q_ = (u64)loaded * XPT_INB + lane * 16u; nxt = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } __syncthreads(); }
+	XPT_BLOCK() XPT_BLOCK()
+	auto rb = [&](uint32_t q) -> uint32_t { return s_in[q & (2u * XPT_INB - 1u)]; };
+	const uint32_t* in32 = reinterpret_cast<const uint32_t*>(s_in);
+	uint32_t ip = a0;
+	u64 op = 0, tc = 0;
+	int32_t status = -3;
+	uint32_t half = 0; bool have_half = false, done = false;
+	while (!done) {
+		if (ip + 4u > endq) { status = -3; break; }                     // :461 the input ended at a flag word
+		while ((u64)loaded * XPT_INB < (u64)ip + 352u && (u64)loaded * XPT_INB < endq) { XPT_BLOCK() }   // a flag word and its 32 tokens take at most 4 + 32 * 10 bytes
+		uint32_t m;                                                      // bit i: token i is a match
+		{ const uint32_t i_ = (ip >> 2) & (2u * XPT_INB / 4u - 1u); m = __builtin_bitreverse32(__builtin_amdgcn_alignbyte(in32[(i_ + 1u) & (2u * XPT_INB / 4u - 1u)], in32[i_], ip & 3u)); }
+		ip += 4u;
+		uint32_t j0 = 0;                                                 // first token of the flag word not taken yet
+		while (j0 < 32u) {
+			const uint32_t mm = m >> j0, cntl = 32u - j0, r = lane & 31u;
+			const bool act = lane < cntl;
+			const bool is_m = (mm >> r) & 1u;
+			// Matches with length field 7 ("long") take their length from a nibble: every other one brings a byte for two of them (the
+			// first, if none is pending, :88-95), which moves the tokens behind it by one. Which matches are long depends on where they
+			// are, and that on the long ones before them: solved by iteration -- positions from the current set, the set from the symbols at
+			// those positions, until it stands. A nibble of 15 is followed by a length byte (:96-99; 255 there: longer forms, not taken here), one
+			// more byte to move by: a second set, iterated along. The sets are right up to one token further every round at least (token 0 is
+			// always right) and the true sets are a fixed point, the only one; typically 1 + the number of shifting matches rounds.
+			const uint32_t below = (1u << r) - 1u, mbefore = (uint32_t)__builtin_popcount(mm & below);
+			const uint32_t hsel = have_half ? 1u : 0u;                   // which long matches bring the nibble byte: every other one, the first unless a nibble is pending
+			uint32_t longs = 0, ext1 = 0, q, w, hbn, nib, extb;
+			bool lng, brings, e1;
+			for (;;) {
+				const uint32_t kb = (uint32_t)__builtin_popcount(longs & below);
+				q = ip + r + mbefore + ((kb + 1u - hsel) >> 1) + (uint32_t)__builtin_popcount(ext1 & below);
+				{ const uint32_t i_ = (q >> 2) & (2u * XPT_INB / 4u - 1u); w = __builtin_amdgcn_alignbyte(in32[(i_ + 1u) & (2u * XPT_INB / 4u - 1u)], in32[i_], q & 3u); }   // bytes q .. q+3
+				lng = act && is_m && (w & 7u) == 7u;
+				const uint32_t now = (uint32_t)__ballot(lng);
+				hbn = (w >> 16) & 0xFFu;
+				if (now == 0) { brings = false; e1 = false; nib = 0; extb = 0; if (longs == 0 && ext1 == 0) { break; } longs = 0; ext1 = 0; continue; }   // no long match at all: most flag words of text
+				const uint32_t kn = (uint32_t)__builtin_popcount(now & below);
+				brings = lng && ((kn & 1u) == hsel);
+				const uint32_t pv = now & below;
+				const uint32_t hprev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((31u - (uint32_t)__builtin_clz(pv ? pv : 1u)) << 2), (int)hbn);
+				nib = brings ? (hbn & 0xFu) : ((kn ? hprev : half) >> 4);
+				extb = brings ? w >> 24 : hbn;                          // the length byte behind a nibble of 15
+				e1 = lng && nib == 0xFu && extb != 0xFFu;
+				const uint32_t now1 = (uint32_t)__ballot(e1);
+				if (now == longs && now1 == ext1) { break; }
+				longs = now; ext1 = now1;
+			}
+			const uint32_t b0 = w & 0xFFu, sym = w & 0xFFFFu;
+			const bool gone = q >= endq;
+			const bool cut = is_m && (q + 2u > endq || (brings && q + 2u == endq) || (lng && nib == 0xFu && q + 2u + (brings ? 1u : 0u) >= endq));   // :64 / :92 / :97
+			const u64 ev = __ballot(act && (gone || cut || (lng && nib == 0xFu && !e1)));
+			const uint32_t first = ev ? ctz64(ev) : cntl;                // tokens j0 .. j0 + first - 1 are plain: literals and matches of up to 279 bytes
+			const bool plain = lane < first;
+			const uint32_t len = is_m ? (lng ? (e1 ? extb + 25u : nib + 10u) : (sym & 7u) + 3u) : 1u, off = (sym >> 3) + 1u;
+			const uint32_t l = plain ? len : 0u, incl = wave_incl_scan_add_u32(l);
+			const u64 opi = op + (incl - l);
+			const bool bad_off = plain && is_m && (u64)off > opi;                                   // :442
+			const bool bad_cap = plain && (is_m ? (u64)len > cap - opi : opi >= cap);               // :443 / :455
+			const u64 eb = __ballot(bad_off || bad_cap);
+			if (eb) {
+				const uint32_t e = ctz64(eb);
+				status = ((__ballot(bad_off) >> e) & 1u) ? -3 : -5; done = true; break;
+			}
+			if (plain) { mytok[tc + lane] = is_m ? ((len << 16) | off) : (0x80000000u | b0); }
+			tc += first;
+			op += first ? (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(first - 1u)) : 0u;
+			{	// the nibble state behind the plain tokens
+				const uint32_t pl = longs & (first < 32u ? (1u << first) - 1u : 0xFFFFFFFFu);
+				if (pl) {
+					const bool pend = have_half ^ (((uint32_t)__builtin_popcount(pl) & 1u) != 0);
+					if (pend) { half = (uint32_t)__builtin_amdgcn_readlane((int)hbn, (int)(31u - (uint32_t)__builtin_clz(pl))); }   // (the last long one brought it)
+					have_half = pend;
+				}
+			}
+			if (first == cntl) { ip = (uint32_t)__builtin_amdgcn_readlane((int)(q + (is_m ? 2u : 1u) + (brings ? 1u : 0u) + (e1 ? 1u : 0u)), (int)(cntl - 1u)); break; }
+			ip = (uint32_t)__builtin_amdgcn_readlane((int)q, (int)first);
+			if ((__ballot(gone) >> first) & 1u) {                        // :433-438: the input ends here: this flag and all behind it must be set
+				const uint32_t k = j0 + first;
+				status = (m >> k) == (0xFFFFFFFFu >> k) ? 0 : -3; done = true; break;
+			}
+			if ((__ballot(cut) >> first) & 1u) { status = -3; done = true; break; }
+			// a match with extra length bytes, by all lanes as one (READ_SYMBOL :62-107)
+			const uint32_t sy = (uint32_t)__builtin_amdgcn_readlane((int)sym, (int)first);
+			const uint32_t loff = (sy >> 3) + 1u;
+			uint32_t used = 2u, ll;
+			if (have_half) { ll = half >> 4; have_half = false; }
+			else if (ip + used == endq) { status = -3; done = true; break; }
+			else { half = rb(ip + 2u); used = 3u; have_half = true; ll = half & 0xFu; }
+			if (ll == 0xFu) {
+				if (ip + used == endq) { status = -3; done = true; break; }
+				ll = rb(ip + used); ++used;
+				if (ll == 0xFFu) {
+					if (ip + used + 2u > endq) { status = -3; done = true; break; }
+					ll = rb(ip + used) | (rb(ip + used + 1u) << 8); used += 2u;
+					if (ll == 0) {
+						if (ip + used + 4u > endq) { status = -3; done = true; break; }
+						ll = rb(ip + used) | (rb(ip + used + 1u) << 8) | (rb(ip + used + 2u) << 16) | (rb(ip + used + 3u) << 24); used += 4u;
+					}
+					if (ll < 0xFu + 0x7u) { status = -3; done = true; break; }
+					ll -= 0xFu + 0x7u;
+				}
+				ll += 0xFu;
+			}
+			ll += 0x7u + 0x3u;
+			if ((u64)loff > op) { status = -3; done = true; break; }     // :442
+			if ((u64)ll > cap - op) { status = -5; done = true; break; } // :443
+			const uint32_t np = ll / LZT_MAXLEN + (ll % LZT_MAXLEN ? 1u : 0u);    // pieces with the same offset copy the same bytes
+			for (uint32_t k = lane; k < np; k += 64u) { mytok[tc + k] = ((k + 1u == np ? ll - (np - 1u) * LZT_MAXLEN : LZT_MAXLEN) << 16) | loff; }
+			tc += np; op += ll; ip += used;
+			j0 += first + 1u;
+		}
+	}
+	#undef XPT_BLOCK
+	if (lane == 0) { d_status[u] = status; d_out_len[u] = status == 0 ? op : 0; ntok[u] = status == 0 ? tc : 0; }
+}
+
+void launch_xpress_decompress_tokens(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
+                                     uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase);
+
 // ===================================================================================================================
 // Xpress+Huffman: one wave per buffer
 // ===================================================================================================================
@@ -728,7 +883,6 @@ void launch_xpress_decompress(hipStream_t st, const uint8_t* d_in, const BatchTa
 // keeps 7 KiB of LDS: 23 buffers per CU instead of the 2 that a 64 KiB output window allows. The bytes are produced afterwards
 // by lz_copy_kernel, in parallel.
 #define XHD_INB  2048u
-#define LZT_MAXLEN 32766u
 struct XhdLds {
 	__attribute__((aligned(16))) uint8_t in[2u * XHD_INB];
 	uint16_t fast[512];                 // 9-bit prefix -> symbol << 4 | length (0: longer code)
@@ -1137,13 +1291,13 @@ struct LzcLds { __attribute__((aligned(16))) uint8_t win[LZC_W + 64]; uint32_t i
 
 __global__ __launch_bounds__(64) void lz_copy_kernel(BatchTables bt, const u64* __restrict__ tok_prefix, const uint32_t* __restrict__ tok,
                                                     const u64* __restrict__ ntok, const u64* __restrict__ d_out_len, const int32_t* __restrict__ d_status,
-                                                    uint8_t* __restrict__ d_out)
+                                                    uint8_t* __restrict__ d_out, uint32_t lzb_min)
 {
 	__shared__ LzcLds L;
 	const uint32_t lane = threadIdx.x, u = blockIdx.x;
 	if (d_status[u] != 0) { return; }
 	const u64 total = d_out_len[u], nt = ntok[u];
-	if (total >= (256u << 10)) { return; }                               // large units: lz_copy_block_kernel
+	if (total >= lzb_min) { return; }                                    // larger units: lz_copy_block_kernel
 	const uint32_t* __restrict__ mytok = tok + tok_prefix[u];
 	uint8_t* dst = d_out + bt.out_off[u];
 	u64 t = 0, tpos = 0;                                                 // next token to place, its output offset
@@ -1222,12 +1376,17 @@ __global__ __launch_bounds__(64) void lz_copy_kernel(BatchTables bt, const u64* 
 // match offset back -- in the last 64 KiB of output, kept in an LDS ring (offsets reach at most 65535 back: resolved), or inside the tile
 // (a pointer); pointers are then jumped (ptr = ptr[ptr], at most 13 rounds, usually 2-4) until every byte has its value. One word per byte
 // holds "value" or "pointer", so a racing read sees one or the other, both of which are right.
+#define LZB_MIN_KB 32                                             // (a wave per unit, lz_copy_kernel, takes 3.8 ms for a 64 KiB unit; the block 57 us: 3 239 units 4.0 -> 1.6 ms)
 #define LZB_T    8192u
 #ifndef LZB_NT
 #define LZB_NT   1024u
 #endif
 #define LZB_RING 73728u                                            // 65536 + LZB_T, a multiple of LZB_T: a tile never wraps
-#define LZB_MIN  (256u << 10)                                      // units with at least this much output take the block kernel
+static uint32_t lzb_min_bytes()                                    // units with at least this much output take the block kernel (MSCOMP_AMD_LZB_MIN_KB overrides, for measurements)
+{
+	static const uint32_t v = [] { const char* e = getenv("MSCOMP_AMD_LZB_MIN_KB"); const long k = e ? atol(e) : 0; return (uint32_t)((k > 0 && k < (1 << 20) ? k : LZB_MIN_KB) << 10); }();
+	return v;
+}
 struct LzbLds {
 	__attribute__((aligned(16))) uint8_t ring[LZB_RING];
 	uint32_t info[LZB_T];                                          // token word at its start position; later: 0x80000000 | value, or the in-tile source
@@ -1249,14 +1408,14 @@ extern "C" void mscomp_amd_debug_lzb_prof(unsigned long long* out) { (void)hipMe
 #endif
 __global__ __launch_bounds__(LZB_NT) void lz_copy_block_kernel(BatchTables bt, const u64* __restrict__ tok_prefix, const uint32_t* __restrict__ tok,
                                                               const u64* __restrict__ ntok, const u64* __restrict__ d_out_len, const int32_t* __restrict__ d_status,
-                                                              uint8_t* __restrict__ d_out)
+                                                              uint8_t* __restrict__ d_out, uint32_t lzb_min)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lzb_smem[];
 	LzbLds& L = *reinterpret_cast<LzbLds*>(lzb_smem);
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, u = blockIdx.x;
 	if (d_status[u] != 0) { return; }
 	const u64 total = d_out_len[u], nt = ntok[u];
-	if (total < LZB_MIN) { return; }
+	if (total < lzb_min) { return; }
 	const uint32_t* __restrict__ mytok = tok + tok_prefix[u];
 	uint8_t* __restrict__ dst = d_out + bt.out_off[u];
 	u64 t = 0, tpos = 0;                                             // next token to place, its output offset (uniform)
@@ -1422,11 +1581,22 @@ void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const Ba
 	default: {
 		static bool attr_set = false;
 		if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_copy_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzbLds)); attr_set = true; }
-		hipLaunchKernelGGL(lz_copy_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out);
-		hipLaunchKernelGGL(lz_copy_block_kernel, dim3(bt.n_units), dim3(LZB_NT), sizeof(LzbLds), st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out);
+		hipLaunchKernelGGL(lz_copy_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes());
+		hipLaunchKernelGGL(lz_copy_block_kernel, dim3(bt.n_units), dim3(LZB_NT), sizeof(LzbLds), st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes());
 		break;
 	}
 	}
+}
+
+void launch_xpress_decompress_tokens(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
+                                     uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase)
+{
+	if (bt.n_units == 0) { return; }
+	if (phase == 0) { hipLaunchKernelGGL(xpt_parse_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, tok_prefix, tok, ntok, d_out_len, d_status); return; }
+	static bool attr_set = false;
+	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_copy_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzbLds)); attr_set = true; }
+	if (phase == 1) { hipLaunchKernelGGL(lz_copy_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes()); }
+	else { hipLaunchKernelGGL(lz_copy_block_kernel, dim3(bt.n_units), dim3(LZB_NT), sizeof(LzbLds), st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes()); }
 }
 
 } // namespace msc

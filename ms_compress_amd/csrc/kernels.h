@@ -63,6 +63,9 @@ void launch_lzd_finalize(hipStream_t st, const BatchTables& bt, const LzdBufs& b
 
 // Xpress: one wave per stream
 void launch_xpress_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* d_out, u64* d_out_len, int32_t* d_status);
+// the same through 32-bit tokens: phase 0 = xpt_parse_kernel (a flag word at a time), 1 = lz_copy_kernel, 2 = lz_copy_block_kernel
+void launch_xpress_decompress_tokens(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
+                                     uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase);
 
 // Xpress+Huffman, in phases: 0 mark candidate chunk starts, 1 walk every candidate as one chunk, 2 chain check per buffer, 3 tokens of the
 // accepted chunks, 4 serial walk of the buffers the speculation could not do, 5 tokens -> bytes. tok_prefix[u] = first token slot of unit u,

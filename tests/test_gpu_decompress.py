@@ -153,3 +153,57 @@ def test_one_shot_lznt1_with_a_very_generous_capacity(oracle, gpu_ctx):
     out = C.create_string_buffer(len(data) + 16)
     n = C.c_size_t(1 << 40)                                          # "a terabyte of room" (the buffer behind it is only as large as needed)
     assert lib.ms_decompress(2, comp, len(comp), out, C.byref(n)) == 0 and n.value == len(data) and out.raw[: len(data)] == data
+
+
+def _dense_matches(rnd, n):
+    """bytes whose Xpress stream is packed with matches of every length form: 3-9 (in the symbol), 10-24 (shared nibble), 25-279 (+ a byte),
+    280-65557 (+ 16 bits) and longer (+ 32 bits), a few literals between them"""
+    out = bytearray(rnd.randbytes(40))
+    while len(out) < n:
+        if rnd.random() < 0.25:
+            out += rnd.randbytes(rnd.randint(1, 4))
+        form = 4 if (n >= 100000 and rnd.random() < 0.02) else rnd.choice((0, 0, 1, 1, 1, 2, 2, 3))
+        ln = (rnd.randint(3, 9), rnd.randint(10, 24), rnd.randint(25, 279), rnd.randint(280, 3000), rnd.randint(65558, 70000))[form]
+        off = rnd.randint(1, min(len(out), 8192))
+        for _ in range(ln):
+            out.append(out[-off])
+    return bytes(out)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_xpress_length_forms_truncations_and_corruptions(oracle, gpu_ctx, mode):
+    """The token-parallel Xpress parser (mode 0: 32 tokens of a flag word at a time, the positions behind nibble-bearing matches by iteration)
+    and the token-at-a-time kernel (mode 1) on streams dense with long matches: valid (exact, short and generous capacities), EVERY prefix of
+    one stream (each way the input can end inside a token), and random corruptions -- status and bytes against the checker."""
+    import random
+    import ms_compress_amd as m
+    rnd = random.Random(77)
+    datas = [_dense_matches(rnd, rnd.choice((300, 2000, 20000))) for _ in range(24)] + [_dense_matches(rnd, 200000)]
+    comps = [oracle.oracle_compress(3, d)[1] for d in datas]
+    streams = []
+    for d, c in zip(datas, comps):
+        streams += [(c, len(d)), (c, len(d) + 7), (c, len(d) - 1), (c, len(d) // 2)]
+    d0, c0 = datas[2], comps[2]
+    streams += [(c0[:k], len(d0)) for k in range(len(c0))]
+    for d, c in zip(datas[:12], comps[:12]):
+        for _ in range(25):
+            b = bytearray(c)
+            for _ in range(rnd.randint(1, 3)):
+                b[rnd.randrange(len(b))] = rnd.randrange(256)
+            streams.append((bytes(b), len(d) + rnd.choice((0, 0, 100, 70000))))
+    gpu_ctx.lib.mscomp_amd_debug_set_xpress_decoder(mode)
+    try:
+        outs, sts = m.decompress_units(3, [s for s, _ in streams], [c for _, c in streams], ctx=gpu_ctx)
+    finally:
+        gpu_ctx.lib.mscomp_amd_debug_set_xpress_decoder(0)
+    n_ok = n_err = 0
+    for (stream, cap), out, st in zip(streams, outs, sts):
+        so, oo, undefined = oracle.oracle_decompress_ex(3, stream, cap)
+        assert not undefined
+        assert st == so, (len(stream), cap, st, so)
+        if so == 0:
+            assert out == oo, (len(stream), cap)
+            n_ok += 1
+        else:
+            n_err += 1
+    assert n_ok > 100 and n_err > 300
