@@ -58,6 +58,7 @@ struct mscomp_amd_ctx {
 	DevBuf tokbits, counts, extra, lens, codes, fb_list, fbflag;   // Xpress+Huffman per-chunk scratch
 	DevBuf dz_cin, dz_csize, dz_unit;                  // LZNT1 decompression: header offset / decoded size per chunk slot, per-unit records
 	DevBuf dz_tok, dz_ntok, dz_xhc;                    // Xpress+Huffman decompression: 32-bit tokens of every unit, token counts, candidate chunk records
+	DevBuf lzg_bsum, lzg_dir, lzg_words;               // tokens -> bytes of large units by all CUs (lzglobal.hip): token block sums, tile directory, a word per output byte + pass counters
 	DevBuf cp_tab;                                     // compaction: out_off (u64) | tile_prefix (u32) of the batch being packed
 	DevBuf one_in, one_out, one_meta;                  // staging of the host-pointer one-shot path
 	uint64_t epoch = 1;                                // bumped when one of the buffers above moves (captured graphs are stale then)
@@ -68,7 +69,7 @@ struct mscomp_amd_ctx {
 	{
 		return { &slots, &slot_size, &prefix, &tile_sums, &links, &lasthead, &mlen3, &moff, &wtok, &wmat, &wfar, &wrec, &sbrec,
 		         &tokbits, &counts, &extra, &lens, &codes, &fb_list, &fbflag, &dz_cin, &dz_csize, &dz_unit, &dz_tok, &dz_ntok, &dz_xhc,
-		         &cp_tab, &one_in, &one_out, &one_meta };
+		         &lzg_bsum, &lzg_dir, &lzg_words, &cp_tab, &one_in, &one_out, &one_meta };
 	}
 	mscomp_amd_ctx() { for (DevBuf* b : bufs()) { b->epoch = &epoch; } }
 };
@@ -83,6 +84,9 @@ struct mscomp_amd_plan {
 	DevBuf tables;                                     // in_off | out_off | chunk_prefix
 	DevBuf tokpre;                                     // decompression by tokens: first token slot | first candidate slot of every unit (2 x (n_units + 1) u64)
 	uint32_t xhc_slots = 0;                            // candidate chunk slots of the batch
+	DevBuf lzg_tab;                                    // lzglobal.hip: unit (u32 x n_big, padded) | tb_prefix | tile_prefix | word_prefix (u64 x (n_big + 1) each)
+	uint32_t lzg_big = 0, lzg_tb = 0, lzg_tiles = 0;   // units taken by that path (0: not used), their token blocks and tiles
+	uint64_t lzg_words = 0;
 	BatchTables bt{};
 	// the launch sequence of plan_execute as a hipGraph: captured on the plan's second execution, replayed while the
 	// arguments and the scratch buffers stay where they were
@@ -298,7 +302,35 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 			if (okd && (hipMemcpyAsync(p->tokpre.p, tp.data(), tp.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
 			            hipStreamSynchronize(c->stream) != hipSuccess)) { p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_ERRNO; }
 		}
-		if (!okd) { p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_MEM_ERROR; }
+		if (okd && (format == MSCOMP_XPRESS || format == MSCOMP_XPRESS_HUFF)) {
+			// units with room for LZG_MIN_CAP bytes or more get their bytes from all CUs (lzglobal.hip): 4 bytes of scratch per byte of capacity;
+			// when that is more than the budget (MSCOMP_AMD_LZG_MAX_MB, default 16 GiB; 0 switches the path off) the block-per-unit kernel takes them
+			static const uint64_t budget = [] { const char* e = getenv("MSCOMP_AMD_LZG_MAX_MB"); const long long v = e ? atoll(e) : 16384; return (uint64_t)(v < 0 ? 0 : v) << 20; }();
+			std::vector<uint32_t> big;
+			uint64_t words = 0;
+			for (size_t i = 0; i < n_units; ++i) { if (out_cap[i] >= LZG_MIN_CAP && out_cap[i] < 0xFFFFFF00ull) { big.push_back((uint32_t)i); words += out_cap[i] + 64; } }
+			if (!big.empty() && words * 4 <= budget) {
+				const size_t nb = big.size(), upad = (nb + 1) / 2;              // the unit list in whole u64 slots
+				std::vector<uint64_t> tab(upad + 3 * (nb + 1));
+				memcpy(tab.data(), big.data(), nb * 4);
+				uint64_t* tbp = tab.data() + upad; uint64_t* tlp = tbp + nb + 1; uint64_t* wdp = tlp + nb + 1;
+				uint64_t tb = 0, tl = 0, wd = 0;
+				for (size_t k = 0; k < nb; ++k) {
+					const size_t i = big[k];
+					const uint64_t by_in = (format == MSCOMP_XPRESS ? 1 : 8) * in_len[i] + out_cap[i] / 32766u + 1, cnt = (out_cap[i] < by_in ? out_cap[i] : by_in) + 64;   // (the unit's token slots, as above)
+					tbp[k] = tb; tlp[k] = tl; wdp[k] = wd;
+					tb += (cnt + 8191) / 8192; tl += (out_cap[i] + 8191) / 8192; wd += out_cap[i] + 64;
+				}
+				tbp[nb] = tb; tlp[nb] = tl; wdp[nb] = wd;
+				if (tb < 0x7FFFFFF0ull && tl < 0x7FFFFFF0ull) {
+					okd = p->lzg_tab.reserve(tab.size() * 8) && c->lzg_bsum.reserve(tb * 8 + 64) && c->lzg_dir.reserve(tl * 8 + 64) && c->lzg_words.reserve(wd * 4 + LZG_PASSES * 4 + 64);
+					if (okd && (hipMemcpyAsync(p->lzg_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+					            hipStreamSynchronize(c->stream) != hipSuccess)) { p->lzg_tab.release(); p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_ERRNO; }
+					if (okd) { p->lzg_big = (uint32_t)nb; p->lzg_tb = (uint32_t)tb; p->lzg_tiles = (uint32_t)tl; p->lzg_words = wd; }
+				}
+			}
+		}
+		if (!okd) { p->lzg_tab.release(); p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_MEM_ERROR; }
 		*out = p;
 		return MSCOMP_OK;
 	}
@@ -345,8 +377,31 @@ void mscomp_amd_plan_destroy(mscomp_amd_plan* p)
 	DeviceGuard g(p->ctx->device);
 	(void)hipStreamSynchronize(p->ctx->stream);
 	if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); }
-	p->tables.release(); p->tokpre.release();
+	p->tables.release(); p->tokpre.release(); p->lzg_tab.release();
 	delete p;
+}
+
+static LzgTables lzg_tables(const mscomp_amd_plan* p, mscomp_amd_ctx* c)
+{
+	LzgTables g = {};
+	g.n_big = p->lzg_big; g.n_tb = p->lzg_tb; g.n_tiles = p->lzg_tiles;
+	if (!g.n_big) { return g; }
+	const size_t nb = g.n_big, upad = (nb + 1) / 2;
+	const uint64_t* t = static_cast<const uint64_t*>(p->lzg_tab.p);
+	g.unit = reinterpret_cast<const uint32_t*>(t); g.tb_prefix = t + upad; g.tile_prefix = g.tb_prefix + nb + 1; g.word_prefix = g.tile_prefix + nb + 1;
+	g.bsum = static_cast<u64*>(c->lzg_bsum.p);
+	g.dir_tok = static_cast<uint32_t*>(c->lzg_dir.p); g.dir_pos = g.dir_tok + p->lzg_tiles;
+	g.words = static_cast<uint32_t*>(c->lzg_words.p); g.open = g.words + p->lzg_words;
+	return g;
+}
+// the last stage of Xpress / Xpress+Huffman decompression: tokens -> bytes (a wave per small unit, a block per middle one, all CUs for the large ones)
+static void run_lz_copy_global(mscomp_amd_ctx* c, const mscomp_amd_plan* p, hipStream_t st, const u64* tp, const uint32_t* tok, const u64* ntok,
+                               const u64* d_out_len, const int32_t* d_status, uint8_t* d_out)
+{
+	if (!p->lzg_big) { return; }
+	const LzgTables g = lzg_tables(p, c);
+	static const char* const names[3] = {"lzg_dir_kernels", "lzg_expand_kernel", "lzg_jump_kernel"};
+	for (int ph = 0; ph < 3; ++ph) { KernelTimer t(c, names[ph]); launch_lz_copy_global(st, g, p->bt, tp, tok, ntok, d_out_len, d_status, d_out, ph); }
 }
 
 static XpressWinBufs xpress_win_bufs(mscomp_amd_ctx* c, uint32_t n_chunks)
@@ -396,7 +451,9 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 			if (g_xpd_mode.load(std::memory_order_relaxed) == 1) { KernelTimer t(c, "xpd_kernel"); launch_xpress_decompress(st, d_in, p->bt, d_out, d_out_len, d_status); return MSCOMP_OK; }
 			const u64* tp = static_cast<const u64*>(p->tokpre.p); uint32_t* tok = static_cast<uint32_t*>(c->dz_tok.p); u64* ntok = static_cast<u64*>(c->dz_ntok.p);
 			static const char* const names[3] = {"xpt_parse_kernel", "lz_copy_kernel", "lz_copy_block_kernel"};
-			for (int ph = 0; ph < 3; ++ph) { KernelTimer t(c, names[ph]); launch_xpress_decompress_tokens(st, d_in, p->bt, tp, tok, ntok, d_out, d_out_len, d_status, ph); }
+			const u64 gmin = p->lzg_big ? (u64)LZG_MIN_CAP : ~(u64)0;
+			for (int ph = 0; ph < 3; ++ph) { KernelTimer t(c, names[ph]); launch_xpress_decompress_tokens(st, d_in, p->bt, tp, tok, ntok, d_out, d_out_len, d_status, ph, gmin); }
+			run_lz_copy_global(c, p, st, tp, tok, ntok, d_out_len, d_status, d_out);
 			return MSCOMP_OK;
 		}
 		case MSCOMP_XPRESS_HUFF: {
@@ -414,8 +471,9 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 			static const char* const names[6] = { "xhc_mark_kernel", "xhc_parse_kernel", "xhc_chain_kernel", "xhc_parse2_kernel", "xhd_parse_kernel", "lz_copy_kernel" };
 			for (int ph = 0; ph < 6; ++ph) {
 				KernelTimer t(c, names[ph]);
-				launch_xpress_huff_decompress(st, d_in, p->bt, tp, tok, ntok, cp, p->xhc_slots, xb, d_out, d_out_len, d_status, ph);
+				launch_xpress_huff_decompress(st, d_in, p->bt, tp, tok, ntok, cp, p->xhc_slots, xb, d_out, d_out_len, d_status, ph, p->lzg_big ? (u64)LZG_MIN_CAP : ~(u64)0);
 			}
+			run_lz_copy_global(c, p, st, tp, tok, ntok, d_out_len, d_status, d_out);
 			return MSCOMP_OK;
 		}
 		default:

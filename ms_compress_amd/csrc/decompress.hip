@@ -868,7 +868,7 @@ __global__ __launch_bounds__(64) void xpt_parse_kernel(const uint8_t* __restrict
 }
 
 void launch_xpress_decompress_tokens(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
-                                     uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase);
+                                     uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase, u64 lzg_min_cap);
 
 // ===================================================================================================================
 // Xpress+Huffman: one wave per buffer
@@ -1098,8 +1098,8 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 	uint32_t* __restrict__ mytok = tok + tok_prefix[u] + tok_at;
 	const u64 tokcap = tok_prefix[u + 1] - tok_prefix[u] - tok_at;      // chunk 0 writes before the capacity is judged: never beyond the unit's slots
 	u64 reach = 0;
-	u64 nt = 0; uint32_t ns = 0, treg = 0;                               // tokens in HBM; tokens staged: token k of the batch waits in lane k
-	#define XHD_EMIT(w) { treg = lane == ns ? (w) : treg; ++ns; if (ns == 64u) { if (writing && nt + 64u <= tokcap) { mytok[nt + lane] = treg; } nt += 64u; ns = 0; } }
+	u64 nt = 0;                                                          // tokens so far
+	#define XHD_EMIT(w) { if (writing && lane == 0 && nt < tokcap) { mytok[nt] = (w); } ++nt; }
 	int32_t status = 1; u64 op = 0;                                      // 1 = running
 	// ---- input ring (see xpd_kernel) ----
 	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
@@ -1181,6 +1181,65 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 			// (:87) -- possibly to the end of the buffer. A candidate is not followed there: it counts as "not a chunk", and a buffer
 			// whose chain does not close without it goes to the serial walk, which follows the reference to the letter.
 			if (!writing && prod >= 65536u) { status = -3; break; }
+			if (prod < 65536u && bits >= 16u && endq - ip >= 16u) {
+				// ---- many symbols per step: lane b decodes the symbol that would start b bits from here (the code through the same tables, a match's
+				// offset bits behind it); the symbols that really follow each other are then a walk b -> b + bits taken from lane 0, by readlane.
+				// Stops in front of a match with length bytes (they sit in the byte stream, where the next 16 bits would be pulled from: the
+				// symbol-at-a-time code below takes that one) and in front of anything invalid; the bit buffer is rebuilt as Bitstream.h would hold it.
+				XHD_NEED(ip, 16u)
+				uint32_t d0, d1, d2;                                       // bytes ip .. ip + 11: six 16-bit words, each the next 16 bits of the stream
+				{
+					const uint32_t* in32 = reinterpret_cast<const uint32_t*>(S.in);
+					const uint32_t i_ = (ip >> 2) & (2u * XHD_INB / 4u - 1u), sh_ = ip & 3u, M_ = 2u * XHD_INB / 4u - 1u;
+					const uint32_t a_ = in32[i_], b_ = in32[(i_ + 1u) & M_], c_ = in32[(i_ + 2u) & M_], e_ = in32[(i_ + 3u) & M_];
+					d0 = __builtin_amdgcn_alignbyte(b_, a_, sh_); d1 = __builtin_amdgcn_alignbyte(c_, b_, sh_); d2 = __builtin_amdgcn_alignbyte(e_, c_, sh_);
+				}
+				#define XHD_SWAP16(x) (((x) << 16) | ((x) >> 16))              /* word k of the stream first: (w0 << 16) | w1 */
+				const u64 t0 = ((u64)XHD_SWAP16(d0) << 32) | XHD_SWAP16(d1), t1 = (u64)XHD_SWAP16(d2) << 32;
+				#undef XHD_SWAP16
+				const u64 s_hi = ((u64)mask << 32) | (t0 >> bits), s_lo = (t0 << (64u - bits)) | (t1 >> bits);   // the next 128 bits of the stream (bits + 96 of them real)
+				const uint32_t view = (uint32_t)((lane ? (s_hi << lane) | (s_lo >> (64u - lane)) : s_hi) >> 32);
+				const uint32_t x15 = view >> 17;
+				const uint32_t f = S.fast[x15 >> 6];
+				uint32_t n, sy;
+				if (f) { n = f & 0xFu; sy = f >> 4; }
+				else { n = 1; while (x15 >= S.lims[n]) { ++n; } const uint32_t s_ = S.poss[n] + ((x15 - S.lims[n - 1u]) >> (15u - n)); sy = s_ >= 512u ? 0xFFFFu : S.syms[s_]; }
+				const bool lit = sy < 0x100u, mat = !lit && sy != 0xFFFFu;
+				const uint32_t ob = (sy >> 4) & 0xFu;
+				const uint32_t cons = n + (mat ? ob : 0u);
+				const uint32_t moff = ob ? ((view << n) >> (32u - ob)) + (1u << ob) : 1u;
+				const uint32_t mlen = lit ? 1u : (sy & 0xFu) + 3u;
+				const bool evl = !lit && (!mat || (sy & 0xFu) == 0xFu);
+				const u64 evm = __ballot(evl);
+				const uint32_t step = evl ? 64u : cons;                      // (the walk ends on a symbol it must not take, which is then dropped again)
+				u64 mark = 0; uint32_t b = 0;
+				while (b < 64u) { mark |= (u64)1 << b; b += (uint32_t)__builtin_amdgcn_readlane((int)step, (int)b); }
+				if (mark & evm) { b = ctz64(mark & evm); mark &= ~evm; }
+				bool on = (mark >> lane) & 1u;
+				const uint32_t l = on ? mlen : 0u, incl = wave_incl_scan_add_u32(l), before = incl - l;
+				const u64 over = __ballot(on && prod + before >= 65536u);                    // the chunk is full in front of this symbol: the loop condition decides there
+				if (over) { const uint32_t sl = ctz64(over); mark &= ((u64)1 << sl) - 1u; b = sl; on = (mark >> lane) & 1u; }
+				if (mark) {
+					const uint32_t lastl = 63u - (uint32_t)__builtin_clzll(mark);
+					const uint32_t adv = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)lastl);
+					const u64 opi = op + before;
+					const uint32_t rch = (on && mat && (u64)moff > opi) ? (uint32_t)((u64)moff - opi) : 0u;    // how far the match reaches in front of the chunk (offsets are below 65536 + 32768)
+					const uint32_t rmax = wave_max_u32(rch);
+					if (rmax > reach) { reach = rmax; }
+					const u64 ti = nt + popc_below(mark);
+					if (writing && on && ti < tokcap) { mytok[ti] = lit ? (0x80000000u | sy) : (moff | (mlen << 16)); }
+					nt += (uint32_t)__builtin_popcountll(mark);
+					op += adv; prod += adv;
+					// Bitstream.h:61-75: a word is pulled whenever fewer than 16 bits are left
+					const int32_t avail = (int32_t)bits - (int32_t)b;
+					const uint32_t pulls = avail < 16 ? (uint32_t)(16 - avail + 15) >> 4 : 0u;
+					const uint32_t nb = (uint32_t)(avail + 16 * (int32_t)pulls);
+					const u64 x64 = b == 0 ? s_hi : (b < 64u ? (s_hi << b) | (s_lo >> (64u - b)) : s_lo << (b - 64u));
+					mask = (uint32_t)(x64 >> 32) & (nb >= 32u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> nb));
+					bits = nb; ip += 2u * pulls;
+					continue;
+				}
+			}
 			uint32_t sym;
 			XHD_DECODE(sym)
 			if (sym < 0x100u) {
@@ -1233,10 +1292,9 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 	#undef XHD_SKIP
 	#undef XHD_MASK_ZERO
 	#undef XHD_DECODE
-	if (writing && lane < ns && nt + ns <= tokcap) { mytok[nt + lane] = treg; }
 	#undef XHD_EMIT
 	if (PASS == 1 && lane == 0) {
-		xb.res_state[slot] = status == 1 ? state : 2u; xb.res_end[slot] = next_at; xb.res_prod[slot] = op; xb.res_ntok[slot] = nt + ns;
+		xb.res_state[slot] = status == 1 ? state : 2u; xb.res_end[slot] = next_at; xb.res_prod[slot] = op; xb.res_ntok[slot] = nt;
 		xb.res_reach[slot] = reach > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)reach;
 	}
 }
@@ -1291,11 +1349,11 @@ struct LzcLds { __attribute__((aligned(16))) uint8_t win[LZC_W + 64]; uint32_t i
 
 __global__ __launch_bounds__(64) void lz_copy_kernel(BatchTables bt, const u64* __restrict__ tok_prefix, const uint32_t* __restrict__ tok,
                                                     const u64* __restrict__ ntok, const u64* __restrict__ d_out_len, const int32_t* __restrict__ d_status,
-                                                    uint8_t* __restrict__ d_out, uint32_t lzb_min)
+                                                    uint8_t* __restrict__ d_out, uint32_t lzb_min, u64 lzg_min_cap)
 {
 	__shared__ LzcLds L;
 	const uint32_t lane = threadIdx.x, u = blockIdx.x;
-	if (d_status[u] != 0) { return; }
+	if (d_status[u] != 0 || bt.out_cap[u] >= lzg_min_cap) { return; }   // (units with that much room: lzglobal.hip)
 	const u64 total = d_out_len[u], nt = ntok[u];
 	if (total >= lzb_min) { return; }                                    // larger units: lz_copy_block_kernel
 	const uint32_t* __restrict__ mytok = tok + tok_prefix[u];
@@ -1408,12 +1466,12 @@ extern "C" void mscomp_amd_debug_lzb_prof(unsigned long long* out) { (void)hipMe
 #endif
 __global__ __launch_bounds__(LZB_NT) void lz_copy_block_kernel(BatchTables bt, const u64* __restrict__ tok_prefix, const uint32_t* __restrict__ tok,
                                                               const u64* __restrict__ ntok, const u64* __restrict__ d_out_len, const int32_t* __restrict__ d_status,
-                                                              uint8_t* __restrict__ d_out, uint32_t lzb_min)
+                                                              uint8_t* __restrict__ d_out, uint32_t lzb_min, u64 lzg_min_cap)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lzb_smem[];
 	LzbLds& L = *reinterpret_cast<LzbLds*>(lzb_smem);
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6, u = blockIdx.x;
-	if (d_status[u] != 0) { return; }
+	if (d_status[u] != 0 || bt.out_cap[u] >= lzg_min_cap) { return; }   // (units with that much room: lzglobal.hip)
 	const u64 total = d_out_len[u], nt = ntok[u];
 	if (total < lzb_min) { return; }
 	const uint32_t* __restrict__ mytok = tok + tok_prefix[u];
@@ -1568,7 +1626,7 @@ __global__ __launch_bounds__(LZB_NT) void lz_copy_block_kernel(BatchTables bt, c
 
 void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
                                    const u64* cand_prefix, uint32_t n_slots, const XhcBufs& xb,
-                                   uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase)
+                                   uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase, u64 lzg_min_cap)
 {
 	if (bt.n_units == 0) { return; }
 	switch (phase) {
@@ -1581,22 +1639,22 @@ void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const Ba
 	default: {
 		static bool attr_set = false;
 		if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_copy_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzbLds)); attr_set = true; }
-		hipLaunchKernelGGL(lz_copy_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes());
-		hipLaunchKernelGGL(lz_copy_block_kernel, dim3(bt.n_units), dim3(LZB_NT), sizeof(LzbLds), st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes());
+		hipLaunchKernelGGL(lz_copy_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes(), lzg_min_cap);
+		hipLaunchKernelGGL(lz_copy_block_kernel, dim3(bt.n_units), dim3(LZB_NT), sizeof(LzbLds), st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes(), lzg_min_cap);
 		break;
 	}
 	}
 }
 
 void launch_xpress_decompress_tokens(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
-                                     uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase)
+                                     uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase, u64 lzg_min_cap)
 {
 	if (bt.n_units == 0) { return; }
 	if (phase == 0) { hipLaunchKernelGGL(xpt_parse_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, tok_prefix, tok, ntok, d_out_len, d_status); return; }
 	static bool attr_set = false;
 	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_copy_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzbLds)); attr_set = true; }
-	if (phase == 1) { hipLaunchKernelGGL(lz_copy_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes()); }
-	else { hipLaunchKernelGGL(lz_copy_block_kernel, dim3(bt.n_units), dim3(LZB_NT), sizeof(LzbLds), st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes()); }
+	if (phase == 1) { hipLaunchKernelGGL(lz_copy_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes(), lzg_min_cap); }
+	else { hipLaunchKernelGGL(lz_copy_block_kernel, dim3(bt.n_units), dim3(LZB_NT), sizeof(LzbLds), st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes(), lzg_min_cap); }
 }
 
 } // namespace msc

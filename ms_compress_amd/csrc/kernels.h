@@ -65,7 +65,7 @@ void launch_lzd_finalize(hipStream_t st, const BatchTables& bt, const LzdBufs& b
 void launch_xpress_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* d_out, u64* d_out_len, int32_t* d_status);
 // the same through 32-bit tokens: phase 0 = xpt_parse_kernel (a flag word at a time), 1 = lz_copy_kernel, 2 = lz_copy_block_kernel
 void launch_xpress_decompress_tokens(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
-                                     uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase);
+                                     uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase, u64 lzg_min_cap);
 
 // Xpress+Huffman, in phases: 0 mark candidate chunk starts, 1 walk every candidate as one chunk, 2 chain check per buffer, 3 tokens of the
 // accepted chunks, 4 serial walk of the buffers the speculation could not do, 5 tokens -> bytes. tok_prefix[u] = first token slot of unit u,
@@ -76,7 +76,26 @@ struct XhcBufs { uint32_t* cand_cnt; uint32_t* mode; uint32_t* cand_pos; uint32_
                  u64* res_prod; u64* res_ntok; u64* tok_off; };
 void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
                                    const u64* cand_prefix, uint32_t n_slots, const XhcBufs& xb,
-                                   uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase);
+                                   uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase, u64 lzg_min_cap);
+
+// ---- tokens -> bytes for large units by all CUs (lzglobal.hip) ----
+#define LZG_PASSES 33u                                    // pointer passes launched (chains halve at least: 2^32 bytes); a pass returns at once when the one before left nothing open
+#define LZG_MIN_CAP (1u << 20)                            // units with at least this much output capacity take this path (when the plan has the scratch for it)
+struct LzgTables {
+	const uint32_t* unit;          // n_big: the units taken
+	const u64* tb_prefix;          // n_big + 1: first token block (8192 tokens) of each
+	const u64* tile_prefix;        // n_big + 1: first tile (8192 output bytes) of each
+	const u64* word_prefix;        // n_big + 1: first word of each in `words`
+	u64*      bsum;                // per token block: bytes its tokens give; then the bytes before it
+	uint32_t* dir_tok;             // per tile: the first token that starts in the tile or behind it ...
+	uint32_t* dir_pos;             // ... and where
+	uint32_t* words;               // per output byte: LZG_VAL | byte, or the index of its source
+	uint32_t* open;                // LZG_PASSES counters: words still pointing after each pass
+	uint32_t  n_big, n_tb, n_tiles;
+};
+// phase 0 = directory (3 kernels), 1 = lzg_expand_kernel, 2 = the pointer passes
+void launch_lz_copy_global(hipStream_t st, const LzgTables& g, const BatchTables& bt, const u64* tok_prefix, const uint32_t* tok, const u64* ntok,
+                           const u64* d_out_len, const int32_t* d_status, uint8_t* d_out, int phase);
 
 // ---- utilities (util.hip) ----
 // prefix[0..n] = exclusive scan of sizes[0..n) as u64 (prefix[n] = total). block_sums: scratch of ceil(n/1024)+1 u64.
