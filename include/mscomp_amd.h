@@ -203,6 +203,9 @@ int          mscomp_amd_get_lznt1_sa_dict(void);
 /* Test hook: Xpress decompression has two bit-identical paths: 0 = default (32-bit tokens, a flag word per step, then the copy kernels that
  * Xpress+Huffman uses), 1 = one wave per stream taking a token per step and moving the bytes itself (round 1's kernel). Process-wide. */
 void         mscomp_amd_debug_set_xpress_decoder(int mode);
+/* Test hook: after a decompression whose large units (capacity >= 1 MiB) got their bytes from csrc/lzglobal.hip: out[0..32] = words still
+ * pointing after each pointer pass (`words` = sum over those units of capacity + 64). 0 = read. */
+int          mscomp_amd_debug_lzg_open(mscomp_amd_ctx* ctx, uint64_t words, uint32_t* out);
 /* Test hook: the Xpress-family match finder evaluates every position (1 = default) or runs lazily (0: Find only where a greedy parse can
  * start a token, csrc/xlazy.hip; Xpress: units up to 64 KiB; exact but slower); the parse kernels get the same answers on
  * every path they walk. Process-wide. */

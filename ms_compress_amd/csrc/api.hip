@@ -319,11 +319,11 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 					const size_t i = big[k];
 					const uint64_t by_in = (format == MSCOMP_XPRESS ? 1 : 8) * in_len[i] + out_cap[i] / 32766u + 1, cnt = (out_cap[i] < by_in ? out_cap[i] : by_in) + 64;   // (the unit's token slots, as above)
 					tbp[k] = tb; tlp[k] = tl; wdp[k] = wd;
-					tb += (cnt + 8191) / 8192; tl += (out_cap[i] + 8191) / 8192; wd += out_cap[i] + 64;
+					tb += (cnt + 8191) / 8192; tl += (out_cap[i] + (1u << LZG_TILE_SHIFT) - 1) >> LZG_TILE_SHIFT; wd += out_cap[i] + 64;
 				}
 				tbp[nb] = tb; tlp[nb] = tl; wdp[nb] = wd;
 				if (tb < 0x7FFFFFF0ull && tl < 0x7FFFFFF0ull) {
-					okd = p->lzg_tab.reserve(tab.size() * 8) && c->lzg_bsum.reserve(tb * 8 + 64) && c->lzg_dir.reserve(tl * 8 + 64) && c->lzg_words.reserve(wd * 4 + LZG_PASSES * 4 + 64);
+					okd = p->lzg_tab.reserve(tab.size() * 8) && c->lzg_bsum.reserve(tb * 8 + 64) && c->lzg_dir.reserve(tl * 8 + 64) && c->lzg_words.reserve(wd * 4 + LZG_PASSES * 4 + tl + 64);
 					if (okd && (hipMemcpyAsync(p->lzg_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
 					            hipStreamSynchronize(c->stream) != hipSuccess)) { p->lzg_tab.release(); p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_ERRNO; }
 					if (okd) { p->lzg_big = (uint32_t)nb; p->lzg_tb = (uint32_t)tb; p->lzg_tiles = (uint32_t)tl; p->lzg_words = wd; }
@@ -391,7 +391,7 @@ static LzgTables lzg_tables(const mscomp_amd_plan* p, mscomp_amd_ctx* c)
 	g.unit = reinterpret_cast<const uint32_t*>(t); g.tb_prefix = t + upad; g.tile_prefix = g.tb_prefix + nb + 1; g.word_prefix = g.tile_prefix + nb + 1;
 	g.bsum = static_cast<u64*>(c->lzg_bsum.p);
 	g.dir_tok = static_cast<uint32_t*>(c->lzg_dir.p); g.dir_pos = g.dir_tok + p->lzg_tiles;
-	g.words = static_cast<uint32_t*>(c->lzg_words.p); g.open = g.words + p->lzg_words;
+	g.words = static_cast<uint32_t*>(c->lzg_words.p); g.open = g.words + p->lzg_words; g.tile_pass = reinterpret_cast<uint8_t*>(g.open + LZG_PASSES);
 	return g;
 }
 // the last stage of Xpress / Xpress+Huffman decompression: tokens -> bytes (a wave per small unit, a block per middle one, all CUs for the large ones)
@@ -682,6 +682,13 @@ uint32_t mscomp_amd_debug_lzd_walked(mscomp_amd_ctx* c)
 
 void mscomp_amd_set_lznt1_sa_dict(int on) { g_lznt1_sa.store(on ? 1 : 0, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 int  mscomp_amd_get_lznt1_sa_dict(void) { return g_lznt1_sa.load(std::memory_order_relaxed); }
+int mscomp_amd_debug_lzg_open(mscomp_amd_ctx* c, uint64_t words, uint32_t* out)
+{	// test hook: the open-word counters of the last lzglobal.hip run (`words` = the plan's word count: sum of capacity + 64 over the units taken)
+	if (!c || !out || !c->lzg_words.p) { return -1; }
+	DeviceGuard g(c->device);
+	if (!g.ok || hipStreamSynchronize(c->stream) != hipSuccess) { return -1; }
+	return hipMemcpy(out, static_cast<uint32_t*>(c->lzg_words.p) + words, LZG_PASSES * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
 void mscomp_amd_debug_set_xpress_decoder(int mode) { g_xpd_mode.store(mode, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 void mscomp_amd_debug_set_finder(int mode) { g_finder_mode.store(mode, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 void mscomp_amd_debug_set_lznt1(int mode) { set_lznt1_mode(mode); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }

@@ -80,6 +80,9 @@ void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const Ba
 
 // ---- tokens -> bytes for large units by all CUs (lzglobal.hip) ----
 #define LZG_PASSES 33u                                    // pointer passes launched (chains halve at least: 2^32 bytes); a pass returns at once when the one before left nothing open
+#ifndef LZG_TILE_SHIFT
+#define LZG_TILE_SHIFT 13                                   // output bytes per tile of lzg_expand_kernel: 8 KiB (32 KiB tiles: expansion 0.78 -> 1.37 ms, passes 4.1 -> 4.6 ms on the 12 files)
+#endif
 #define LZG_MIN_CAP (1u << 20)                            // units with at least this much output capacity take this path (when the plan has the scratch for it)
 struct LzgTables {
 	const uint32_t* unit;          // n_big: the units taken
@@ -91,6 +94,7 @@ struct LzgTables {
 	uint32_t* dir_pos;             // ... and where
 	uint32_t* words;               // per output byte: LZG_VAL | byte, or the index of its source
 	uint32_t* open;                // LZG_PASSES counters: words still pointing after each pass
+	uint8_t*  tile_pass;           // per tile: the pointer pass that has to look at it next (0xFF: none)
 	uint32_t  n_big, n_tb, n_tiles;
 };
 // phase 0 = directory (3 kernels), 1 = lzg_expand_kernel, 2 = the pointer passes

@@ -19,7 +19,8 @@
 
 namespace msc {
 
-#define LZG_T   8192u                                              // output bytes per tile, tokens per token block
+#define LZG_T   (1u << LZG_TILE_SHIFT)                             // output bytes per tile
+#define LZG_TB  8192u                                              // tokens per token block
 #define LZG_NT  1024u
 #define LZG_VAL 0xFFFFFF00u                                        // word >= this: the byte is word & 0xFF; below: the index of the source byte in the unit
 
@@ -57,11 +58,11 @@ __global__ __launch_bounds__(LZG_NT) void lzg_sums_kernel(LzgTables g, const u64
 	const u64 j = blockIdx.x - g.tb_prefix[b];
 	if (d_status[u] != 0) { return; }
 	const u64 nt = ntok[u];
-	if (j * LZG_T >= nt) { return; }
+	if (j * LZG_TB >= nt) { return; }
 	const uint32_t* __restrict__ mytok = tok + tok_prefix[u];
 	u64 sum = 0;
 	#pragma unroll
-	for (uint32_t r = 0; r < LZG_T / LZG_NT; ++r) { const u64 ti = j * LZG_T + (u64)tid * (LZG_T / LZG_NT) + r; if (ti < nt) { sum += lzg_len(mytok[ti]); } }
+	for (uint32_t r = 0; r < LZG_TB / LZG_NT; ++r) { const u64 ti = j * LZG_TB + (u64)tid * (LZG_TB / LZG_NT) + r; if (ti < nt) { sum += lzg_len(mytok[ti]); } }
 	u64 tot;
 	(void)lzg_block_excl(sum, s_w, tid, &tot);
 	if (tid == 0) { g.bsum[blockIdx.x] = tot; }
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(LZG_NT) void lzg_scan_kernel(LzgTables g, const u64
 	__shared__ u64 s_w[16];
 	const uint32_t tid = threadIdx.x, b = blockIdx.x, u = g.unit[b];
 	if (d_status[u] != 0) { return; }
-	const u64 nb = (ntok[u] + LZG_T - 1u) / LZG_T;
+	const u64 nb = (ntok[u] + LZG_TB - 1u) / LZG_TB;
 	u64* __restrict__ my = g.bsum + g.tb_prefix[b];
 	u64 carry = 0;
 	for (u64 i0 = 0; i0 < nb; i0 += LZG_NT) {
@@ -97,19 +98,19 @@ __global__ __launch_bounds__(LZG_NT) void lzg_dir_kernel(LzgTables g, const u64*
 	uint32_t* __restrict__ dt = g.dir_tok + g.tile_prefix[b];
 	uint32_t* __restrict__ dp = g.dir_pos + g.tile_prefix[b];
 	if (j == 0 && tid == 0) { dt[0] = 0; dp[0] = 0; }
-	if (j * LZG_T >= nt) { return; }
+	if (j * LZG_TB >= nt) { return; }
 	const uint32_t* __restrict__ mytok = tok + tok_prefix[u];
-	constexpr uint32_t TPT = LZG_T / LZG_NT;
+	constexpr uint32_t TPT = LZG_TB / LZG_NT;
 	uint32_t len[TPT]; u64 sum = 0;
 	#pragma unroll
-	for (uint32_t r = 0; r < TPT; ++r) { const u64 ti = j * LZG_T + (u64)tid * TPT + r; len[r] = ti < nt ? lzg_len(mytok[ti]) : 0u; sum += len[r]; }
+	for (uint32_t r = 0; r < TPT; ++r) { const u64 ti = j * LZG_TB + (u64)tid * TPT + r; len[r] = ti < nt ? lzg_len(mytok[ti]) : 0u; sum += len[r]; }
 	u64 tot;
 	u64 p = g.bsum[blockIdx.x] + lzg_block_excl(sum, s_w, tid, &tot);
 	#pragma unroll
 	for (uint32_t r = 0; r < TPT; ++r) {
 		const u64 e = p + len[r];                                       // where the next token starts
-		for (u64 k = (p >> 13) + 1u; k <= (e >> 13) && k * LZG_T < total; ++k) {   // tile boundaries in (p, e]: the next token is the first that starts at or behind them
-			dt[k] = (uint32_t)(j * LZG_T + (u64)tid * TPT + r + 1u); dp[k] = (uint32_t)e;
+		for (u64 k = (p >> LZG_TILE_SHIFT) + 1u; k <= (e >> LZG_TILE_SHIFT) && k * LZG_T < total; ++k) {   // tile boundaries in (p, e]: the next token is the first that starts at or behind them
+			dt[k] = (uint32_t)(j * LZG_TB + (u64)tid * TPT + r + 1u); dp[k] = (uint32_t)e;
 		}
 		p = e;
 	}
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(LZG_NT) void lzg_expand_kernel(LzgTables g, BatchTa
                                                            const u64* __restrict__ ntok, const u64* __restrict__ d_out_len, const int32_t* __restrict__ d_status,
                                                            uint8_t* __restrict__ d_out)
 {
-	__shared__ LzgLds L;
+	extern __shared__ __attribute__((aligned(16))) uint8_t lzg_smem[];
+	LzgLds& L = *reinterpret_cast<LzgLds*>(lzg_smem);
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
 	const uint32_t b = lzg_seg(g.tile_prefix, g.n_big, blockIdx.x), u = g.unit[b];
 	const u64 k = blockIdx.x - g.tile_prefix[b];
@@ -230,37 +232,42 @@ __global__ __launch_bounds__(LZG_NT) void lzg_expand_kernel(LzgTables g, BatchTa
 		}
 		if (!__syncthreads_or(open ? 1 : 0)) { break; }
 	}
+	bool ext = false;
 	#pragma unroll
 	for (uint32_t r = 0; r < TPT; ++r) {
 		const uint32_t q = r * LZG_NT + tid;
 		if (q < wlen) {
 			const uint32_t mine = myw[r];
 			if (mine & LZG_W_VAL) { dst[w0 + q] = (uint8_t)mine; P[w0 + q] = LZG_VAL | (mine & 0xFFu); }
-			else { P[w0 + q] = (uint32_t)(w0 - (mine & 0xFFFFu)); }      // (the parsers have checked that no match reaches in front of the unit)
+			else { P[w0 + q] = (uint32_t)(w0 - (mine & 0xFFFFu)); ext = true; }      // (the parsers have checked that no match reaches in front of the unit)
 		}
 	}
+	const int any = __syncthreads_or(ext ? 1 : 0);
+	if (tid == 0) { g.tile_pass[blockIdx.x] = any ? 0u : 0xFFu; }       // the pass that has to look at this tile next (0xFF: none)
 }
 
 // ---- pointer passes ------------------------------------------------------------------------------------------------------------------------
 #define LZG_HOPS 8u
 __global__ __launch_bounds__(256) void lzg_jump_kernel(LzgTables g, BatchTables bt, const u64* __restrict__ d_out_len, const int32_t* __restrict__ d_status,
-                                                      uint8_t* __restrict__ d_out, uint32_t pass)
+                                                      uint8_t* __restrict__ d_out, uint32_t pass, uint32_t hops)
 {
 	if (pass > 0 && g.open[pass - 1u] == 0) { return; }                  // the pass before left nothing open
-	const u64 stride = (u64)gridDim.x * 256u;
-	uint32_t still = 0;
-	for (uint32_t b = 0; b < g.n_big; ++b) {
-		const uint32_t u = g.unit[b];
-		if (d_status[u] != 0) { continue; }
-		const u64 total = d_out_len[u];
+	uint32_t still_all = 0;
+	for (uint32_t tile = blockIdx.x; tile < g.n_tiles; tile += gridDim.x) {
+		if (g.tile_pass[tile] != pass) { continue; }                     // all its words are values already (or it lies behind the unit's end)
+		const uint32_t b = lzg_seg(g.tile_prefix, g.n_big, tile), u = g.unit[b];
+		const u64 total = d_out_len[u], w0 = (u64)(tile - g.tile_prefix[b]) * LZG_T;
+		if (d_status[u] != 0 || w0 >= total) { continue; }                 // (a tile the expansion did not visit: its flag is stale)
 		uint32_t* __restrict__ P = g.words + g.word_prefix[b];
 		uint8_t* __restrict__ dst = d_out + bt.out_off[u];
-		for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < total; i += stride) {
+		const u64 end = total - w0 < LZG_T ? total : w0 + LZG_T;
+		uint32_t still = 0;
+		for (u64 i = w0 + threadIdx.x; i < end; i += 256u) {
 			uint32_t v = __hip_atomic_load(&P[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (v >= LZG_VAL) { continue; }
 			bool done = false;
 			#pragma unroll 1
-			for (uint32_t h = 0; h < LZG_HOPS; ++h) {
+			for (uint32_t h = 0; h < hops; ++h) {
 				const uint32_t w = __hip_atomic_load(&P[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				v = w;
 				if (w >= LZG_VAL) { done = true; break; }
@@ -268,13 +275,15 @@ __global__ __launch_bounds__(256) void lzg_jump_kernel(LzgTables g, BatchTables 
 			__hip_atomic_store(&P[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (done) { dst[i] = (uint8_t)v; } else { ++still; }
 		}
+		const int any = __syncthreads_or(still ? 1 : 0);
+		if (any && threadIdx.x == 0) { g.tile_pass[tile] = (uint8_t)(pass + 1u); }
+		still_all += still;
 	}
-	const u64 m = __ballot(still != 0);
-	if (m) {
-		uint32_t s = still;
+	if (__ballot(still_all != 0)) {
+		uint32_t s = still_all;
 		#pragma unroll
 		for (uint32_t d = 32; d > 0; d >>= 1) { s += (uint32_t)__shfl_down((int)s, d, 64); }
-		if ((threadIdx.x & 63u) == 0) { atomicAdd(&g.open[pass], s); }
+		if ((threadIdx.x & 63u) == 0 && s) { atomicAdd(&g.open[pass], s); }
 	}
 }
 
@@ -290,11 +299,14 @@ void launch_lz_copy_global(hipStream_t st, const LzgTables& g, const BatchTables
 		hipLaunchKernelGGL(lzg_dir_kernel, dim3(g.n_tb), dim3(LZG_NT), 0, st, g, tok_prefix, tok, ntok, d_out_len, d_status);
 		break;
 	case 1:
-		hipLaunchKernelGGL(lzg_expand_kernel, dim3(g.n_tiles), dim3(LZG_NT), 0, st, g, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out);
+		{ static bool attr_set = false; if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lzg_expand_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzgLds)); attr_set = true; } }
+		hipLaunchKernelGGL(lzg_expand_kernel, dim3(g.n_tiles), dim3(LZG_NT), sizeof(LzgLds), st, g, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out);
 		break;
-	default:
-		for (uint32_t pass = 0; pass < LZG_PASSES; ++pass) { hipLaunchKernelGGL(lzg_jump_kernel, dim3(2048), dim3(256), 0, st, g, bt, d_out_len, d_status, d_out, pass); }
+	default: {
+		static const uint32_t hops = [] { const char* e = getenv("MSCOMP_AMD_LZG_HOPS"); const long v = e ? atol(e) : 0; return (uint32_t)(v > 0 && v < 1000 ? v : LZG_HOPS); }();
+		for (uint32_t pass = 0; pass < LZG_PASSES; ++pass) { hipLaunchKernelGGL(lzg_jump_kernel, dim3(g.n_tiles < 4096u ? g.n_tiles : 4096u), dim3(256), 0, st, g, bt, d_out_len, d_status, d_out, pass, hops); }
 		break;
+	}
 	}
 }
 

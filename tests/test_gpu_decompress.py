@@ -207,3 +207,37 @@ def test_xpress_length_forms_truncations_and_corruptions(oracle, gpu_ctx, mode):
         else:
             n_err += 1
     assert n_ok > 100 and n_err > 300
+
+
+@pytest.mark.parametrize("fmt", ["xpress", "xpress_huff"])
+def test_large_units_get_their_bytes_from_all_cus(oracle, gpu_ctx, fmt):
+    """csrc/lzglobal.hip (units with room for 1 MiB or more: tile directory, per-tile expansion, pointer passes) next to the block-per-unit
+    and wave-per-unit kernels in ONE batch: deep copy chains (5 MB of one byte: every byte copies its neighbour; short periods), data whose
+    sources lie far back, a generous capacity (tiles behind the end of the output), a unit that ends in an error, small units in between."""
+    import ctypes as C
+    import ms_compress_amd as m
+    from ms_compress_amd import corpus
+    f = FMTS[fmt]
+    rng = np.random.default_rng(31)
+    per7 = np.tile(rng.integers(0, 256, 7, dtype=np.uint8), 3_000_000 // 7 + 1)[:3_000_000].tobytes()
+    far = bytearray(rng.integers(0, 256, 40000, dtype=np.uint8).tobytes())
+    while len(far) < 2_500_000:                                   # copies of 100 - 4000 bytes from up to 8000 back, over and over: chains through hundreds of tiles
+        o = int(rng.integers(2000, 8000)); n = int(rng.integers(100, 4000)); far += far[-o:-o + n]
+    units = [bytes(5_000_000), per7, bytes(far), corpus.file_bytes(1, 4_000_000).tobytes(), corpus.file_bytes(3, 1_500_000).tobytes(),
+             b"small unit " * 50, corpus.file_bytes(0, 300_000).tobytes(), rng.integers(0, 256, 2_000_000, dtype=np.uint8).tobytes()]
+    comp, st = m.compress_units(f, units, ctx=gpu_ctx)
+    assert all(s == 0 for s in st)
+    caps = [len(u) for u in units]
+    caps[1] += 3 << 20                                            # room for 3 MiB more than comes out
+    streams = list(comp) + [comp[3][: len(comp[3]) // 2]]         # half a stream: an error (or a shorter output) next to the good ones
+    caps.append(len(units[3]))
+    back, st2 = m.decompress_units(f, streams, caps, ctx=gpu_ctx)
+    for i, u in enumerate(units):
+        assert st2[i] == 0 and back[i] == u, (fmt, i, st2[i], len(back[i]), len(u))
+    so, oo, _ = oracle.oracle_decompress_ex(f, streams[-1], caps[-1])
+    assert st2[-1] == so and (so != 0 or back[-1] == oo)
+    opened = (C.c_uint32 * 33)()
+    gpu_ctx.lib.mscomp_amd_debug_lzg_open.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    assert gpu_ctx.lib.mscomp_amd_debug_lzg_open(gpu_ctx._h, sum(c + 64 for c in caps if c >= (1 << 20)), opened) == 0
+    opened = list(opened)
+    assert opened[0] > 1_000_000 and 0 in opened and all(x == 0 for x in opened[opened.index(0):])   # the path ran, took several passes, and ended
