@@ -264,9 +264,10 @@ def cpu_baseline(fmt, blob, budget_s=10.0):
             "sample": "%d passes over the first %d B of the batch, %d threads x %d B independent ms_compress calls" % (passes, sample, len(slices), piece)}
 
 
-def cpu_decompress_baseline(fmt, blob, budget_s=3.0):
+def cpu_decompress_baseline(fmt, blob, budget_s=3.0, whole=None):
     """The reference's CPU decoder beside the GPU decompression leg: the same kind of bounded sample (64 KiB units for the Xpress
-    formats, 4 MiB pieces for LZNT1; compressed by the reference, untimed), all host cores, output MB/s."""
+    formats, 4 MiB pieces for LZNT1; compressed by the reference, untimed), all host cores, output MB/s. whole = [(offset, length)]:
+    these buffers instead, one ms_decompress call each (the 12 files: at most 12 threads have work)."""
     from oracle import loader
     ref = loader.load_ref()
     kind = "reference" if ref is not None else "port"
@@ -274,8 +275,19 @@ def cpu_decompress_baseline(fmt, blob, budget_s=3.0):
     unit = (4 << 20) if fmt == 2 else 65536
     per_thread = 4 << 20
     sample = min(len(blob), per_thread * cores) // unit * unit
-    data = blob[:sample].tobytes()
+    data = blob[:sample].tobytes() if whole is None else None
     comp = loader.ref_compress if ref is not None else loader.oracle_compress
+    if whole is not None:
+        units = [blob[int(o):int(o) + int(l)].tobytes() for o, l in whole]
+        sample = sum(len(u) for u in units)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(min(cores, len(units))) as ex:      # (ctypes drops the GIL inside the call)
+            streams = list(ex.map(lambda u: comp(fmt, u)[1], units))
+        threads = min(cores, len(units))
+        fn = ref.ms_decompress if ref is not None else loader.load_oracle().orc_decompress
+        passes, dt = _cpu_timed(fn, fmt, streams, [len(u) for u in units], threads, budget_s)
+        return {"value": round(sample * passes / dt / 1e6, 1), "unit": "MB/s (output)", "cores": threads, "kind": kind,
+                "sample": "%d passes over %d whole buffers (%d B), one ms_decompress call each" % (passes, len(units), sample)}
     units = [data[o:o + unit] for o in range(0, sample, unit)]
     streams = [comp(fmt, u)[1] for u in units]
     threads = min(cores, len(units))
@@ -421,6 +433,15 @@ def main():
             if not args.no_cpu:
                 dec[codec]["cpu_baseline"] = cpu_decompress_baseline(f2, b2)
         extra["decompress"] = dec
+        # the same for whole files as single buffers (large units: chunk-parallel Huffman walk / one serial Xpress token chain; bytes by all CUs, lzglobal.hip)
+        decf = {}
+        for codec in ("xpress_huff", "xpress"):
+            f2 = m.FORMATS[codec]
+            b2, o2, l2, d2 = single_gpu_workload(cor, "silesia_files")
+            decf[codec] = decompress_leg(m, ctx, f2, b2, o2, l2, d2, 2, sharding)
+            if not args.no_cpu:
+                decf[codec]["cpu_baseline"] = cpu_decompress_baseline(f2, b2, whole=list(zip(o2, l2)))
+        extra["decompress_files"] = decf
     if extra:
         res["extra"] = extra
     if rank == 0:

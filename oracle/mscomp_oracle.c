@@ -995,11 +995,15 @@ long long orc_xp_flag_starts(const uint8_t* in, size_t n, size_t cap, uint8_t* m
 	free(out);
 	return st == ORC_OK ? (long long)len : st;
 }
-size_t orc_xp_sync(const uint8_t* in, size_t n, size_t start, const uint8_t* mark, const uint32_t* halfpos)
+size_t orc_xp_sync2(const uint8_t* in, size_t n, size_t start, const uint8_t* mark, const uint32_t* halfpos, int pending);
+size_t orc_xp_sync(const uint8_t* in, size_t n, size_t start, const uint8_t* mark, const uint32_t* halfpos) { return orc_xp_sync2(in, n, start, mark, halfpos, 0); }
+/* pending = 1: the parse starts as if a nibble were pending in a byte it has not seen (its value then counts as "not 15": right 15 times in 16) */
+size_t orc_xp_sync2(const uint8_t* in, size_t n, size_t start, const uint8_t* mark, const uint32_t* halfpos, int pending)
 {
-	size_t ip = start, half = 0; int have_half = 0;
+	const size_t UNSEEN = (size_t)-1;
+	size_t ip = start, half = pending ? UNSEEN : 0; int have_half = pending ? 1 : 0;
 	while (ip + 4 <= n) {
-		if ((mark[ip] == 1 && !have_half) || (mark[ip] == 2 && have_half && halfpos[ip] == (uint32_t)half)) { return ip; }
+		if ((mark[ip] == 1 && !have_half) || (mark[ip] == 2 && have_half && (half == UNSEEN || halfpos[ip] == (uint32_t)half))) { return ip; }
 		uint32_t flags = get32(in + ip);
 		ip += 4;
 		for (int t = 0; t < 32; ++t, flags <<= 1) {
@@ -1009,7 +1013,7 @@ size_t orc_xp_sync(const uint8_t* in, size_t n, size_t start, const uint8_t* mar
 			const uint32_t sym = get16(in + ip); ip += 2;
 			if ((sym & 7) != 7) { continue; }
 			uint32_t len;
-			if (have_half) { len = in[half] >> 4; have_half = 0; }
+			if (have_half) { len = half == UNSEEN ? 0 : in[half] >> 4; have_half = 0; }
 			else { if (ip >= n) { return n; } half = ip; have_half = 1; len = in[ip++] & 0xF; }
 			if (len != 0xF) { continue; }
 			if (ip >= n) { return n; }

@@ -9,7 +9,9 @@ from ms_compress_amd import corpus
 lib = loader.load_oracle()
 lib.orc_xp_flag_starts.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]; lib.orc_xp_flag_starts.restype = C.c_longlong
 lib.orc_xp_sync.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]; lib.orc_xp_sync.restype = C.c_size_t
+lib.orc_xp_sync2.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]; lib.orc_xp_sync2.restype = C.c_size_t
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+TWO = len(sys.argv) > 2 and sys.argv[2] == "two"
 rnd = random.Random(3)
 allv = []
 for i, name in enumerate(corpus.NAMES):
@@ -21,6 +23,7 @@ for i, name in enumerate(corpus.NAMES):
     for _ in range(400):
         s = rnd.randrange(0, max(1, len(comp) - 200000))
         e = lib.orc_xp_sync(comp, len(comp), s, mark.ctypes.data, hp.ctypes.data)
+        if TWO: e = min(e, lib.orc_xp_sync2(comp, len(comp), s, mark.ctypes.data, hp.ctypes.data, 1))   # the better of the two hypotheses about a pending nibble
         if e >= len(comp): never += 1
         else: dist.append(e - s)
     d = np.array(dist) if dist else np.array([0])
