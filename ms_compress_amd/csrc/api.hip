@@ -26,7 +26,7 @@ namespace {
 static std::atomic<uint64_t> g_mode_epoch{1};
 static int lznt1_sa_env() { const char* e = getenv("MSCOMP_AMD_LZNT1_SA_DICT"); return (e && *e && *e != '0') ? 1 : 0; }
 static std::atomic<int> g_lznt1_sa{lznt1_sa_env()};    // 1 = LZNT1 compresses with the suffix-array dictionary flavour (lznt1_sa.hip; the reference's MSCOMP_WITH_LZNT1_SA_DICT build)
-static std::atomic<int> g_xpd_mode{0};                 // Xpress decompression: 0 = tokens a flag word at a time + copy kernels (default), 1 = xpd_kernel (a token at a time, bytes in the same wave)
+static std::atomic<int> g_xpd_mode{0};                 // Xpress decompression: 0 = tokens a flag word at a time + copy kernels (default; large streams by segments), 1 = xpd_kernel (a token at a time, bytes in the same wave), 2 = as 0 without the segments
 static std::atomic<int> g_finder_mode{1};              // 1 = Find for every position (default), 0 = the lazy finder of xlazy.hip (experimental: exact, slower -- DESIGN 5)
 struct DevBuf {
 	void* p = nullptr; size_t cap = 0;
@@ -59,6 +59,7 @@ struct mscomp_amd_ctx {
 	DevBuf dz_cin, dz_csize, dz_unit;                  // LZNT1 decompression: header offset / decoded size per chunk slot, per-unit records
 	DevBuf dz_tok, dz_ntok, dz_xhc;                    // Xpress+Huffman decompression: 32-bit tokens of every unit, token counts, candidate chunk records
 	DevBuf lzg_bsum, lzg_dir, lzg_words;               // tokens -> bytes of large units by all CUs (lzglobal.hip): token block sums, tile directory, a word per output byte + pass counters
+	DevBuf xps_buf;                                    // large Xpress streams by segments: segment records | mode per stream | done per unit
 	DevBuf cp_tab;                                     // compaction: out_off (u64) | tile_prefix (u32) of the batch being packed
 	DevBuf one_in, one_out, one_meta;                  // staging of the host-pointer one-shot path
 	uint64_t epoch = 1;                                // bumped when one of the buffers above moves (captured graphs are stale then)
@@ -69,7 +70,7 @@ struct mscomp_amd_ctx {
 	{
 		return { &slots, &slot_size, &prefix, &tile_sums, &links, &lasthead, &mlen3, &moff, &wtok, &wmat, &wfar, &wrec, &sbrec,
 		         &tokbits, &counts, &extra, &lens, &codes, &fb_list, &fbflag, &dz_cin, &dz_csize, &dz_unit, &dz_tok, &dz_ntok, &dz_xhc,
-		         &lzg_bsum, &lzg_dir, &lzg_words, &cp_tab, &one_in, &one_out, &one_meta };
+		         &lzg_bsum, &lzg_dir, &lzg_words, &xps_buf, &cp_tab, &one_in, &one_out, &one_meta };
 	}
 	mscomp_amd_ctx() { for (DevBuf* b : bufs()) { b->epoch = &epoch; } }
 };
@@ -87,6 +88,8 @@ struct mscomp_amd_plan {
 	DevBuf lzg_tab;                                    // lzglobal.hip: unit (u32 x n_big, padded) | tb_prefix | tile_prefix | word_prefix (u64 x (n_big + 1) each)
 	uint32_t lzg_big = 0, lzg_tb = 0, lzg_tiles = 0;   // units taken by that path (0: not used), their token blocks and tiles
 	uint64_t lzg_words = 0;
+	DevBuf xps_tab;                                    // xps_*: unit (u32 x n_big, padded) | seg_prefix (u64 x (n_big + 1))
+	uint32_t xps_big = 0, xps_seg = 0, xps_seg_bytes = 0, xps_warm_bytes = 0;
 	BatchTables bt{};
 	// the launch sequence of plan_execute as a hipGraph: captured on the plan's second execution, replayed while the
 	// arguments and the scratch buffers stay where they were
@@ -330,7 +333,29 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 				}
 			}
 		}
-		if (!okd) { p->lzg_tab.release(); p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_MEM_ERROR; }
+		if (okd && format == MSCOMP_XPRESS) {
+			std::vector<uint32_t> big;
+			for (size_t i = 0; i < n_units; ++i) { if (in_len[i] >= XPS_MIN_IN) { big.push_back((uint32_t)i); } }
+			if (!big.empty()) {
+				const size_t nb = big.size(), upad = (nb + 1) / 2;
+				std::vector<uint64_t> tab(upad + nb + 1);
+				memcpy(tab.data(), big.data(), nb * 4);
+				// segment size / warm-up (MSCOMP_AMD_XPS_SEG_KB / _WARM_KB override the defaults, for measurements)
+				static const uint32_t seg_b = [] { const char* e = getenv("MSCOMP_AMD_XPS_SEG_KB"); const long v = e ? atol(e) : 0; return (uint32_t)(v >= 4 && v <= 65536 ? v << 10 : XPS_SEG); }();
+				static const uint32_t warm_b = [] { const char* e = getenv("MSCOMP_AMD_XPS_WARM_KB"); const long v = e ? atol(e) : 0; const uint32_t w = (uint32_t)(v >= 1 && v <= 65536 ? v << 10 : XPS_WARM); return w < seg_b ? w : seg_b; }();
+				p->xps_seg_bytes = seg_b; p->xps_warm_bytes = warm_b;
+				uint64_t sg = 0;
+				for (size_t k = 0; k < nb; ++k) { tab[upad + k] = sg; sg += (in_len[big[k]] + seg_b - 1) / seg_b; }
+				tab[upad + nb] = sg;
+				if (sg < 0x7FFFFFF0ull) {
+					okd = p->xps_tab.reserve(tab.size() * 8) && c->xps_buf.reserve(sg * XPS_SEG_BYTES + nb * 4 + n_units * 4 + 64);
+					if (okd && (hipMemcpyAsync(p->xps_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+					            hipStreamSynchronize(c->stream) != hipSuccess)) { p->xps_tab.release(); p->lzg_tab.release(); p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_ERRNO; }
+					if (okd) { p->xps_big = (uint32_t)nb; p->xps_seg = (uint32_t)sg; }
+				}
+			}
+		}
+		if (!okd) { p->xps_tab.release(); p->lzg_tab.release(); p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_MEM_ERROR; }
 		*out = p;
 		return MSCOMP_OK;
 	}
@@ -377,7 +402,7 @@ void mscomp_amd_plan_destroy(mscomp_amd_plan* p)
 	DeviceGuard g(p->ctx->device);
 	(void)hipStreamSynchronize(p->ctx->stream);
 	if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); }
-	p->tables.release(); p->tokpre.release(); p->lzg_tab.release();
+	p->tables.release(); p->tokpre.release(); p->lzg_tab.release(); p->xps_tab.release();
 	delete p;
 }
 
@@ -452,7 +477,18 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 			const u64* tp = static_cast<const u64*>(p->tokpre.p); uint32_t* tok = static_cast<uint32_t*>(c->dz_tok.p); u64* ntok = static_cast<u64*>(c->dz_ntok.p);
 			static const char* const names[3] = {"xpt_parse_kernel", "lz_copy_kernel", "lz_copy_block_kernel"};
 			const u64 gmin = p->lzg_big ? (u64)LZG_MIN_CAP : ~(u64)0;
-			for (int ph = 0; ph < 3; ++ph) { KernelTimer t(c, names[ph]); launch_xpress_decompress_tokens(st, d_in, p->bt, tp, tok, ntok, d_out, d_out_len, d_status, ph, gmin); }
+			XpsTables x = {};
+			if (p->xps_big && g_xpd_mode.load(std::memory_order_relaxed) != 2) {
+				const size_t nb = p->xps_big, upad = (nb + 1) / 2;
+				const uint64_t* t = static_cast<const uint64_t*>(p->xps_tab.p);
+				x.unit = reinterpret_cast<const uint32_t*>(t); x.seg_prefix = t + upad; x.n_big = p->xps_big; x.n_seg = p->xps_seg; x.seg_bytes = p->xps_seg_bytes; x.warm_bytes = p->xps_warm_bytes;
+				x.seg = c->xps_buf.p; x.mode = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(c->xps_buf.p) + (size_t)p->xps_seg * XPS_SEG_BYTES); x.done = x.mode + nb;
+				{ KernelTimer t2(c, "xps_walk_kernel"); launch_xpress_decompress_tokens(st, d_in, p->bt, tp, tok, ntok, d_out, d_out_len, d_status, -1, gmin, x); }
+				static const uint32_t rounds = [] { const char* e = getenv("MSCOMP_AMD_XPS_ROUNDS"); const long v = e ? atol(e) : 0; return (uint32_t)(v >= 1 && v <= 256 ? v : XPS_ROUNDS); }();
+				for (uint32_t r = 0; r < rounds; ++r) { KernelTimer t2(c, "xps_redo_kernels"); launch_xpress_decompress_tokens(st, d_in, p->bt, tp, tok, ntok, d_out, d_out_len, d_status, -2, gmin, x); }
+				{ KernelTimer t2(c, "xps_emit_kernel"); launch_xpress_decompress_tokens(st, d_in, p->bt, tp, tok, ntok, d_out, d_out_len, d_status, -3, gmin, x); }
+			}
+			for (int ph = 0; ph < 3; ++ph) { KernelTimer t(c, names[ph]); launch_xpress_decompress_tokens(st, d_in, p->bt, tp, tok, ntok, d_out, d_out_len, d_status, ph, gmin, x); }
 			run_lz_copy_global(c, p, st, tp, tok, ntok, d_out_len, d_status, d_out);
 			return MSCOMP_OK;
 		}

@@ -728,37 +728,26 @@ void launch_xpress_decompress(hipStream_t st, const uint8_t* d_in, const BatchTa
 // serial walk: the first token, in order, that fails decides.
 #define XPT_INB 1024u
 #define LZT_MAXLEN 32766u                                       // longest match a 32-bit token holds (15 bits); longer ones are cut into pieces
-__global__ __launch_bounds__(64) void xpt_parse_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, const u64* __restrict__ tok_prefix, uint32_t* __restrict__ tok,
-                                                      u64* __restrict__ ntok, u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
+#define XPS_DONE 0x5EC0D0E5u
+// The walk of one wave from a flag word on: state in / state out. EMIT: tokens are written at mytok[tc ...] and the copy's tests (:442-443, :455)
+// are made against the output offset `op` and the capacity; without it the walk only counts (tokens, bytes) -- for a stretch of a stream whose
+// place in the output is not known yet (xps_* below). It ends in front of the first flag word at or behind `limit` (running = true) or where
+// the reference's loop ends (status). Offsets are relative to the 16-byte aligned base `ab`, as in xpd_kernel.
+struct XptWalk { uint32_t ip; u64 op, tc; uint32_t half, hp; bool have_half; int32_t status; bool running; };
+#define XPT_BLOCK() { __syncthreads(); *reinterpret_cast<uint4*>(s_in + (loaded & 1u) * XPT_INB + lane * 16u) = nxt; ++loaded; \
+	{ const u64 q_ = (u64)loaded * XPT_INB + lane * 16u; nxt = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } __syncthreads(); }
+template <bool EMIT>
+__device__ __forceinline__ void xpt_walk(uint8_t* s_in, const uint8_t* __restrict__ ab, const uint32_t endq, uint32_t& loaded, uint4& nxt, XptWalk& W,
+                                         const uint32_t limit, const u64 cap, uint32_t* __restrict__ mytok, const uint32_t lane)
 {
-	__shared__ __attribute__((aligned(16))) uint8_t s_in[2u * XPT_INB];
-	const uint32_t lane = threadIdx.x, u = blockIdx.x;
-	const uint32_t n = (uint32_t)bt.in_len[u];
-	const u64 cap = bt.out_cap[u];
-	const uint8_t* src = d_in + bt.in_off[u];
-	uint32_t* __restrict__ mytok = tok + tok_prefix[u];
-	if (n < 5u) {                                                        // :414-418
-		bool ok = n == 0;
-		if (n == 4u) { ok = ((uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24)) != 0xFFFFFFFFu; }
-		if (lane == 0) { d_status[u] = ok ? 0 : -3; d_out_len[u] = 0; ntok[u] = 0; }
-		return;
-	}
-	// input ring as in xpd_kernel (two blocks of 1024 bytes); the block after the newest one is already on its way from HBM, in registers
-	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
-	const uint8_t* ab = src - a0;
-	const uint32_t endq = a0 + n;
-	uint32_t loaded = 0;
-	uint4 nxt = lane * 16u < endq ? *reinterpret_cast<const uint4*>(ab + lane * 16u) : make_uint4(0, 0, 0, 0);
-	#define XPT_BLOCK() { __syncthreads(); *reinterpret_cast<uint4*>(s_in + (loaded & 1u) * XPT_INB + lane * 16u) = nxt; ++loaded; \
-		{ const u64 q_ = (u64)loaded * XPT_INB + lane * 16u; nxt = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } __syncthreads(); }
-	XPT_BLOCK() XPT_BLOCK()
 	auto rb = [&](uint32_t q) -> uint32_t { return s_in[q & (2u * XPT_INB - 1u)]; };
 	const uint32_t* in32 = reinterpret_cast<const uint32_t*>(s_in);
-	uint32_t ip = a0;
-	u64 op = 0, tc = 0;
+	uint32_t ip = W.ip, half = W.half, hp = W.hp;
+	u64 op = W.op, tc = W.tc;
+	bool have_half = W.have_half, done = false, running = false;
 	int32_t status = -3;
-	uint32_t half = 0; bool have_half = false, done = false;
 	while (!done) {
+		if (ip >= limit) { running = true; break; }                     // a flag word at or behind the limit: the walk stops in front of it
 		if (ip + 4u > endq) { status = -3; break; }                     // :461 the input ended at a flag word
 		while ((u64)loaded * XPT_INB < (u64)ip + 352u && (u64)loaded * XPT_INB < endq) { XPT_BLOCK() }   // a flag word and its 32 tokens take at most 4 + 32 * 10 bytes
 		uint32_t m;                                                      // bit i: token i is a match
@@ -807,21 +796,21 @@ __global__ __launch_bounds__(64) void xpt_parse_kernel(const uint8_t* __restrict
 			const uint32_t len = is_m ? (lng ? (e1 ? extb + 25u : nib + 10u) : (sym & 7u) + 3u) : 1u, off = (sym >> 3) + 1u;
 			const uint32_t l = plain ? len : 0u, incl = wave_incl_scan_add_u32(l);
 			const u64 opi = op + (incl - l);
-			const bool bad_off = plain && is_m && (u64)off > opi;                                   // :442
+			const bool bad_off = EMIT && plain && is_m && (u64)off > opi;                                   // :442
 			const bool bad_cap = plain && (is_m ? (u64)len > cap - opi : opi >= cap);               // :443 / :455
 			const u64 eb = __ballot(bad_off || bad_cap);
 			if (eb) {
 				const uint32_t e = ctz64(eb);
 				status = ((__ballot(bad_off) >> e) & 1u) ? -3 : -5; done = true; break;
 			}
-			if (plain) { mytok[tc + lane] = is_m ? ((len << 16) | off) : (0x80000000u | b0); }
+			if (EMIT && plain) { mytok[tc + lane] = is_m ? ((len << 16) | off) : (0x80000000u | b0); }
 			tc += first;
 			op += first ? (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(first - 1u)) : 0u;
 			{	// the nibble state behind the plain tokens
 				const uint32_t pl = longs & (first < 32u ? (1u << first) - 1u : 0xFFFFFFFFu);
 				if (pl) {
 					const bool pend = have_half ^ (((uint32_t)__builtin_popcount(pl) & 1u) != 0);
-					if (pend) { half = (uint32_t)__builtin_amdgcn_readlane((int)hbn, (int)(31u - (uint32_t)__builtin_clz(pl))); }   // (the last long one brought it)
+					if (pend) { const uint32_t ll_ = 31u - (uint32_t)__builtin_clz(pl); half = (uint32_t)__builtin_amdgcn_readlane((int)hbn, (int)ll_); hp = (uint32_t)__builtin_amdgcn_readlane((int)q, (int)ll_) + 2u; }   // (the last long one brought it)
 					have_half = pend;
 				}
 			}
@@ -838,7 +827,7 @@ __global__ __launch_bounds__(64) void xpt_parse_kernel(const uint8_t* __restrict
 			uint32_t used = 2u, ll;
 			if (have_half) { ll = half >> 4; have_half = false; }
 			else if (ip + used == endq) { status = -3; done = true; break; }
-			else { half = rb(ip + 2u); used = 3u; have_half = true; ll = half & 0xFu; }
+			else { half = rb(ip + 2u); hp = ip + 2u; used = 3u; have_half = true; ll = half & 0xFu; }
 			if (ll == 0xFu) {
 				if (ip + used == endq) { status = -3; done = true; break; }
 				ll = rb(ip + used); ++used;
@@ -855,20 +844,200 @@ __global__ __launch_bounds__(64) void xpt_parse_kernel(const uint8_t* __restrict
 				ll += 0xFu;
 			}
 			ll += 0x7u + 0x3u;
-			if ((u64)loff > op) { status = -3; done = true; break; }     // :442
+			if (EMIT && (u64)loff > op) { status = -3; done = true; break; }     // :442
 			if ((u64)ll > cap - op) { status = -5; done = true; break; } // :443
 			const uint32_t np = ll / LZT_MAXLEN + (ll % LZT_MAXLEN ? 1u : 0u);    // pieces with the same offset copy the same bytes
-			for (uint32_t k = lane; k < np; k += 64u) { mytok[tc + k] = ((k + 1u == np ? ll - (np - 1u) * LZT_MAXLEN : LZT_MAXLEN) << 16) | loff; }
+			for (uint32_t k = lane; EMIT && k < np; k += 64u) { mytok[tc + k] = ((k + 1u == np ? ll - (np - 1u) * LZT_MAXLEN : LZT_MAXLEN) << 16) | loff; }
 			tc += np; op += ll; ip += used;
 			j0 += first + 1u;
 		}
 	}
-	#undef XPT_BLOCK
-	if (lane == 0) { d_status[u] = status; d_out_len[u] = status == 0 ? op : 0; ntok[u] = status == 0 ? tc : 0; }
+	W.ip = ip; W.op = op; W.tc = tc; W.half = half; W.hp = hp; W.have_half = have_half; W.status = status; W.running = running;
+}
+
+// ring start for a walk that begins at offset ip0 (from the aligned base): blocks ip0 / 1024 and the next one resident, the third on its way
+#define XPT_RING_START(ip0) { loaded = (ip0) / XPT_INB; { const u64 q_ = (u64)loaded * XPT_INB + lane * 16u; nxt = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } XPT_BLOCK() XPT_BLOCK() }
+
+__global__ __launch_bounds__(64) void xpt_parse_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, const u64* __restrict__ tok_prefix, uint32_t* __restrict__ tok,
+                                                      u64* __restrict__ ntok, u64* __restrict__ d_out_len, int32_t* __restrict__ d_status, const uint32_t* __restrict__ spec_done)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t s_in[2u * XPT_INB];
+	const uint32_t lane = threadIdx.x, u = blockIdx.x;
+	if (spec_done && spec_done[u] == XPS_DONE) { return; }              // the segment-parallel walk has done this stream (xps_* below)
+	const uint32_t n = (uint32_t)bt.in_len[u];
+	const u64 cap = bt.out_cap[u];
+	const uint8_t* src = d_in + bt.in_off[u];
+	uint32_t* __restrict__ mytok = tok + tok_prefix[u];
+	if (n < 5u) {                                                        // :414-418
+		bool ok = n == 0;
+		if (n == 4u) { ok = ((uint32_t)src[0] | ((uint32_t)src[1] << 8) | ((uint32_t)src[2] << 16) | ((uint32_t)src[3] << 24)) != 0xFFFFFFFFu; }
+		if (lane == 0) { d_status[u] = ok ? 0 : -3; d_out_len[u] = 0; ntok[u] = 0; }
+		return;
+	}
+	// input ring as in xpd_kernel (two blocks of 1024 bytes); the block after the newest one is already on its way from HBM, in registers
+	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
+	const uint8_t* ab = src - a0;
+	const uint32_t endq = a0 + n;
+	uint32_t loaded; uint4 nxt;
+	XPT_RING_START(a0)
+	XptWalk W = { a0, 0, 0, 0, 0, false, -3, false };
+	xpt_walk<true>(s_in, ab, endq, loaded, nxt, W, 0xFFFFFFFFu, cap, mytok, lane);
+	if (lane == 0) { d_status[u] = W.status; d_out_len[u] = W.status == 0 ? W.op : 0; ntok[u] = W.status == 0 ? W.tc : 0; }
+}
+
+// ---- ONE large Xpress stream by many waves (SURVEY.md 8f-1 / 8f-2a on the decoding side) ----------------------------------------------------
+// Where a flag word starts is known only to a walk that comes from the start of the stream. But a walk that starts at a WRONG place falls
+// into step with the right one sooner or later (tools/xp_sync_study.py: after 2 KB in the median, 27 KB at the 90th, 137 KB at the 99th
+// percentile of 4 800 starts in the corpus: whenever it reaches a flag word of the right walk in the right state, it IS the right walk).
+// So the input of a stream is cut into segments of XPS_SEG bytes and
+//   round 0: a wave per segment starts XPS_WARM bytes before its segment as if a flag word began there (no nibble pending), notes the state
+//            in which it arrives at the first flag word at or behind the segment start ("landing": offset, pending nibble and where its byte
+//            is) and counts tokens and bytes from there to the first flag word at or behind the segment end ("exit"). Segment 0 starts at the start.
+//   check:   segment k holds if its landing is the exit of segment k - 1 (and that one ran on); by induction from segment 0 a chain of
+//            holding segments is the true parse. A segment that does not hold is walked again from the exit of the segment before it, all such
+//            segments at the same time, XPS_ROUNDS times: each round makes at least the first of them right; the 99 % case is one round.
+//   emit:    with the segments' token and byte counts summed up, every segment is walked once more from its true state, writing its tokens
+//            at their place and making the tests that need the output offset.
+// Whatever does not fit this picture -- a segment that ends in an error, more rounds needed, a test failing, output beyond the capacity --
+// sends the stream to the one-wave walk above, which gives the reference's status to the letter.
+struct XpsSeg { uint32_t l_ip, l_hp, e_ip, e_hp, kind, redo; u64 ntok, nout, tbase, obase, pad_; };
+static_assert(sizeof(XpsSeg) == XPS_SEG_BYTES, "XpsSeg");   // l_hp / e_hp: 0xFFFFFFFF = no nibble pending; kind: 0 ran on, 1 the stream ended well, 2 anything else
+__device__ __forceinline__ XpsSeg* xps_segs(const XpsTables& x, uint32_t b) { return reinterpret_cast<XpsSeg*>(static_cast<uint8_t*>(x.seg) + x.seg_prefix[b] * XPS_SEG_BYTES); }
+__device__ __forceinline__ void xps_segment_of(const XpsTables& x, uint32_t flat, uint32_t& b, uint32_t& k)
+{
+	uint32_t lo = 0, hi = x.n_big;
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (x.seg_prefix[mid] <= flat) { lo = mid; } else { hi = mid; } }
+	b = lo; k = flat - (uint32_t)x.seg_prefix[lo];
+}
+
+__global__ void xps_init_kernel(XpsTables x) { const uint32_t b = blockIdx.x * 256u + threadIdx.x; if (b < x.n_big) { x.mode[b] = 1u; } }
+
+// ROUND 0: every segment (speculative start); ROUND > 0: the segments the check marked, from the exit of the segment before
+template <int ROUND>
+__global__ __launch_bounds__(64) void xps_walk_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, XpsTables x)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t s_in[2u * XPT_INB];
+	const uint32_t lane = threadIdx.x;
+	uint32_t b, k;
+	xps_segment_of(x, blockIdx.x, b, k);
+	const uint32_t u = x.unit[b];
+	XpsSeg* __restrict__ seg = xps_segs(x, b);
+	const uint32_t nseg = (uint32_t)(x.seg_prefix[b + 1] - x.seg_prefix[b]);
+	if (ROUND > 0 && (x.mode[b] != 1u || !seg[k].redo)) { return; }     // (mode 1: rounds still running)
+	const uint32_t n = (uint32_t)bt.in_len[u];
+	const uint8_t* src = d_in + bt.in_off[u];
+	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
+	const uint8_t* ab = src - a0;
+	const uint32_t endq = a0 + n;
+	const uint32_t lim = k + 1u == nseg ? 0xFFFFFFFFu : a0 + (k + 1u) * x.seg_bytes;
+	uint32_t loaded; uint4 nxt;
+	XptWalk W = { a0, 0, 0, 0, 0, false, -3, false };
+	if (ROUND == 0 && k > 0) {
+		W.ip = a0 + k * x.seg_bytes - x.warm_bytes;
+		XPT_RING_START(W.ip)
+		xpt_walk<false>(s_in, ab, endq, loaded, nxt, W, a0 + k * x.seg_bytes, ~(u64)0, nullptr, lane);
+		if (!W.running) {                                                  // it fell over before the segment: nothing to offer
+			if (lane == 0) { seg[k].l_ip = 0xFFFFFFFFu; seg[k].l_hp = 0; seg[k].e_ip = 0; seg[k].e_hp = 0; seg[k].kind = 2u; seg[k].ntok = 0; seg[k].nout = 0; seg[k].redo = 0; }
+			return;
+		}
+		W.op = 0; W.tc = 0;
+	} else if (ROUND > 0) {
+		if (seg[k - 1u].kind != 0u) { if (lane == 0) { seg[k].kind = 2u; seg[k].redo = 0; seg[k].l_ip = 0xFFFFFFFFu; } return; }   // nothing to start from
+		W.ip = seg[k - 1u].e_ip;
+		const uint32_t hp = seg[k - 1u].e_hp;
+		W.have_half = hp != 0xFFFFFFFFu; W.hp = W.have_half ? hp : 0u; W.half = W.have_half ? ab[hp] : 0u;
+		XPT_RING_START(W.ip)
+	} else { XPT_RING_START(a0) }
+	const uint32_t l_ip = W.ip, l_hp = W.have_half ? W.hp : 0xFFFFFFFFu;
+	xpt_walk<false>(s_in, ab, endq, loaded, nxt, W, lim, ~(u64)0, nullptr, lane);
+	if (lane == 0) {
+		seg[k].l_ip = l_ip; seg[k].l_hp = l_hp; seg[k].e_ip = W.ip; seg[k].e_hp = W.have_half ? W.hp : 0xFFFFFFFFu;
+		seg[k].kind = W.running ? 0u : (W.status == 0 ? 1u : 2u); seg[k].ntok = W.tc; seg[k].nout = W.op; seg[k].redo = 0;
+	}
+}
+
+// which segments hold; LAST: sums, verdict (mode 2 = done by segments, 0 = the one-wave walk takes the stream) and the caller's results
+template <bool LAST>
+__global__ __launch_bounds__(256) void xps_check_kernel(BatchTables bt, XpsTables x, u64* __restrict__ ntok, u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
+{
+	__shared__ uint32_t s_bad;
+	__shared__ u64 s_t[4], s_o[4];
+	const uint32_t tid = threadIdx.x, b = blockIdx.x, u = x.unit[b];
+	XpsSeg* __restrict__ seg = xps_segs(x, b);
+	const uint32_t nseg = (uint32_t)(x.seg_prefix[b + 1] - x.seg_prefix[b]);
+	if (x.mode[b] != 1u) { return; }
+	if (tid == 0) { s_bad = 0; }
+	__syncthreads();
+	uint32_t bad = 0;                                                    // 1: some segment has to be walked again; 2: no use
+	for (uint32_t k = tid; k < nseg; k += 256u) {
+		bool redo = false;
+		if (k > 0) {
+			const XpsSeg p = seg[k - 1u];
+			if (p.kind != 0u) { bad |= 2u; }                               // the stream ends (well or not) before its last segment: not our case
+			else if (seg[k].l_ip != p.e_ip || seg[k].l_hp != p.e_hp) { redo = true; bad |= 1u; }
+		}
+		if (k + 1u == nseg && seg[k].kind != 1u && !redo) { bad |= seg[k].kind == 2u ? 2u : 2u; }   // the last segment must end the stream, and well
+		seg[k].redo = redo ? 1u : 0u;
+	}
+	if (bad) { atomicOr(&s_bad, bad); }
+	__syncthreads();
+	const uint32_t verdict = s_bad;
+	if (!LAST) {
+		if (tid == 0 && (verdict & 2u) && !(verdict & 1u)) { x.mode[b] = 0u; }   // (while segments are still being redone, a bad kind may be that of a wrong walk)
+		return;
+	}
+	if (verdict) { if (tid == 0) { x.mode[b] = 0u; } return; }
+	// all segments hold: where their tokens and bytes go
+	u64 tcar = 0, ocar = 0;
+	for (uint32_t k0 = 0; k0 < nseg; k0 += 256u) {
+		const uint32_t k = k0 + tid;
+		const u64 t = k < nseg ? seg[k].ntok : 0, o = k < nseg ? seg[k].nout : 0;
+		u64 ti = t, oi = o;
+		#pragma unroll
+		for (uint32_t d = 1; d < 64u; d <<= 1) { const u64 a = __shfl_up(ti, d, 64), c = __shfl_up(oi, d, 64); if ((tid & 63u) >= d) { ti += a; oi += c; } }
+		if ((tid & 63u) == 63u) { s_t[tid >> 6] = ti; s_o[tid >> 6] = oi; }
+		__syncthreads();
+		u64 tb = tcar, ob = ocar, tt = 0, ot = 0;
+		for (uint32_t w = 0; w < 4u; ++w) { if (w < (tid >> 6)) { tb += s_t[w]; ob += s_o[w]; } tt += s_t[w]; ot += s_o[w]; }
+		if (k < nseg) { seg[k].tbase = tb + ti - t; seg[k].obase = ob + oi - o; }
+		tcar += tt; ocar += ot;
+		__syncthreads();
+	}
+	if (tid == 0) {
+		const bool fits = ocar <= bt.out_cap[u];                           // beyond the capacity: the one-wave walk says where and how
+		x.mode[b] = fits ? 2u : 0u;
+		if (fits) { d_status[u] = 0; d_out_len[u] = ocar; ntok[u] = tcar; x.done[u] = XPS_DONE; }
+	}
+}
+
+__global__ __launch_bounds__(64) void xps_emit_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, XpsTables x, const u64* __restrict__ tok_prefix, uint32_t* __restrict__ tok)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t s_in[2u * XPT_INB];
+	const uint32_t lane = threadIdx.x;
+	uint32_t b, k;
+	xps_segment_of(x, blockIdx.x, b, k);
+	if (x.mode[b] != 2u) { return; }
+	const uint32_t u = x.unit[b];
+	const XpsSeg* __restrict__ seg = xps_segs(x, b);
+	const uint32_t nseg = (uint32_t)(x.seg_prefix[b + 1] - x.seg_prefix[b]);
+	const uint32_t n = (uint32_t)bt.in_len[u];
+	const uint8_t* src = d_in + bt.in_off[u];
+	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
+	const uint8_t* ab = src - a0;
+	const uint32_t endq = a0 + n;
+	const uint32_t lim = k + 1u == nseg ? 0xFFFFFFFFu : a0 + (k + 1u) * x.seg_bytes;
+	uint32_t loaded; uint4 nxt;
+	XptWalk W = { seg[k].l_ip, seg[k].obase, seg[k].tbase, 0, 0, false, -3, false };
+	if (seg[k].l_hp != 0xFFFFFFFFu) { W.have_half = true; W.hp = seg[k].l_hp; W.half = ab[W.hp]; }
+	XPT_RING_START(W.ip)
+	xpt_walk<true>(s_in, ab, endq, loaded, nxt, W, lim, bt.out_cap[u], tok + tok_prefix[u], lane);
+	// the same walk as the one that was counted, now with the tests that need the output offset: anything else than the counted end is a failed test
+	const bool same = W.ip == seg[k].e_ip && W.tc == seg[k].tbase + seg[k].ntok && W.op == seg[k].obase + seg[k].nout && (W.running ? seg[k].kind == 0u : (seg[k].kind == 1u && W.status == 0));
+	if (!same && lane == 0) { x.done[u] = 0; }                            // the one-wave walk takes the stream after all
 }
 
 void launch_xpress_decompress_tokens(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
-                                     uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase, u64 lzg_min_cap);
+                                     uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase, u64 lzg_min_cap, const XpsTables& x);
 
 // ===================================================================================================================
 // Xpress+Huffman: one wave per buffer
@@ -1647,10 +1816,25 @@ void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const Ba
 }
 
 void launch_xpress_decompress_tokens(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
-                                     uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase, u64 lzg_min_cap)
+                                     uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase, u64 lzg_min_cap, const XpsTables& x)
 {
 	if (bt.n_units == 0) { return; }
-	if (phase == 0) { hipLaunchKernelGGL(xpt_parse_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, tok_prefix, tok, ntok, d_out_len, d_status); return; }
+	if (phase < 0) {                                                     // large streams by segments (nothing to do without any): -1 speculative walks, -2 one round of check + walk again, -3 verdict + tokens
+		if (!x.n_big) { return; }
+		if (phase == -1) {
+			(void)hipMemsetAsync(x.done, 0, (size_t)bt.n_units * 4u, st);
+			hipLaunchKernelGGL(xps_init_kernel, dim3((x.n_big + 255u) / 256u), dim3(256), 0, st, x);
+			hipLaunchKernelGGL(xps_walk_kernel<0>, dim3(x.n_seg), dim3(64), 0, st, d_in, bt, x);
+		} else if (phase == -2) {
+			hipLaunchKernelGGL(xps_check_kernel<false>, dim3(x.n_big), dim3(256), 0, st, bt, x, ntok, d_out_len, d_status);
+			hipLaunchKernelGGL(xps_walk_kernel<1>, dim3(x.n_seg), dim3(64), 0, st, d_in, bt, x);
+		} else {
+			hipLaunchKernelGGL(xps_check_kernel<true>, dim3(x.n_big), dim3(256), 0, st, bt, x, ntok, d_out_len, d_status);
+			hipLaunchKernelGGL(xps_emit_kernel, dim3(x.n_seg), dim3(64), 0, st, d_in, bt, x, tok_prefix, tok);
+		}
+		return;
+	}
+	if (phase == 0) { hipLaunchKernelGGL(xpt_parse_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, tok_prefix, tok, ntok, d_out_len, d_status, (const uint32_t*)(x.n_big ? x.done : nullptr)); return; }
 	static bool attr_set = false;
 	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_copy_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzbLds)); attr_set = true; }
 	if (phase == 1) { hipLaunchKernelGGL(lz_copy_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes(), lzg_min_cap); }

@@ -63,9 +63,24 @@ void launch_lzd_finalize(hipStream_t st, const BatchTables& bt, const LzdBufs& b
 
 // Xpress: one wave per stream
 void launch_xpress_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* d_out, u64* d_out_len, int32_t* d_status);
-// the same through 32-bit tokens: phase 0 = xpt_parse_kernel (a flag word at a time), 1 = lz_copy_kernel, 2 = lz_copy_block_kernel
+// large Xpress streams by segments (decompress.hip, xps_*): plan tables + scratch
+#define XPS_SEG    32768u                                 // input bytes per segment (12 whole files, segment / warm-up KiB: 128/64 26.1 ms, 64/64 19.3, 32/32 15.5, 32/16 15.2; 16/16 needs more rounds than there are)
+#define XPS_WARM   32768u                                 // a speculative walk starts this far before its segment
+#define XPS_SEG_BYTES 64u
+#define XPS_MIN_IN (512u << 10)                           // streams with at least this much input
+#define XPS_ROUNDS 32u                                    // rounds of "walk the segments again that do not hold"
+struct XpsTables {
+	const uint32_t* unit;          // n_big: the streams taken
+	const u64* seg_prefix;         // n_big + 1: first segment of each
+	void*     seg;                 // per segment: 64 bytes of state (XpsSeg)
+	uint32_t* mode;                // per stream taken: 1 rounds running, 2 done by segments, 0 left to the one-wave walk
+	uint32_t* done;                // per unit of the batch: XPS_DONE when the one-wave walk has nothing to do
+	uint32_t  n_big, n_seg;
+	uint32_t  seg_bytes, warm_bytes; // input bytes per segment; a speculative walk starts this far before its segment (<= seg_bytes)
+};
+// the same through 32-bit tokens: phase -1 = the segment kernels, 0 = xpt_parse_kernel (a flag word at a time), 1 = lz_copy_kernel, 2 = lz_copy_block_kernel
 void launch_xpress_decompress_tokens(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
-                                     uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase, u64 lzg_min_cap);
+                                     uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase, u64 lzg_min_cap, const XpsTables& x);
 
 // Xpress+Huffman, in phases: 0 mark candidate chunk starts, 1 walk every candidate as one chunk, 2 chain check per buffer, 3 tokens of the
 // accepted chunks, 4 serial walk of the buffers the speculation could not do, 5 tokens -> bytes. tok_prefix[u] = first token slot of unit u,

@@ -229,13 +229,15 @@ def test_large_units_get_their_bytes_from_all_cus(oracle, gpu_ctx, fmt):
     assert all(s == 0 for s in st)
     caps = [len(u) for u in units]
     caps[1] += 3 << 20                                            # room for 3 MiB more than comes out
-    streams = list(comp) + [comp[3][: len(comp[3]) // 2]]         # half a stream: an error (or a shorter output) next to the good ones
-    caps.append(len(units[3]))
+    streams = list(comp) + [comp[3][: len(comp[3]) // 2], comp[3], comp[4]]   # half a stream: an error (or a shorter output) next to the good ones;
+    caps += [len(units[3]), len(units[3]) - 1, len(units[4]) // 3]            # and two whose output does not fit
     back, st2 = m.decompress_units(f, streams, caps, ctx=gpu_ctx)
     for i, u in enumerate(units):
         assert st2[i] == 0 and back[i] == u, (fmt, i, st2[i], len(back[i]), len(u))
-    so, oo, _ = oracle.oracle_decompress_ex(f, streams[-1], caps[-1])
-    assert st2[-1] == so and (so != 0 or back[-1] == oo)
+    for j in (-3, -2, -1):
+        so, oo, _ = oracle.oracle_decompress_ex(f, streams[j], caps[j])
+        assert st2[j] == so and (so != 0 or back[j] == oo), (fmt, j, st2[j], so)
+    assert st2[-2] == -5 and st2[-1] == -5
     opened = (C.c_uint32 * 33)()
     gpu_ctx.lib.mscomp_amd_debug_lzg_open.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
     assert gpu_ctx.lib.mscomp_amd_debug_lzg_open(gpu_ctx._h, sum(c + 64 for c in caps if c >= (1 << 20)), opened) == 0
