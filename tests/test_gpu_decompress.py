@@ -232,14 +232,33 @@ def test_large_units_get_their_bytes_from_all_cus(oracle, gpu_ctx, fmt):
     streams = list(comp) + [comp[3][: len(comp[3]) // 2], comp[3], comp[4]]   # half a stream: an error (or a shorter output) next to the good ones;
     caps += [len(units[3]), len(units[3]) - 1, len(units[4]) // 3]            # and two whose output does not fit
     back, st2 = m.decompress_units(f, streams, caps, ctx=gpu_ctx)
+    # (the counters of THIS batch: read before the next decompression overwrites them)
+    opened = (C.c_uint32 * 33)()
+    gpu_ctx.lib.mscomp_amd_debug_lzg_open.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    assert gpu_ctx.lib.mscomp_amd_debug_lzg_open(gpu_ctx._h, sum(c + 64 for c in caps if c >= (1 << 20)), opened) == 0
+    opened = list(opened)
+    assert opened[0] > 1_000_000 and 0 in opened and all(x == 0 for x in opened[opened.index(0):])   # the path ran, took several passes, and ended
     for i, u in enumerate(units):
         assert st2[i] == 0 and back[i] == u, (fmt, i, st2[i], len(back[i]), len(u))
     for j in (-3, -2, -1):
         so, oo, _ = oracle.oracle_decompress_ex(f, streams[j], caps[j])
         assert st2[j] == so and (so != 0 or back[j] == oo), (fmt, j, st2[j], so)
     assert st2[-2] == -5 and st2[-1] == -5
-    opened = (C.c_uint32 * 33)()
-    gpu_ctx.lib.mscomp_amd_debug_lzg_open.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
-    assert gpu_ctx.lib.mscomp_amd_debug_lzg_open(gpu_ctx._h, sum(c + 64 for c in caps if c >= (1 << 20)), opened) == 0
-    opened = list(opened)
-    assert opened[0] > 1_000_000 and 0 in opened and all(x == 0 for x in opened[opened.index(0):])   # the path ran, took several passes, and ended
+    # large streams with a few bytes changed, anywhere: whatever the segment walks make of them, status and bytes are those of the checker
+    import random
+    rnd = random.Random(5)
+    bad = []
+    for src_i in (3, 4, 2):
+        for _ in range(6):
+            b = bytearray(comp[src_i])
+            for _ in range(rnd.randint(1, 4)):
+                b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+            bad.append((bytes(b), len(units[src_i]) + rnd.choice((0, 0, 4096))))
+    outs, sts = m.decompress_units(f, [b for b, _ in bad], [c for _, c in bad], ctx=gpu_ctx)
+    n_judged = 0
+    for (stream, cap), out, st in zip(bad, outs, sts):
+        so, oo, undefined = oracle.oracle_decompress_ex(f, stream, cap)
+        if not undefined:
+            assert st == so and (so != 0 or out == oo), (fmt, len(stream), cap, st, so)
+            n_judged += 1
+    assert n_judged >= 12
