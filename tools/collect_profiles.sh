@@ -2,7 +2,7 @@
 # Run on the GPU box (through gpurun): everything profiles/<tag>_* is made of. Output: gpurun_out/prof_<tag>/, condensed by
 # tools/update_profiles.py into profiles/.
 #   usage: bash tools/collect_profiles.sh r02 [quick]
-#  1. the default bench line;
+#  1. (last, so that it carries the counters of this very run) the default bench line;
 #  2. rocprofv3 --kernel-trace --stats of the HEADLINE command (bench.py --no-extra: every launch of the dominant kernel is the
 #     headline workload, so its average duration is comparable with the HIP-event figure of the line) and of the full default command;
 #  3. HBM traffic: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (TCC counters do not fit one pass), per leg (tools/gpu_leg.py);
@@ -15,9 +15,7 @@ D=$R/gpurun_out/prof_$TAG
 mkdir -p $D
 cd /tmp && export TMPDIR=/tmp
 cd $R
-python bench.py 2> $D/bench.err | tail -1 > $D/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $D -o kt_head -- python bench.py --no-extra --no-cpu --steps 5 --warmup 1 2> $D/kt_head.err | tail -1 > $D/bench_headline_under_rocprof.json
-[ -n "$QUICK" ] || rocprofv3 --kernel-trace --stats --output-format csv -d $D -o kt_full -- python bench.py --no-cpu --steps 4 --warmup 1 2> $D/kt_full.err | tail -1 > $D/bench_full_under_rocprof.json
+rm -f $D/bench.json
 LEGS="config5:lznt1 config5:xpress config5:xpress_huff single:lznt1 single:xpress single:xpress_huff"
 [ -n "$QUICK" ] && LEGS="config5:lznt1"
 for leg in $LEGS; do
@@ -27,12 +25,17 @@ for leg in $LEGS; do
 done
 SQA="SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS"
 SQB="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS"
-SLEGS="single:lznt1 single:xpress single:xpress_huff"
+SLEGS="single:lznt1 single:xpress single:xpress_huff decompress:xpress decompress:xpress_huff"
 [ -n "$QUICK" ] && SLEGS="single:lznt1"
 for leg in $SLEGS; do
   t=${leg/:/_}
   rocprofv3 --kernel-trace --pmc $SQA --output-format csv -d $D -o sqa_$t -- python tools/gpu_leg.py $leg 3 > $D/sqa_$t.out 2>&1
   rocprofv3 --kernel-trace --pmc $SQB --output-format csv -d $D -o sqb_$t -- python tools/gpu_leg.py $leg 3 > $D/sqb_$t.out 2>&1
 done
-find $D -name "*.csv" | head -60
+# the counter summaries go into profiles/ of THIS copy of the repository first: the bench line below attaches them (roofline.traffic / .secondary)
+python tools/update_profiles.py $D $TAG > $D/update_on_box.log 2>&1
+python bench.py 2> $D/bench.err | tail -1 > $D/bench.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $D -o kt_head -- python bench.py --no-extra --no-cpu --steps 5 --warmup 1 2> $D/kt_head.err | tail -1 > $D/bench_headline_under_rocprof.json
+[ -n "$QUICK" ] || rocprofv3 --kernel-trace --stats --output-format csv -d $D -o kt_full -- python bench.py --no-cpu --steps 4 --warmup 1 2> $D/kt_full.err | tail -1 > $D/bench_full_under_rocprof.json
+find $D -name "*.csv" | head -80
 du -sh $D

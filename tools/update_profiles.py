@@ -24,18 +24,20 @@ def per_kernel(path):
     return {k: {c: (sum(x) / len(x), len(x)) for c, x in v.items()} for k, v in agg.items()}
 
 
-shutil.copy(os.path.join(src, "bench.json"), P("bench.json"))
+if os.path.exists(os.path.join(src, "bench.json")) and os.path.getsize(os.path.join(src, "bench.json")):
+    shutil.copy(os.path.join(src, "bench.json"), P("bench.json"))
 for f in ("bench_headline_under_rocprof.json", "bench_full_under_rocprof.json"):
     if os.path.exists(os.path.join(src, f)) and os.path.getsize(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), P(f))
-txt = stats_table(os.path.join(src, "kt_head_kernel_stats.csv"),
-                  "rocprofv3 --kernel-trace --stats -- python bench.py --no-extra --no-cpu --steps 5 --warmup 1   (the headline leg alone: LZNT1 over BASELINE configs[4])")
-if os.path.exists(os.path.join(src, "kt_full_kernel_stats.csv")):
-    txt += "\n" + stats_table(os.path.join(src, "kt_full_kernel_stats.csv"),
-                              "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --steps 4 --warmup 1   (all legs: a kernel's launches mix workloads)")
-open(P("kernel_stats.txt"), "w").write(txt)
+if os.path.exists(os.path.join(src, "kt_head_kernel_stats.csv")):
+    txt = stats_table(os.path.join(src, "kt_head_kernel_stats.csv"),
+                      "rocprofv3 --kernel-trace --stats -- python bench.py --no-extra --no-cpu --steps 5 --warmup 1   (the headline leg alone: LZNT1 over BASELINE configs[4])")
+    if os.path.exists(os.path.join(src, "kt_full_kernel_stats.csv")):
+        txt += "\n" + stats_table(os.path.join(src, "kt_full_kernel_stats.csv"),
+                                  "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --steps 4 --warmup 1   (all legs, compressors and decompressors: a kernel's launches mix workloads)")
+    open(P("kernel_stats.txt"), "w").write(txt)
 
-WL = {"config5": "config5_n1", "single": "single_gpu"}
+WL = {"config5": "config5_n1", "single": "single_gpu", "decompress": "decompress_units64k"}
 traffic = {}
 for f in sorted(glob.glob(os.path.join(src, "fetch_*_counter_collection.csv"))):
     leg = os.path.basename(f)[len("fetch_"):-len("_counter_collection.csv")]
@@ -76,5 +78,5 @@ json.dump({"how": "rocprofv3 --kernel-trace --pmc <8 SQ counters> -- python tool
                   "SQ_ACTIVE_INST_ANY/_VALU/_SCA/_LDS; B: SQ_INSTS_VALU/_SALU/_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS). "
                   "Averages per launch. wave-time fractions are shares of SQ_WAVE_CYCLES (WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES); lds_pipe_busy = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES.",
            "workloads": sq}, open(P("sq_counters.json"), "w"), indent=1)
-r = json.load(open(P("bench.json")))
+r = json.load(open(P("bench.json"))) if os.path.exists(P("bench.json")) else {"value": None, "roofline": {"frac": None, "traffic": None}}
 print(r["value"], r["roofline"]["frac"], r["roofline"]["traffic"], r["roofline"].get("secondary", {}) and r["roofline"]["secondary"].get("derived", {}).get("bound"))
