@@ -80,3 +80,23 @@ json.dump({"how": "rocprofv3 --kernel-trace --pmc <8 SQ counters> -- python tool
            "workloads": sq}, open(P("sq_counters.json"), "w"), indent=1)
 r = json.load(open(P("bench.json"))) if os.path.exists(P("bench.json")) else {"value": None, "roofline": {"frac": None, "traffic": None}}
 print(r["value"], r["roofline"]["frac"], r["roofline"]["traffic"], r["roofline"].get("secondary", {}) and r["roofline"]["secondary"].get("derived", {}).get("bound"))
+
+# the decompression legs of the same bench line, kernel by kernel (HIP events), with the SQ shares of the decoder kernels
+if "extra" in r and "decompress" in r["extra"]:
+    out = ["# decompression legs of profiles/%s_bench.json (bench.py: HIP events around every kernel, ms per pass; output MB/s; cpu = the reference's decoder on the host cores named)" % tag]
+    for group in ("decompress", "decompress_files"):
+        for codec, v in r["extra"].get(group, {}).items():
+            cb = v.get("cpu_baseline", {})
+            out.append("%-17s %-14s %-70s %9.3f ms/pass %10.1f MB/s   cpu %s MB/s on %s threads (%s)   round trip %s" %
+                       (group, codec, v["workload"][:70], v["ms_per_step"], v["MB_per_s"], cb.get("value"), cb.get("cores"), cb.get("kind"), "ok" if v["round_trip_ok"] else "BAD"))
+            for k, ms in v["kernels_ms_per_step"].items():
+                out.append("       %-28s %10.4f ms" % (k, ms))
+    out.append("")
+    out.append("# SQ counters of the decoder kernels on the 3 239-unit legs (profiles/%s_sq_counters.json, workload decompress_units64k): shares of wave time, issue mix, LDS pipe" % tag)
+    for k, v in sq.get("decompress_units64k", {}).items():
+        if any(x in k for x in ("xpt_", "lz_copy", "xhc_", "xhd_", "lzg_", "xps_")):
+            d = v["derived"]
+            out.append("%-34s %-12s waiting %.2f  issue-stalled %.2f  issuing %.2f | valu %.2f salu %.2f lds %.2f | LDS pipe busy %.2f | %s" %
+                       (k.replace("msc::", ""), v["codec"], d["wave_time_waiting_frac"], d["wave_time_issue_stalled_frac"], d["wave_time_issuing_frac"],
+                        d["issue_mix"]["valu"], d["issue_mix"]["salu"], d["issue_mix"]["lds"], d["lds_pipe_busy_frac"], d["bound"]))
+    open(P("decompress_kernels.txt"), "w").write("\n".join(out) + "\n")
