@@ -57,6 +57,7 @@ struct mscomp_amd_ctx {
 	DevBuf wrec, sbrec;                                // ... state / counts / prefixes per window (6 x u32), per super-block (tot 4 x u32, pre 3 x u64, seams)
 	DevBuf tokbits, counts, extra, lens, codes, fb_list, fbflag;   // Xpress+Huffman per-chunk scratch
 	DevBuf dz_cin, dz_csize, dz_unit;                  // LZNT1 decompression: header offset / decoded size per chunk slot, per-unit records
+	DevBuf dz_scr;                                     // Xpress+Huffman decompression: token scratch of the candidates of multi-chunk buffers
 	DevBuf dz_tok, dz_ntok, dz_xhc;                    // Xpress+Huffman decompression: 32-bit tokens of every unit, token counts, candidate chunk records
 	DevBuf lzg_bsum, lzg_dir, lzg_words;               // tokens -> bytes of large units by all CUs (lzglobal.hip): token block sums, tile directory, a word per output byte + pass counters
 	DevBuf xps_buf;                                    // large Xpress streams by segments: segment records | mode per stream | done per unit
@@ -69,7 +70,7 @@ struct mscomp_amd_ctx {
 	std::vector<DevBuf*> bufs()
 	{
 		return { &slots, &slot_size, &prefix, &tile_sums, &links, &lasthead, &mlen3, &moff, &wtok, &wmat, &wfar, &wrec, &sbrec,
-		         &tokbits, &counts, &extra, &lens, &codes, &fb_list, &fbflag, &dz_cin, &dz_csize, &dz_unit, &dz_tok, &dz_ntok, &dz_xhc,
+		         &tokbits, &counts, &extra, &lens, &codes, &fb_list, &fbflag, &dz_cin, &dz_csize, &dz_unit, &dz_tok, &dz_ntok, &dz_xhc, &dz_scr,
 		         &lzg_bsum, &lzg_dir, &lzg_words, &xps_buf, &cp_tab, &one_in, &one_out, &one_meta };
 	}
 	mscomp_amd_ctx() { for (DevBuf* b : bufs()) { b->epoch = &epoch; } }
@@ -85,6 +86,7 @@ struct mscomp_amd_plan {
 	DevBuf tables;                                     // in_off | out_off | chunk_prefix
 	DevBuf tokpre;                                     // decompression by tokens: first token slot | first candidate slot of every unit (2 x (n_units + 1) u64)
 	uint32_t xhc_slots = 0;                            // candidate chunk slots of the batch
+	uint64_t xhc_scr = 0;                              // token-scratch slots (candidates of multi-chunk buffers), 0 = none
 	DevBuf lzg_tab;                                    // lzglobal.hip: unit (u32 x n_big, padded) | tb_prefix | tile_prefix | word_prefix (u64 x (n_big + 1) each)
 	uint32_t lzg_big = 0, lzg_tb = 0, lzg_tiles = 0;   // units taken by that path (0: not used), their token blocks and tiles
 	uint64_t lzg_words = 0;
@@ -273,21 +275,27 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 		}
 		if (okd && format == MSCOMP_XPRESS_HUFF) {
 			// a symbol gives one token, a match one more per 32766 bytes; no token without an output byte
-			std::vector<uint64_t> tp(2 * (n_units + 1));
-			uint64_t slots = 0, cands = 0;
+			std::vector<uint64_t> tp(3 * (n_units + 1));                  // first token slot | first candidate slot | first token-scratch slot of every unit
+			uint64_t slots = 0, cands = 0, scr = 0;
 			for (size_t i = 0; i < n_units; ++i) {
-				tp[i] = slots; tp[n_units + 1 + i] = cands;
+				tp[i] = slots; tp[n_units + 1 + i] = cands; tp[2 * (n_units + 1) + i] = scr;
 				const uint64_t by_in = 8 * in_len[i] + out_cap[i] / 32766u + 1, cnt = out_cap[i] < by_in ? out_cap[i] : by_in;
 				slots += cnt + 64;
 				// candidate chunk starts: a chunk gives 65536 bytes and takes at least 260; a quarter more for windows that only look like a table
 				const uint64_t by_out = out_cap[i] / 65536u + 2, by_len = in_len[i] / 260u + 1, most = by_out < by_len ? by_out : by_len;
 				cands += most + most / 4 + 2;
+				if (out_cap[i] > 65536u) { scr += most + most / 4 + 2; }   // a buffer of several chunks: its candidates keep their tokens (no second walk)
 			}
-			tp[n_units] = slots; tp[2 * n_units + 1] = cands;
+			tp[n_units] = slots; tp[2 * n_units + 1] = cands; tp[3 * n_units + 2] = scr;
+			{	// ... if that scratch is affordable (MSCOMP_AMD_XHC_SCR_MAX_MB, default 8 GiB; 0 = always walk twice)
+				static const uint64_t scr_budget = [] { const char* e = getenv("MSCOMP_AMD_XHC_SCR_MAX_MB"); const long long v = e ? atoll(e) : 8192; return (uint64_t)(v < 0 ? 0 : v) << 20; }();
+				if (scr * XHC_SCR * 4 > scr_budget) { for (size_t i = 0; i <= n_units; ++i) { tp[2 * (n_units + 1) + i] = 0; } scr = 0; }
+				p->xhc_scr = scr;
+			}
 			if (cands > 0x7FFFFFF0u) { p->tables.release(); delete p; return MSCOMP_ARG_ERROR; }
 			p->xhc_slots = (uint32_t)cands;
 			okd = p->tokpre.reserve(tp.size() * 8) && c->dz_tok.reserve(slots * 4 + 256) && c->dz_ntok.reserve((n_units + 1) * 8) &&
-			      c->dz_xhc.reserve(((size_t)n_units + 1) * 8 + (size_t)cands * (4 * 4 + 3 * 8) + 64);
+			      c->dz_xhc.reserve(((size_t)n_units + 1) * 8 + (size_t)cands * (4 * 4 + 3 * 8) + 64) && (scr == 0 || c->dz_scr.reserve(scr * XHC_SCR * 4 + 64));
 			if (okd && (hipMemcpyAsync(p->tokpre.p, tp.data(), tp.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
 			            hipStreamSynchronize(c->stream) != hipSuccess)) { p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_ERRNO; }
 		}
@@ -495,7 +503,8 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 		case MSCOMP_XPRESS_HUFF: {
 			const u64* tp = static_cast<const u64*>(p->tokpre.p); uint32_t* tok = static_cast<uint32_t*>(c->dz_tok.p); u64* ntok = static_cast<u64*>(c->dz_ntok.p);
 			const u64* cp = tp + (p->n_units + 1u);
-			XhcBufs xb;
+			XhcBufs xb = {};
+			if (p->xhc_scr) { xb.scr_prefix = tp + 2 * (p->n_units + 1u); xb.scr_tok = static_cast<uint32_t*>(c->dz_scr.p); }
 			{
 				const size_t nu = (size_t)p->n_units + 1, ns = p->xhc_slots;
 				uint8_t* q = static_cast<uint8_t*>(c->dz_xhc.p);

@@ -1258,17 +1258,23 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 	const uint32_t idx = slot - (uint32_t)cand_prefix[u];
 	const uint32_t have = xb.cand_cnt[u], room = (uint32_t)(cand_prefix[u + 1] - cand_prefix[u]);
 	if (idx >= (have < room ? have : room)) { return; }
-	if (PASS == 2 && (xb.mode[u] != XHC_SPEC || xb.tok_off[slot] == ~(u64)0 || xb.cand_pos[slot] == 0)) { return; }
+	// a buffer of several chunks may have token scratch: its candidates keep their tokens there in PASS 1 (xhc_gather_kernel moves those of the
+	// accepted chunks to their place), and PASS 2 is left with the chunks whose tokens did not fit (state bit 4)
+	const bool has_scr = xb.scr_prefix != nullptr && xb.scr_prefix[u + 1] > xb.scr_prefix[u];
+	if (PASS == 2 && (xb.mode[u] != XHC_SPEC || xb.tok_off[slot] == ~(u64)0 || xb.cand_pos[slot] == 0 || (has_scr && !(xb.res_state[slot] & 4u)))) { return; }
 	const bool writing = PASS == 2 || xb.cand_pos[slot] == 0;
+	const bool scr = PASS == 1 && !writing && has_scr;
+	bool scr_ok = true;
 	const uint32_t at = xb.cand_pos[slot];
 	const uint32_t n = (uint32_t)bt.in_len[u];
 	const uint8_t* src = d_in + bt.in_off[u];
 	const u64 tok_at = PASS == 2 ? xb.tok_off[slot] : (u64)0;
-	uint32_t* __restrict__ mytok = tok + tok_prefix[u] + tok_at;
-	const u64 tokcap = tok_prefix[u + 1] - tok_prefix[u] - tok_at;      // chunk 0 writes before the capacity is judged: never beyond the unit's slots
+	uint32_t* __restrict__ mytok = scr ? xb.scr_tok + (xb.scr_prefix[u] + idx) * (u64)XHC_SCR : tok + tok_prefix[u] + tok_at;
+	const u64 tokcap = scr ? (u64)XHC_SCR : tok_prefix[u + 1] - tok_prefix[u] - tok_at;   // chunk 0 writes before the capacity is judged: never beyond the unit's slots
+	const bool storing = writing || scr;
 	u64 reach = 0;
 	u64 nt = 0;                                                          // tokens so far
-	#define XHD_EMIT(w) { if (writing && lane == 0 && nt < tokcap) { mytok[nt] = (w); } ++nt; }
+	#define XHD_EMIT(w) { if (storing && lane == 0 && nt < tokcap) { mytok[nt] = (w); } ++nt; }
 	int32_t status = 1; u64 op = 0;                                      // 1 = running
 	// ---- input ring (see xpd_kernel) ----
 	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
@@ -1396,7 +1402,7 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 					const uint32_t rmax = wave_max_u32(rch);
 					if (rmax > reach) { reach = rmax; }
 					const u64 ti = nt + popc_below(mark);
-					if (writing && on && ti < tokcap) { mytok[ti] = lit ? (0x80000000u | sy) : (moff | (mlen << 16)); }
+					if (storing && on && ti < tokcap) { mytok[ti] = lit ? (0x80000000u | sy) : (moff | (mlen << 16)); }
 					nt += (uint32_t)__builtin_popcountll(mark);
 					op += adv; prod += adv;
 					// Bitstream.h:61-75: a word is pulled whenever fewer than 16 bits are left
@@ -1441,8 +1447,8 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 				XHD_SKIP(ob)
 				if (off > op && off - op > reach) { reach = off - op; }   // :120 is judged when the chunk's place in the output is known
 				op += len; prod = prod + len < prod ? 0xFFFFFFFFu : prod + len;
-				if (writing) { while (len > LZT_MAXLEN) { XHD_EMIT(off | (LZT_MAXLEN << 16)) len -= LZT_MAXLEN; } }
-				else if (len > LZT_MAXLEN) { nt += (len - 1u) / LZT_MAXLEN; len = LZT_MAXLEN; }   // only counted: a candidate that is no chunk may "hold" gigabyte matches
+				if (writing || (scr && len <= 4u * LZT_MAXLEN)) { while (len > LZT_MAXLEN) { XHD_EMIT(off | (LZT_MAXLEN << 16)) len -= LZT_MAXLEN; } }
+				else if (len > LZT_MAXLEN) { nt += (len - 1u) / LZT_MAXLEN; len = LZT_MAXLEN; scr_ok = false; }   // only counted: a candidate that is no chunk may "hold" gigabyte matches
 				XHD_EMIT(off | (len << 16))
 			}
 		}
@@ -1463,7 +1469,7 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 	#undef XHD_DECODE
 	#undef XHD_EMIT
 	if (PASS == 1 && lane == 0) {
-		xb.res_state[slot] = status == 1 ? state : 2u; xb.res_end[slot] = next_at; xb.res_prod[slot] = op; xb.res_ntok[slot] = nt;
+		xb.res_state[slot] = (status == 1 ? state : 2u) | ((scr && (!scr_ok || nt > XHC_SCR)) ? 4u : 0u); xb.res_end[slot] = next_at; xb.res_prod[slot] = op; xb.res_ntok[slot] = nt;
 		xb.res_reach[slot] = reach > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)reach;
 	}
 }
@@ -1490,7 +1496,7 @@ __global__ __launch_bounds__(64) void xhc_chain_kernel(BatchTables bt, const u64
 		}
 		if (found == 0xFFFFFFFFu) { break; }
 		const u64 sl = base + found;
-		const uint32_t st = xb.res_state[sl], reach = xb.res_reach[sl], end = xb.res_end[sl];
+		const uint32_t st = xb.res_state[sl] & 3u, reach = xb.res_reach[sl], end = xb.res_end[sl];
 		if (st == 2u || reach == 0xFFFFFFFFu || (u64)reach > out) { break; }     // not a chunk, or a match reaches in front of the buffer (:120)
 		if (lane == 0) { xb.tok_off[sl] = nt; }
 		out += xb.res_prod[sl]; nt += xb.res_ntok[sl];
@@ -1503,6 +1509,22 @@ __global__ __launch_bounds__(64) void xhc_chain_kernel(BatchTables bt, const u64
 		xb.mode[u] = success ? XHC_SPEC : XHC_SERIAL;
 		if (success) { d_status[u] = 0; d_out_len[u] = out; ntok[u] = nt; }
 	}
+}
+
+// the tokens of the accepted chunks of a buffer with token scratch: from where PASS 1 left them to their place in the buffer's token stream
+__global__ __launch_bounds__(256) void xhc_gather_kernel(BatchTables bt, const u64* __restrict__ tok_prefix, const u64* __restrict__ cand_prefix, XhcBufs xb, uint32_t* __restrict__ tok)
+{
+	const uint32_t slot = blockIdx.x;
+	const uint32_t u = seg_of_flat(cand_prefix, bt.n_units, slot);
+	const uint32_t idx = slot - (uint32_t)cand_prefix[u];
+	const uint32_t have = xb.cand_cnt[u], room = (uint32_t)(cand_prefix[u + 1] - cand_prefix[u]);
+	if (idx >= (have < room ? have : room)) { return; }
+	if (xb.scr_prefix == nullptr || xb.scr_prefix[u + 1] <= xb.scr_prefix[u]) { return; }
+	if (xb.mode[u] != XHC_SPEC || xb.tok_off[slot] == ~(u64)0 || xb.cand_pos[slot] == 0 || (xb.res_state[slot] & 4u)) { return; }
+	const uint32_t* __restrict__ from = xb.scr_tok + (xb.scr_prefix[u] + idx) * (u64)XHC_SCR;
+	uint32_t* __restrict__ to = tok + tok_prefix[u] + xb.tok_off[slot];
+	const uint32_t cnt = (uint32_t)xb.res_ntok[slot];
+	for (uint32_t i = threadIdx.x; i < cnt; i += 256u) { to[i] = from[i]; }
 }
 
 // ===================================================================================================================
@@ -1803,7 +1825,8 @@ void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const Ba
 	        hipLaunchKernelGGL(xhc_mark_kernel, dim3(bt.n_chunks), dim3(256), 0, st, d_in, bt, cand_prefix, xb); break;
 	case 1: hipLaunchKernelGGL(xhc_parse_kernel<1>, dim3(n_slots), dim3(64), 0, st, d_in, bt, tok_prefix, cand_prefix, xb, tok); break;
 	case 2: hipLaunchKernelGGL(xhc_chain_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, cand_prefix, xb, ntok, d_out_len, d_status); break;
-	case 3: hipLaunchKernelGGL(xhc_parse_kernel<2>, dim3(n_slots), dim3(64), 0, st, d_in, bt, tok_prefix, cand_prefix, xb, tok); break;
+	case 3: if (xb.scr_prefix) { hipLaunchKernelGGL(xhc_gather_kernel, dim3(n_slots), dim3(256), 0, st, bt, tok_prefix, cand_prefix, xb, tok); }
+	        hipLaunchKernelGGL(xhc_parse_kernel<2>, dim3(n_slots), dim3(64), 0, st, d_in, bt, tok_prefix, cand_prefix, xb, tok); break;
 	case 4: hipLaunchKernelGGL(xhd_parse_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, tok_prefix, tok, ntok, d_out_len, d_status, xb.mode); break;
 	default: {
 		static bool attr_set = false;

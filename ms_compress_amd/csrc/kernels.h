@@ -88,7 +88,9 @@ void launch_xpress_decompress_tokens(hipStream_t st, const uint8_t* d_in, const 
 #define XHC_TILE_BYTES 16384u
 enum { XHC_SERIAL = 1, XHC_SPEC = 2 };
 struct XhcBufs { uint32_t* cand_cnt; uint32_t* mode; uint32_t* cand_pos; uint32_t* res_end; uint32_t* res_reach; uint32_t* res_state;
-                 u64* res_prod; u64* res_ntok; u64* tok_off; };
+                 u64* res_prod; u64* res_ntok; u64* tok_off;
+                 const u64* scr_prefix; uint32_t* scr_tok; };   // token scratch: first scratch slot of every unit (n_units + 1; equal = none), XHC_SCR tokens per candidate
+#define XHC_SCR 65600u                                    // a candidate gives up to 65536 tokens before its 65536th byte
 void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const u64* tok_prefix, uint32_t* tok, u64* ntok,
                                    const u64* cand_prefix, uint32_t n_slots, const XhcBufs& xb,
                                    uint8_t* d_out, u64* d_out_len, int32_t* d_status, int phase, u64 lzg_min_cap);
