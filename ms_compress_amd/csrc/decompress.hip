@@ -923,13 +923,13 @@ __global__ __launch_bounds__(64) void xps_walk_kernel(const uint8_t* __restrict_
 	const uint32_t u = x.unit[b];
 	XpsSeg* __restrict__ seg = xps_segs(x, b);
 	const uint32_t nseg = (uint32_t)(x.seg_prefix[b + 1] - x.seg_prefix[b]);
-	if (ROUND > 0 && (x.mode[b] != 1u || !seg[k].redo)) { return; }     // (mode 1: rounds still running)
+	if (ROUND > 0 && (x.mode[b] != 1u || !seg[k].redo || seg[k - 1u].redo)) { return; }   // (mode 1: rounds still running.) Only the FIRST of a run of
+	                                                                     // segments that do not hold walks: it starts from a segment that holds, and goes on below
 	const uint32_t n = (uint32_t)bt.in_len[u];
 	const uint8_t* src = d_in + bt.in_off[u];
 	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
 	const uint8_t* ab = src - a0;
 	const uint32_t endq = a0 + n;
-	const uint32_t lim = k + 1u == nseg ? 0xFFFFFFFFu : a0 + (k + 1u) * x.seg_bytes;
 	uint32_t loaded; uint4 nxt;
 	XptWalk W = { a0, 0, 0, 0, 0, false, -3, false };
 	if (ROUND == 0 && k > 0) {
@@ -948,11 +948,20 @@ __global__ __launch_bounds__(64) void xps_walk_kernel(const uint8_t* __restrict_
 		W.have_half = hp != 0xFFFFFFFFu; W.hp = W.have_half ? hp : 0u; W.half = W.have_half ? ab[hp] : 0u;
 		XPT_RING_START(W.ip)
 	} else { XPT_RING_START(a0) }
-	const uint32_t l_ip = W.ip, l_hp = W.have_half ? W.hp : 0xFFFFFFFFu;
-	xpt_walk<false>(s_in, ab, endq, loaded, nxt, W, lim, ~(u64)0, nullptr, lane);
-	if (lane == 0) {
-		seg[k].l_ip = l_ip; seg[k].l_hp = l_hp; seg[k].e_ip = W.ip; seg[k].e_hp = W.have_half ? W.hp : 0xFFFFFFFFu;
-		seg[k].kind = W.running ? 0u : (W.status == 0 ? 1u : 2u); seg[k].ntok = W.tc; seg[k].nout = W.op; seg[k].redo = 0;
+	for (;;) {
+		const uint32_t lim = k + 1u == nseg ? 0xFFFFFFFFu : a0 + (k + 1u) * x.seg_bytes;
+		const uint32_t l_ip = W.ip, l_hp = W.have_half ? W.hp : 0xFFFFFFFFu;
+		xpt_walk<false>(s_in, ab, endq, loaded, nxt, W, lim, ~(u64)0, nullptr, lane);
+		const uint32_t e_hp = W.have_half ? W.hp : 0xFFFFFFFFu;
+		if (lane == 0) {
+			seg[k].l_ip = l_ip; seg[k].l_hp = l_hp; seg[k].e_ip = W.ip; seg[k].e_hp = e_hp;
+			seg[k].kind = W.running ? 0u : (W.status == 0 ? 1u : 2u); seg[k].ntok = W.tc; seg[k].nout = W.op; seg[k].redo = 0;
+		}
+		// a walk that comes from a segment that holds goes on through the segments behind it until it arrives where one of them had landed:
+		// a stretch that no speculative walk entered costs one round, however many segments it spans
+		if (ROUND == 0 || !W.running || k + 1u == nseg) { break; }
+		if (seg[k + 1u].l_ip == W.ip && seg[k + 1u].l_hp == e_hp) { break; }
+		++k; W.op = 0; W.tc = 0;
 	}
 }
 

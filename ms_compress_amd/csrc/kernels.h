@@ -64,11 +64,11 @@ void launch_lzd_finalize(hipStream_t st, const BatchTables& bt, const LzdBufs& b
 // Xpress: one wave per stream
 void launch_xpress_decompress(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* d_out, u64* d_out_len, int32_t* d_status);
 // large Xpress streams by segments (decompress.hip, xps_*): plan tables + scratch
-#define XPS_SEG    32768u                                 // input bytes per segment (12 whole files, segment / warm-up KiB: 128/64 26.1 ms, 64/64 19.3, 32/32 15.5, 32/16 15.2; 16/16 needs more rounds than there are)
-#define XPS_WARM   32768u                                 // a speculative walk starts this far before its segment
+#define XPS_SEG    16384u                                 // input bytes per segment (12 whole files, segment / warm-up KiB: 32/32 15.5 ms, 16/16 14.1, 8/8 19.6, 32/8 21.2)
+#define XPS_WARM   16384u                                 // a speculative walk starts this far before its segment
 #define XPS_SEG_BYTES 64u
 #define XPS_MIN_IN (512u << 10)                           // streams with at least this much input
-#define XPS_ROUNDS 32u                                    // rounds of "walk the segments again that do not hold"
+#define XPS_ROUNDS 8u                                     // rounds of "walk the segments again that do not hold"
 struct XpsTables {
 	const uint32_t* unit;          // n_big: the streams taken
 	const u64* seg_prefix;         // n_big + 1: first segment of each
