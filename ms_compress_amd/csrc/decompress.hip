@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(64) void xhd_parse_kernel(const uint8_t* __restrict
 		#define XHD_DECODE(sym) { const uint32_t r_ = bits; const uint32_t x_ = r_ < 15u ? (((mask >> 16) >> (16u - r_)) << (15u - r_)) : (mask >> 17); \
 			const uint32_t f_ = S.fast[x_ >> 6]; uint32_t n_; \
 			if (f_) { n_ = f_ & 0xFu; sym = f_ >> 4; if (n_ > r_) { sym = 0xFFFFu; } else { XHD_SKIP(n_) } } \
-			else { n_ = 1; while (x_ >= S.lims[n_]) { ++n_; } \
+			else { n_ = x_ >= lims9 ? 10u : 1u; while (x_ >= S.lims[n_]) { ++n_; } \
 				if (n_ > r_) { sym = 0xFFFFu; } else { XHD_SKIP(n_) const uint32_t s_ = S.poss[n_] + ((x_ - S.lims[n_ - 1u]) >> (15u - n_)); sym = s_ >= 512u ? 0xFFFFu : S.syms[s_]; } } }
 		while (prod < 65536u || !XHD_MASK_ZERO()) {
 			uint32_t sym;
@@ -1334,6 +1334,7 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 		if (bad) { status = -3; break; }                                 // :149
 		__syncthreads();
 		const uint32_t lims9 = S.lims[9];
+		const uint32_t lim10 = S.lims[10], lim11 = S.lims[11], lim12 = S.lims[12], lim13 = S.lims[13], lim14 = S.lims[14];   // (for the many-symbols step)
 		for (uint32_t i = lane; i < 512u; i += 64u) {
 			uint32_t e = 0;
 			const uint32_t x = i << 6;
@@ -1352,20 +1353,20 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 		uint32_t mask = (rb(ip) << 16) | (rb(ip + 1) << 24) | rb(ip + 2) | (rb(ip + 3) << 8);   // Bitstream.h:44
 		uint32_t bits = 32; ip += 4u;
 		uint32_t prod = 0;                                               // bytes of this chunk so far, saturating
-		bool stream_end = false;
+		bool stream_end = false, skip_wide = false;
 		#define XHD_SKIP(k) { mask <<= (k); bits -= (k); if (bits < 16u && ip + 2u <= endq) { XHD_NEED(ip, 2u) mask |= (rb(ip) | (rb(ip + 1) << 8)) << (16u - bits); bits |= 16u; ip += 2u; } }
 		#define XHD_MASK_ZERO() (bits == 0 || (mask >> (32u - bits)) == 0)
 		#define XHD_DECODE(sym) { const uint32_t r_ = bits; const uint32_t x_ = r_ < 15u ? (((mask >> 16) >> (16u - r_)) << (15u - r_)) : (mask >> 17); \
 			const uint32_t f_ = S.fast[x_ >> 6]; uint32_t n_; \
 			if (f_) { n_ = f_ & 0xFu; sym = f_ >> 4; if (n_ > r_) { sym = 0xFFFFu; } else { XHD_SKIP(n_) } } \
-			else { n_ = 1; while (x_ >= S.lims[n_]) { ++n_; } \
+			else { n_ = x_ >= lims9 ? 10u : 1u; while (x_ >= S.lims[n_]) { ++n_; } \
 				if (n_ > r_) { sym = 0xFFFFu; } else { XHD_SKIP(n_) const uint32_t s_ = S.poss[n_] + ((x_ - S.lims[n_ - 1u]) >> (15u - n_)); sym = s_ >= 512u ? 0xFFFFu : S.syms[s_]; } } }
 		while (prod < 65536u || !XHD_MASK_ZERO()) {
 			// a chunk of an encoder ends with its 65536th byte and an empty bit buffer; what still has bits then runs on in the reference
 			// (:87) -- possibly to the end of the buffer. A candidate is not followed there: it counts as "not a chunk", and a buffer
 			// whose chain does not close without it goes to the serial walk, which follows the reference to the letter.
 			if (!writing && prod >= 65536u) { status = -3; break; }
-			if (prod < 65536u && bits >= 16u && endq - ip >= 16u) {
+			if (!skip_wide && prod < 65536u && bits >= 16u && endq - ip >= 16u) {
 				// ---- many symbols per step: lane b decodes the symbol that would start b bits from here (the code through the same tables, a match's
 				// offset bits behind it); the symbols that really follow each other are then a walk b -> b + bits taken from lane 0, by readlane.
 				// Stops in front of a match with length bytes (they sit in the byte stream, where the next 16 bits would be pulled from: the
@@ -1387,7 +1388,11 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 				const uint32_t f = S.fast[x15 >> 6];
 				uint32_t n, sy;
 				if (f) { n = f & 0xFu; sy = f >> 4; }
-				else { n = 1; while (x15 >= S.lims[n]) { ++n; } const uint32_t s_ = S.poss[n] + ((x15 - S.lims[n - 1u]) >> (15u - n)); sy = s_ >= 512u ? 0xFFFFu : S.syms[s_]; }
+				else if (x15 < lims9) { n = 1; sy = 0xFFFFu; }               // a short code that no symbol has (the table says 0 for it too)
+				else {                                                       // a code of 10 to 15 bits: its length from the limits (wave-uniform, in registers), no loop
+					n = 10u + (x15 >= lim10 ? 1u : 0u) + (x15 >= lim11 ? 1u : 0u) + (x15 >= lim12 ? 1u : 0u) + (x15 >= lim13 ? 1u : 0u) + (x15 >= lim14 ? 1u : 0u);
+					const uint32_t s_ = S.poss[n] + ((x15 - S.lims[n - 1u]) >> (15u - n)); sy = s_ >= 512u ? 0xFFFFu : S.syms[s_];
+				}
 				const bool lit = sy < 0x100u, mat = !lit && sy != 0xFFFFu;
 				const uint32_t ob = (sy >> 4) & 0xFu;
 				const uint32_t cons = n + (mat ? ob : 0u);
@@ -1398,7 +1403,7 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 				const uint32_t step = evl ? 64u : cons;                      // (the walk ends on a symbol it must not take, which is then dropped again)
 				u64 mark = 0; uint32_t b = 0;
 				while (b < 64u) { mark |= (u64)1 << b; b += (uint32_t)__builtin_amdgcn_readlane((int)step, (int)b); }
-				if (mark & evm) { b = ctz64(mark & evm); mark &= ~evm; }
+				if (mark & evm) { b = ctz64(mark & evm); mark &= ~evm; skip_wide = true; }   // (the next symbol is for the code below: no point in looking at it from 64 lanes again)
 				bool on = (mark >> lane) & 1u;
 				const uint32_t l = on ? mlen : 0u, incl = wave_incl_scan_add_u32(l), before = incl - l;
 				const u64 over = __ballot(on && prod + before >= 65536u);                    // the chunk is full in front of this symbol: the loop condition decides there
@@ -1408,8 +1413,7 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 					const uint32_t adv = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)lastl);
 					const u64 opi = op + before;
 					const uint32_t rch = (on && mat && (u64)moff > opi) ? (uint32_t)((u64)moff - opi) : 0u;    // how far the match reaches in front of the chunk (offsets are below 65536 + 32768)
-					const uint32_t rmax = wave_max_u32(rch);
-					if (rmax > reach) { reach = rmax; }
+					if (__ballot(rch != 0)) { const uint32_t rmax = wave_max_u32(rch); if (rmax > reach) { reach = rmax; } }
 					const u64 ti = nt + popc_below(mark);
 					if (storing && on && ti < tokcap) { mytok[ti] = lit ? (0x80000000u | sy) : (moff | (mlen << 16)); }
 					nt += (uint32_t)__builtin_popcountll(mark);
@@ -1424,6 +1428,7 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 					continue;
 				}
 			}
+			skip_wide = false;
 			uint32_t sym;
 			XHD_DECODE(sym)
 			if (sym < 0x100u) {
