@@ -1657,7 +1657,7 @@ struct LzbLds {
 	uint32_t last[LZB_T / 32u];                                    // highest token start in the words before this one (LZB_T = none in this tile)
 	uint32_t wsum[16];
 	uint32_t carry[4];                                             // tpos (2 words), token running at the tile start: its position relative to the tile (biased), its word
-	uint32_t tokbuf[LZB_T];                                        // the next LZB_T tokens of the unit (a tile cannot start more): fetched while the tile before is resolved
+	uint32_t tokbuf[LZB_T + LZB_T / 64u];                          // the next LZB_T tokens of the unit (a tile cannot start more): fetched while the tile before is resolved
 };
 
 #ifdef LZB_PROFILE
@@ -1696,7 +1696,7 @@ __global__ __launch_bounds__(LZB_NT) void lz_copy_block_kernel(BatchTables bt, c
 		if (tid < LZB_T / 32u) { L.bm[tid] = 0; }
 		if (tid == 0) { L.carry[0] = 0; L.carry[3] = 0; }
 		#pragma unroll
-		for (uint32_t r = 0; r < LZB_T / LZB_NT; ++r) { L.tokbuf[r * LZB_NT + tid] = pre[r]; }
+		for (uint32_t r = 0; r < LZB_T / LZB_NT; ++r) { const uint32_t i_ = r * LZB_NT + tid; L.tokbuf[i_ + (i_ >> 6)] = pre[r]; }   // (one word of padding per 64: the reads below, 8 words apart from lane to lane, meet no bank twice)
 		__syncthreads();
 		// ---- the tokens that start in this tile: a tile cannot start more than LZB_T, thread j looks at tokens 8 j .. 8 j + 7 of the buffer ----
 		if (t < nt && tpos < w0 + wlen) {
@@ -1704,7 +1704,7 @@ __global__ __launch_bounds__(LZB_NT) void lz_copy_block_kernel(BatchTables bt, c
 			uint32_t w[TPT], len[TPT], sum = 0;
 			#pragma unroll
 			for (uint32_t r = 0; r < TPT; ++r) {
-				w[r] = L.tokbuf[tid * TPT + r];
+				w[r] = L.tokbuf[tid * TPT + r + ((tid * TPT + r) >> 6)];
 				len[r] = (t + tid * TPT + r < nt) ? ((w[r] & 0x80000000u) ? 1u : (w[r] >> 16) & 0x7FFFu) : 0u;
 				sum += len[r];
 			}
@@ -1729,7 +1729,11 @@ __global__ __launch_bounds__(LZB_NT) void lz_copy_block_kernel(BatchTables bt, c
 			}
 			if (accb) { atomicOr(&L.bm[accw], accb); }
 			// the tokens placed are a prefix of the buffer; the end of the last one is where the next token starts
-			if (cnt) { atomicAdd(&L.carry[3], cnt); atomicMax(&L.carry[0], (uint32_t)(after - w0)); }
+			{	// one update per wave (a thousand updates of one word are served one after the other)
+				const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_add_u32(cnt), 63);
+				const uint32_t aw = wave_max_u32(cnt ? (uint32_t)(after - w0) : 0u);
+				if (lane == 0 && cw) { atomicAdd(&L.carry[3], cw); atomicMax(&L.carry[0], aw); }
+			}
 			__syncthreads();
 			const uint32_t placed = L.carry[3];
 			if (placed) { t += placed; tpos = w0 + L.carry[0]; }
@@ -1798,7 +1802,8 @@ __global__ __launch_bounds__(LZB_NT) void lz_copy_block_kernel(BatchTables bt, c
 				const uint32_t q = r * LZB_NT + tid;
 				uint32_t mine = myw[r];
 				if (!(mine & 0x80000000u)) {
-					const uint32_t tw = __hip_atomic_load(&L.info[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					uint32_t tw = __hip_atomic_load(&L.info[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					if (!(tw & 0x80000000u)) { tw = __hip_atomic_load(&L.info[tw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // (two hops per round: half the barriers)
 					mine = tw;                                              // its value, or where IT looks
 					myw[r] = mine;
 					__hip_atomic_store(&L.info[q], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(LZG_NT) void lzg_expand_kernel(LzgTables g, BatchTa
 			uint32_t mine = myw[r];
 			if (!(mine & (LZG_W_VAL | LZG_W_EXT))) {
 				mine = __hip_atomic_load(&L.info[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // its value, its source before the tile, or where IT looks
+				if (!(mine & (LZG_W_VAL | LZG_W_EXT))) { mine = __hip_atomic_load(&L.info[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // (two hops per round: half the barriers)
 				myw[r] = mine;
 				__hip_atomic_store(&L.info[q], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				open |= !(mine & (LZG_W_VAL | LZG_W_EXT));
