@@ -1257,6 +1257,17 @@ __global__ __launch_bounds__(256) void xhc_mark_kernel(const uint8_t* __restrict
 // is measured (where the next chunk would start, bytes produced, how far its matches reach in front of the chunk, tokens; 2 = not a chunk);
 // the candidate at offset 0 is chunk 0 for sure and writes its tokens at once. PASS 2: the chunks the chain check accepted write their
 // tokens at their place in the unit's token stream.
+#ifdef XHC_PROFILE   // make EXTRA=-DXHC_PROFILE: steps / symbols per step / symbols one at a time, summed and the maximum per chunk (tools/dev/gpu_xhcprof.py)
+__device__ unsigned long long g_xhc_prof[8];
+extern "C" void mscomp_amd_debug_xhc_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xhc_prof), 64); unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xhc_prof), z, 64); }
+#define XHC_CN(i, v) { if (lane == 0) { atomicAdd(&g_xhc_prof[i], (unsigned long long)(v)); } }
+#define XHC_LOC(i) { ++xhc_loc[i]; }
+#define XHC_END() { if (lane == 0) { atomicMax(&g_xhc_prof[4], (unsigned long long)xhc_loc[0]); atomicMax(&g_xhc_prof[5], (unsigned long long)xhc_loc[1]); atomicMax(&g_xhc_prof[6], (unsigned long long)(xhc_loc[0] * 3u + xhc_loc[1])); atomicAdd(&g_xhc_prof[7], 1ull); } }
+#else
+#define XHC_CN(i, v)
+#define XHC_LOC(i)
+#define XHC_END()
+#endif
 template <int PASS>
 __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, const u64* __restrict__ tok_prefix,
                                                       const u64* __restrict__ cand_prefix, XhcBufs xb, uint32_t* __restrict__ tok)
@@ -1281,6 +1292,9 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 	uint32_t* __restrict__ mytok = scr ? xb.scr_tok + (xb.scr_prefix[u] + idx) * (u64)XHC_SCR : tok + tok_prefix[u] + tok_at;
 	const u64 tokcap = scr ? (u64)XHC_SCR : tok_prefix[u + 1] - tok_prefix[u] - tok_at;   // chunk 0 writes before the capacity is judged: never beyond the unit's slots
 	const bool storing = writing || scr;
+#ifdef XHC_PROFILE
+	uint32_t xhc_loc[2] = {0, 0};
+#endif
 	u64 reach = 0;
 	u64 nt = 0;                                                          // tokens so far
 	#define XHD_EMIT(w) { if (storing && lane == 0 && nt < tokcap) { mytok[nt] = (w); } ++nt; }
@@ -1417,6 +1431,7 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 					const u64 ti = nt + popc_below(mark);
 					if (storing && on && ti < tokcap) { mytok[ti] = lit ? (0x80000000u | sy) : (moff | (mlen << 16)); }
 					nt += (uint32_t)__builtin_popcountll(mark);
+					XHC_CN(0, 1) XHC_CN(1, (uint32_t)__builtin_popcountll(mark)) XHC_LOC(0)
 					op += adv; prod += adv;
 					// Bitstream.h:61-75: a word is pulled whenever fewer than 16 bits are left
 					const int32_t avail = (int32_t)bits - (int32_t)b;
@@ -1429,6 +1444,7 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 				}
 			}
 			skip_wide = false;
+			XHC_CN(2, 1) XHC_LOC(1)
 			uint32_t sym;
 			XHD_DECODE(sym)
 			if (sym < 0x100u) {
@@ -1482,6 +1498,7 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 	#undef XHD_MASK_ZERO
 	#undef XHD_DECODE
 	#undef XHD_EMIT
+	XHC_END()
 	if (PASS == 1 && lane == 0) {
 		xb.res_state[slot] = (status == 1 ? state : 2u) | ((scr && (!scr_ok || nt > XHC_SCR)) ? 4u : 0u); xb.res_end[slot] = next_at; xb.res_prod[slot] = op; xb.res_ntok[slot] = nt;
 		xb.res_reach[slot] = reach > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)reach;
