@@ -889,13 +889,16 @@ __global__ __launch_bounds__(64) void xpt_parse_kernel(const uint8_t* __restrict
 // Where a flag word starts is known only to a walk that comes from the start of the stream. But a walk that starts at a WRONG place falls
 // into step with the right one sooner or later (tools/xp_sync_study.py: after 2 KB in the median, 27 KB at the 90th, 137 KB at the 99th
 // percentile of 4 800 starts in the corpus: whenever it reaches a flag word of the right walk in the right state, it IS the right walk).
-// So the input of a stream is cut into segments of XPS_SEG bytes and
+// So the input of a stream is cut into segments of XPS_SEG bytes (16 KiB) and
 //   round 0: a wave per segment starts XPS_WARM bytes before its segment as if a flag word began there (no nibble pending), notes the state
 //            in which it arrives at the first flag word at or behind the segment start ("landing": offset, pending nibble and where its byte
 //            is) and counts tokens and bytes from there to the first flag word at or behind the segment end ("exit"). Segment 0 starts at the start.
 //   check:   segment k holds if its landing is the exit of segment k - 1 (and that one ran on); by induction from segment 0 a chain of
-//            holding segments is the true parse. A segment that does not hold is walked again from the exit of the segment before it, all such
-//            segments at the same time, XPS_ROUNDS times: each round makes at least the first of them right; the 99 % case is one round.
+//            holding segments is the true parse. The FIRST of a run of segments that do not hold is walked again from the exit of the segment
+//            before it -- a segment that holds, so this is the true state -- and goes on through the run until it arrives where a later
+//            segment had landed: one round per run, whatever its length (there are stretches of 100 KB and more that no speculative walk
+//            enters: flag words 0xAAAAAAAA / 0x55555555 in a lattice of 52-54 bytes). XPS_ROUNDS rounds are launched; a segment
+//            behind a run may stop holding when the run's exit changes, which is what the further rounds are for.
 //   emit:    with the segments' token and byte counts summed up, every segment is walked once more from its true state, writing its tokens
 //            at their place and making the tests that need the output offset.
 // Whatever does not fit this picture -- a segment that ends in an error, more rounds needed, a test failing, output beyond the capacity --
