@@ -262,3 +262,38 @@ def test_large_units_get_their_bytes_from_all_cus(oracle, gpu_ctx, fmt):
             assert st == so and (so != 0 or out == oo), (fmt, len(stream), cap, st, so)
             n_judged += 1
     assert n_judged >= 12
+
+
+def test_segment_and_tile_edges_of_large_streams(oracle, gpu_ctx):
+    """Xpress streams whose length sits on the edges of the segment walk (csrc/decompress.hip xps_*: streams from 512 KiB, 16 KiB segments) and
+    outputs on the edges of the byte stage (csrc/lzglobal.hip: capacities from 1 MiB, 8 KiB tiles): prefixes of valid streams cut at those
+    lengths, 600 KB of random bytes as a "stream", capacities one byte around 1 MiB -- status and bytes of the checker in every case."""
+    import ms_compress_amd as m
+    from ms_compress_amd import corpus
+    rng = np.random.default_rng(41)
+    base = corpus.file_bytes(1, 3_000_000).tobytes()                       # mozilla: ~1.6 MB of stream
+    noise = rng.integers(0, 256, 1_400_000, dtype=np.uint8).tobytes()      # incompressible: the stream is longer than the data
+    comp, st = m.compress_units(3, [base, noise], ctx=gpu_ctx)
+    assert all(s == 0 for s in st) and len(comp[0]) > 1_200_000 and len(comp[1]) > 1_400_000
+    cases_ = []
+    for c, n in ((comp[0], len(base)), (comp[1], len(noise))):
+        for cut in (524287, 524288, 524289, 540672, 540673, 16384 * 40 - 1, 16384 * 40, len(c) - 1, len(c)):
+            cases_.append((c[:cut], n))
+    cases_ += [(rng.integers(0, 256, 600_000, dtype=np.uint8).tobytes(), 2_000_000), (bytes(700_000), 1 << 20), (b"\xff" * 600_000, 3_000_000)]
+    for cap in ((1 << 20) - 1, 1 << 20, (1 << 20) + 1, (1 << 20) + 8192, len(base)):
+        cases_.append((comp[0], cap))
+    outs, sts = m.decompress_units(3, [s for s, _ in cases_], [c for _, c in cases_], ctx=gpu_ctx)
+    n_ok = 0
+    for (stream, cap), out, st in zip(cases_, outs, sts):
+        so, oo, undefined = oracle.oracle_decompress_ex(3, stream, cap)
+        assert not undefined
+        assert st == so and (so != 0 or out == oo), (len(stream), cap, st, so)
+        n_ok += so == 0
+    assert n_ok >= 3
+    # the same capacities for Xpress+Huffman (chunk-parallel walk + byte stage)
+    comp4, st = m.compress_units(4, [base], ctx=gpu_ctx)
+    caps = [(1 << 20) - 1, 1 << 20, (1 << 20) + 1, len(base), len(base) + (1 << 20)]
+    outs, sts = m.decompress_units(4, [comp4[0]] * len(caps), caps, ctx=gpu_ctx)
+    for cap, out, st in zip(caps, outs, sts):
+        so, oo, _ = oracle.oracle_decompress_ex(4, comp4[0], cap)
+        assert st == so and (so != 0 or out == oo), (cap, st, so)
