@@ -102,3 +102,29 @@ def test_whole_buffer_xpress_large(oracle, gpu_ctx):
     data = corpus.by_name("samba", 3_000_000)
     got, st = m.compress_units(3, [data.tobytes()], ctx=gpu_ctx)
     assert st == [0] and hashlib.sha256(got[0]).digest() == hashlib.sha256(oracle.oracle_compress(3, data.tobytes())[1]).digest()
+
+
+@pytest.mark.parametrize("fmt", [3, 4])
+def test_whole_files_come_back(gpu_ctx, fmt):
+    """All 12 files as 12 whole buffers -- one Xpress stream each (segment walks, csrc/decompress.hip xps_*), one Xpress+Huffman buffer each
+    (chunk-parallel walk with token scratch) -- compressed (digests of the REFERENCE's output: tests/golden/corpus_full.json) and decompressed in one
+    batch; the bytes of the large units come from csrc/lzglobal.hip. Also through the token-at-a-time Xpress kernel (mode 1) and without the
+    segment walk (mode 2): the same bytes."""
+    import json
+    import os
+    import ms_compress_amd as m
+    from ms_compress_amd import corpus
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "corpus_full.json")))
+    files = [corpus.file_bytes(i).tobytes() for i in range(12)]
+    comp, st = m.compress_units(fmt, files, ctx=gpu_ctx)
+    key = {3: "xpress", 4: "xpress_huff"}[fmt]
+    for name, c, s in zip(corpus.NAMES, comp, st):
+        assert s == 0 and len(c) == gold[name][key]["len"] and hashlib.sha256(c).hexdigest() == gold[name][key]["sha256"], name
+    for mode in ((0, 2) if fmt == 3 else (0,)):          # (mode 1, one token per step, would take seconds for 51 MB: covered at small sizes)
+        gpu_ctx.lib.mscomp_amd_debug_set_xpress_decoder(mode)
+        try:
+            back, st2 = m.decompress_units(fmt, comp, [len(f) for f in files], ctx=gpu_ctx)
+        finally:
+            gpu_ctx.lib.mscomp_amd_debug_set_xpress_decoder(0)
+        for name, b, f, s in zip(corpus.NAMES, back, files, st2):
+            assert s == 0 and b == f, (name, mode)
