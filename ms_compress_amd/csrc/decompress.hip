@@ -1271,6 +1271,9 @@ extern "C" void mscomp_amd_debug_xhc_prof(unsigned long long* out) { (void)hipMe
 #define XHC_LOC(i)
 #define XHC_END()
 #endif
+#ifndef XHC_WIDE2
+#define XHC_WIDE2 1                                            // two windows of 64 bit offsets per step (0: one)
+#endif
 template <int PASS>
 __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, const u64* __restrict__ tok_prefix,
                                                       const u64* __restrict__ cand_prefix, XhcBufs xb, uint32_t* __restrict__ tok)
@@ -1383,6 +1386,99 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 			// (:87) -- possibly to the end of the buffer. A candidate is not followed there: it counts as "not a chunk", and a buffer
 			// whose chain does not close without it goes to the serial walk, which follows the reference to the letter.
 			if (!writing && prod >= 65536u) { status = -3; break; }
+#if XHC_WIDE2
+			if (!skip_wide && prod < 65536u && bits >= 16u && endq - ip >= 24u) {
+				// ---- many symbols per step: lane b decodes the symbols that would start b and 64 + b bits from here (the code through the same
+				// tables, a match's offset bits behind it); the symbols that really follow each other are then a walk b -> b + bits taken from
+				// bit 0, by readlane: ~6 (matches) to 16 (8-bit literals) of them. Stops in front of a match with length bytes (they sit in the byte
+				// stream, where the next 16 bits would be pulled from: the symbol-at-a-time code below takes that one) and in front of anything
+				// invalid; the bit buffer is rebuilt as Bitstream.h would hold it. (One window of 64 bit offsets per step: 8 191 steps for a chunk of
+				// literals, 7.9 ms for the slowest chunk of the bench; with two windows half the steps.)
+				XHD_NEED(ip, 24u)
+				uint32_t dw[5];                                            // bytes ip .. ip + 19: ten 16-bit words, each the next 16 bits of the stream
+				{
+					const uint32_t* in32 = reinterpret_cast<const uint32_t*>(S.in);
+					const uint32_t i_ = (ip >> 2) & (2u * XHD_INB / 4u - 1u), sh_ = ip & 3u, M_ = 2u * XHD_INB / 4u - 1u;
+					uint32_t r_[6];
+					#pragma unroll
+					for (uint32_t k_ = 0; k_ < 6u; ++k_) { r_[k_] = in32[(i_ + k_) & M_]; }
+					#pragma unroll
+					for (uint32_t k_ = 0; k_ < 5u; ++k_) { dw[k_] = __builtin_amdgcn_alignbyte(r_[k_ + 1u], r_[k_], sh_); }
+				}
+				#define XHD_SWAP16(x) (((x) << 16) | ((x) >> 16))              /* word k of the stream first: (w0 << 16) | w1 */
+				const u64 t0 = ((u64)XHD_SWAP16(dw[0]) << 32) | XHD_SWAP16(dw[1]), t1 = ((u64)XHD_SWAP16(dw[2]) << 32) | XHD_SWAP16(dw[3]), t2 = (u64)XHD_SWAP16(dw[4]) << 32;
+				#undef XHD_SWAP16
+				const u64 sq0 = ((u64)mask << 32) | (t0 >> bits), sq1 = (t0 << (64u - bits)) | (t1 >> bits), sq2 = (t1 << (64u - bits)) | (t2 >> bits);   // the next 192 bits (bits + 160 real)
+				uint32_t vw[2];
+				vw[0] = (uint32_t)((lane ? (sq0 << lane) | (sq1 >> (64u - lane)) : sq0) >> 32);
+				vw[1] = (uint32_t)((lane ? (sq1 << lane) | (sq2 >> (64u - lane)) : sq1) >> 32);
+				uint32_t stp[2], tokw[2], mln[2], mof[2]; bool ism[2]; u64 evm[2];
+				#pragma unroll
+				for (uint32_t h_ = 0; h_ < 2u; ++h_) {
+					const uint32_t view = vw[h_];
+					const uint32_t x15 = view >> 17;
+					const uint32_t f = S.fast[x15 >> 6];
+					uint32_t n, sy;
+					if (f) { n = f & 0xFu; sy = f >> 4; }
+					else if (x15 < lims9) { n = 1; sy = 0xFFFFu; }           // a short code that no symbol has (the table says 0 for it too)
+					else {                                                   // a code of 10 to 15 bits: its length from the limits (wave-uniform, in registers), no loop
+						n = 10u + (x15 >= lim10 ? 1u : 0u) + (x15 >= lim11 ? 1u : 0u) + (x15 >= lim12 ? 1u : 0u) + (x15 >= lim13 ? 1u : 0u) + (x15 >= lim14 ? 1u : 0u);
+						const uint32_t s_ = S.poss[n] + ((x15 - S.lims[n - 1u]) >> (15u - n)); sy = s_ >= 512u ? 0xFFFFu : S.syms[s_];
+					}
+					const bool lit = sy < 0x100u, mat = !lit && sy != 0xFFFFu;
+					const uint32_t ob = (sy >> 4) & 0xFu;
+					const uint32_t moff = ob ? ((view << n) >> (32u - ob)) + (1u << ob) : 1u;
+					const uint32_t mlen = lit ? 1u : (sy & 0xFu) + 3u;
+					const bool evl = !lit && (!mat || (sy & 0xFu) == 0xFu);
+					evm[h_] = __ballot(evl);
+					stp[h_] = evl ? 128u : n + (mat ? ob : 0u);              // (the walk ends on a symbol it must not take, which is then dropped again)
+					tokw[h_] = lit ? (0x80000000u | sy) : (moff | (mlen << 16)); mln[h_] = mlen; mof[h_] = moff; ism[h_] = mat;
+				}
+				u64 mk0 = 0, mk1 = 0; uint32_t b = 0;
+				while (b < 64u) { mk0 |= (u64)1 << b; b += (uint32_t)__builtin_amdgcn_readlane((int)stp[0], (int)b); }
+				if (mk0 & evm[0]) { b = ctz64(mk0 & evm[0]); mk0 &= ~evm[0]; skip_wide = true; }
+				else {
+					while (b < 128u) { mk1 |= (u64)1 << (b - 64u); b += (uint32_t)__builtin_amdgcn_readlane((int)stp[1], (int)(b - 64u)); }
+					if (mk1 & evm[1]) { b = 64u + ctz64(mk1 & evm[1]); mk1 &= ~evm[1]; skip_wide = true; }
+				}
+				bool on0 = (mk0 >> lane) & 1u, on1 = (mk1 >> lane) & 1u;
+				const uint32_t l0 = on0 ? mln[0] : 0u, in0 = wave_incl_scan_add_u32(l0), tot0 = (uint32_t)__builtin_amdgcn_readlane((int)in0, 63);
+				const uint32_t l1 = on1 ? mln[1] : 0u, in1 = tot0 + wave_incl_scan_add_u32(l1);
+				const uint32_t bf0 = in0 - l0, bf1 = in1 - l1;
+				{	// the chunk is full in front of a symbol: the loop condition decides there
+					const u64 ov0 = __ballot(on0 && prod + bf0 >= 65536u), ov1 = __ballot(on1 && prod + bf1 >= 65536u);
+					if (ov0) { const uint32_t sl = ctz64(ov0); mk0 &= ((u64)1 << sl) - 1u; mk1 = 0; b = sl; skip_wide = false; }
+					else if (ov1) { const uint32_t sl = ctz64(ov1); mk1 &= ((u64)1 << sl) - 1u; b = 64u + sl; skip_wide = false; }
+					on0 = (mk0 >> lane) & 1u; on1 = (mk1 >> lane) & 1u;
+				}
+				if (mk0) {
+					const uint32_t adv = mk1 ? (uint32_t)__builtin_amdgcn_readlane((int)in1, (int)(63u - (uint32_t)__builtin_clzll(mk1)))
+					                         : (uint32_t)__builtin_amdgcn_readlane((int)in0, (int)(63u - (uint32_t)__builtin_clzll(mk0)));
+					const u64 op0 = op + bf0, op1 = op + bf1;
+					const uint32_t rc0 = (on0 && ism[0] && (u64)mof[0] > op0) ? (uint32_t)((u64)mof[0] - op0) : 0u;   // how far a match reaches in front of the chunk (offsets are below 65536 + 32768)
+					const uint32_t rc1 = (on1 && ism[1] && (u64)mof[1] > op1) ? (uint32_t)((u64)mof[1] - op1) : 0u;
+					if (__ballot((rc0 | rc1) != 0)) { const uint32_t rmax = wave_max_u32(rc0 > rc1 ? rc0 : rc1); if (rmax > reach) { reach = rmax; } }
+					const uint32_t c0 = (uint32_t)__builtin_popcountll(mk0), c1 = (uint32_t)__builtin_popcountll(mk1);
+					const u64 ti0 = nt + popc_below(mk0), ti1 = nt + c0 + popc_below(mk1);
+					if (storing && on0 && ti0 < tokcap) { mytok[ti0] = tokw[0]; }
+					if (storing && on1 && ti1 < tokcap) { mytok[ti1] = tokw[1]; }
+					nt += c0 + c1;
+					XHC_CN(0, 1) XHC_CN(1, c0 + c1) XHC_LOC(0)
+					op += adv; prod += adv;
+					// Bitstream.h:61-75: a word is pulled whenever fewer than 16 bits are left
+					const int32_t avail = (int32_t)bits - (int32_t)b;
+					const uint32_t pulls = avail < 16 ? (uint32_t)(16 - avail + 15) >> 4 : 0u;
+					const uint32_t nb = (uint32_t)(avail + 16 * (int32_t)pulls);
+					u64 x64;
+					if (b < 64u) { x64 = b ? (sq0 << b) | (sq1 >> (64u - b)) : sq0; }
+					else if (b < 128u) { const uint32_t c_ = b - 64u; x64 = c_ ? (sq1 << c_) | (sq2 >> (64u - c_)) : sq1; }
+					else { x64 = sq2 << (b - 128u); }
+					mask = (uint32_t)(x64 >> 32) & (nb >= 32u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> nb));
+					bits = nb; ip += 2u * pulls;
+					continue;
+				}
+			}
+#else
 			if (!skip_wide && prod < 65536u && bits >= 16u && endq - ip >= 16u) {
 				// ---- many symbols per step: lane b decodes the symbol that would start b bits from here (the code through the same tables, a match's
 				// offset bits behind it); the symbols that really follow each other are then a walk b -> b + bits taken from lane 0, by readlane.
@@ -1446,6 +1542,7 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 					continue;
 				}
 			}
+#endif
 			skip_wide = false;
 			XHC_CN(2, 1) XHC_LOC(1)
 			uint32_t sym;
