@@ -287,8 +287,8 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 				if (out_cap[i] > 65536u) { scr += most + most / 4 + 2; }   // a buffer of several chunks: its candidates keep their tokens (no second walk)
 			}
 			tp[n_units] = slots; tp[2 * n_units + 1] = cands; tp[3 * n_units + 2] = scr;
-			{	// ... if that scratch is affordable (MSCOMP_AMD_XHC_SCR_MAX_MB, default 8 GiB; 0 = always walk twice)
-				static const uint64_t scr_budget = [] { const char* e = getenv("MSCOMP_AMD_XHC_SCR_MAX_MB"); const long long v = e ? atoll(e) : 8192; return (uint64_t)(v < 0 ? 0 : v) << 20; }();
+			{	// ... if that scratch is affordable (MSCOMP_AMD_XHC_SCR_MAX_MB, default 32 GiB of the 288; 0 = always walk twice)
+				static const uint64_t scr_budget = [] { const char* e = getenv("MSCOMP_AMD_XHC_SCR_MAX_MB"); const long long v = e ? atoll(e) : 32768; return (uint64_t)(v < 0 ? 0 : v) << 20; }();
 				if (scr * XHC_SCR * 4 > scr_budget) { for (size_t i = 0; i <= n_units; ++i) { tp[2 * (n_units + 1) + i] = 0; } scr = 0; }
 				p->xhc_scr = scr;
 			}
@@ -315,12 +315,22 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 		}
 		if (okd && (format == MSCOMP_XPRESS || format == MSCOMP_XPRESS_HUFF)) {
 			// units with room for LZG_MIN_CAP bytes or more get their bytes from all CUs (lzglobal.hip): 4 bytes of scratch per byte of capacity;
-			// when that is more than the budget (MSCOMP_AMD_LZG_MAX_MB, default 16 GiB; 0 switches the path off) the block-per-unit kernel takes them
-			static const uint64_t budget = [] { const char* e = getenv("MSCOMP_AMD_LZG_MAX_MB"); const long long v = e ? atoll(e) : 16384; return (uint64_t)(v < 0 ? 0 : v) << 20; }();
+			// when that is more than the budget (MSCOMP_AMD_LZG_MAX_MB, default 64 GiB of the 288; 0 switches the path off) the block-per-unit kernel takes them
+			static const uint64_t budget = [] { const char* e = getenv("MSCOMP_AMD_LZG_MAX_MB"); const long long v = e ? atoll(e) : 65536; return (uint64_t)(v < 0 ? 0 : v) << 20; }();
 			std::vector<uint32_t> big;
 			uint64_t words = 0;
 			for (size_t i = 0; i < n_units; ++i) { if (out_cap[i] >= LZG_MIN_CAP && out_cap[i] < 0xFFFFFF00ull) { big.push_back((uint32_t)i); words += out_cap[i] + 64; } }
-			if (!big.empty() && words * 4 <= budget) {
+			// ... and when it pays: the all-CU stage costs about 22 ms per GB of output whatever the units are (74 ms for 192 files, 3.39 GB), the
+			// block-per-unit kernel about 1 ms per MB of the LARGEST unit as long as there are no more large units than CUs (51 ms for the same 192
+			// files, whose largest is 51 MB; 60 ms for 12 of them, where the all-CU stage takes 5 ms)
+			bool pays = false;
+			{
+				uint64_t tot = 0, mx = 0;
+				for (uint32_t i : big) { tot += out_cap[i]; mx = out_cap[i] > mx ? out_cap[i] : mx; }
+				const double mb = 1.0 / (1 << 20), c_all = 0.022 * (double)tot * mb, per_cu = (double)tot * mb / 256.0, c_blk = 1.0 * ((double)mx * mb > per_cu ? (double)mx * mb : per_cu);
+				pays = c_all < c_blk;
+			}
+			if (!big.empty() && pays && words * 4 <= budget) {
 				const size_t nb = big.size(), upad = (nb + 1) / 2;              // the unit list in whole u64 slots
 				std::vector<uint64_t> tab(upad + 3 * (nb + 1));
 				memcpy(tab.data(), big.data(), nb * 4);
