@@ -319,7 +319,9 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 			static const uint64_t budget = [] { const char* e = getenv("MSCOMP_AMD_LZG_MAX_MB"); const long long v = e ? atoll(e) : 65536; return (uint64_t)(v < 0 ? 0 : v) << 20; }();
 			std::vector<uint32_t> big;
 			uint64_t words = 0;
-			for (size_t i = 0; i < n_units; ++i) { if (out_cap[i] >= LZG_MIN_CAP && out_cap[i] < 0xFFFFFF00ull) { big.push_back((uint32_t)i); words += out_cap[i] + 64; } }
+			bool too_large = false;                                       // (32-bit word indices: a unit with room for 4 GiB keeps the whole plan on the block kernel, which every such unit then takes)
+			for (size_t i = 0; i < n_units; ++i) { if (out_cap[i] >= 0xFFFFFF00ull) { too_large = true; } else if (out_cap[i] >= LZG_MIN_CAP) { big.push_back((uint32_t)i); words += out_cap[i] + 64; } }
+			if (too_large) { big.clear(); }
 			// ... and when it pays: the all-CU stage costs about 22 ms per GB of output whatever the units are (74 ms for 192 files, 3.39 GB), the
 			// block-per-unit kernel about 1 ms per MB of the LARGEST unit as long as there are no more large units than CUs (51 ms for the same 192
 			// files, whose largest is 51 MB; 60 ms for 12 of them, where the all-CU stage takes 5 ms)

@@ -297,3 +297,18 @@ def test_segment_and_tile_edges_of_large_streams(oracle, gpu_ctx):
     for cap, out, st in zip(caps, outs, sts):
         so, oo, _ = oracle.oracle_decompress_ex(4, comp4[0], cap)
         assert st == so and (so != 0 or out == oo), (cap, st, so)
+
+
+@pytest.mark.parametrize("fmt", ["xpress", "xpress_huff"])
+def test_a_unit_with_room_for_more_than_4_gib_next_to_large_units(oracle, gpu_ctx, fmt):
+    """the byte stage of csrc/lzglobal.hip indexes a unit's output with 32 bits: a unit with a capacity of 4 GiB or more keeps the whole plan on the
+    block-per-unit kernel (it used to be left without bytes when another large unit took the all-CU stage)"""
+    import ms_compress_amd as m
+    from ms_compress_amd import corpus
+    f = FMTS[fmt]
+    units = [corpus.file_bytes(1, 2_500_000).tobytes(), corpus.file_bytes(3, 400_000).tobytes(), b"abc" * 1000]
+    comp, st = m.compress_units(f, units, ctx=gpu_ctx)
+    assert all(s == 0 for s in st)
+    caps = [len(units[0]), 5 << 30, len(units[2])]
+    back, st2 = m.decompress_units(f, comp, caps, ctx=gpu_ctx)
+    assert list(st2) == [0, 0, 0] and all(b == u for b, u in zip(back, units))
