@@ -46,8 +46,7 @@ SYMBOLS = {
     (2, "lznt1_chunk_kernel"): "msc::lznt1_chunk4_kernel",
     (3, "xp_find_kernel"): "msc::xp_find_kernel<8192u, 8192u, 512u, 4096u>",
     (4, "xp_find_kernel"): "msc::xp_find_kernel<65536u, 0u, 1024u, 8192u>",
-    (3, "xp_lazy_kernel"): "msc::xp_lazy_kernel<0u, false>",
-    (4, "xp_lazy_kernel"): "msc::xp_lazy_kernel<65536u, true>",
+    (3, "xp_lazy2_kernel"): "msc::xp_lazy2_kernel",
 }
 
 

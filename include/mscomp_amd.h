@@ -206,9 +206,9 @@ void         mscomp_amd_debug_set_xpress_decoder(int mode);
 /* Test hook: after a decompression whose large units (capacity >= 1 MiB) got their bytes from csrc/lzglobal.hip: out[0..32] = words still
  * pointing after each pointer pass (`words` = sum over those units of capacity + 64). 0 = read. */
 int          mscomp_amd_debug_lzg_open(mscomp_amd_ctx* ctx, uint64_t words, uint32_t* out);
-/* Test hook: the Xpress-family match finder evaluates every position (1 = default) or runs lazily (0: Find only where a greedy parse can
- * start a token, csrc/xlazy.hip; Xpress: units up to 64 KiB; exact but slower); the parse kernels get the same answers on
- * every path they walk. Process-wide. */
+/* Test hook: how the Xpress match finder runs. 1 = default: batches whose units are at most 64 KiB run Find only where a greedy parse can
+ * start a token (csrc/xpress_lazy.hip); 2 = Find for every position everywhere (xp_find_kernel, what longer streams and Xpress+Huffman
+ * always use). The parse kernels get the same answers on every path they walk. Process-wide. */
 void         mscomp_amd_debug_set_finder(int mode);
 /* Test hook: the LZNT1 chunk stage has two bit-identical kernels (one wave / four waves per 4 KiB chunk). 0 = default, 1 / 2 = force. */
 void         mscomp_amd_debug_set_lznt1(int mode);

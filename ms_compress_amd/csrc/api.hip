@@ -24,10 +24,10 @@ namespace {
 // time, so a plain counter) and a process-wide one for the test hooks that switch kernels (atomic: any thread may call them
 // while other threads execute plans).
 static std::atomic<uint64_t> g_mode_epoch{1};
+static std::atomic<int> g_finder_mode{1};              // 1 = default (Xpress units up to 64 KiB: the lazy finder, xpress_lazy.hip), 2 = Find for every position everywhere
 static int lznt1_sa_env() { const char* e = getenv("MSCOMP_AMD_LZNT1_SA_DICT"); return (e && *e && *e != '0') ? 1 : 0; }
 static std::atomic<int> g_lznt1_sa{lznt1_sa_env()};    // 1 = LZNT1 compresses with the suffix-array dictionary flavour (lznt1_sa.hip; the reference's MSCOMP_WITH_LZNT1_SA_DICT build)
 static std::atomic<int> g_xpd_mode{0};                 // Xpress decompression: 0 = tokens a flag word at a time + copy kernels (default; large streams by segments), 1 = xpd_kernel (a token at a time, bytes in the same wave), 2 = as 0 without the segments
-static std::atomic<int> g_finder_mode{1};              // 1 = Find for every position (default), 0 = the lazy finder of xlazy.hip (experimental: exact, slower -- DESIGN 5)
 struct DevBuf {
 	void* p = nullptr; size_t cap = 0;
 	uint64_t* epoch = nullptr;                         // the owning context's epoch (null for plan-owned tables)
@@ -551,8 +551,8 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 		uint16_t* links = static_cast<uint16_t*>(c->links.p); uint16_t* lasthead = static_cast<uint16_t*>(c->lasthead.p);
 		uint16_t* mlen3 = static_cast<uint16_t*>(c->mlen3.p); uint16_t* moff = static_cast<uint16_t*>(c->moff.p);
 		{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
-		// the lazy finder stages a whole unit in LDS: units of at most 64 KiB (one Xpress stream each); longer streams keep the tiled finder
-		if (g_finder_mode.load(std::memory_order_relaxed) != 1 && p->max_unit <= 65536u) { KernelTimer t(c, "xp_lazy_kernel"); launch_xp_lazy(st, d_in, p->bt, links, lasthead, mlen3, moff, 0, 0u, p->n_chunks); }
+		// units of one link chunk: Find only where a greedy parse can start a token, window and links in LDS; longer streams: every position
+		if (g_finder_mode.load(std::memory_order_relaxed) != 2 && p->max_unit <= 65536u) { KernelTimer t(c, "xp_lazy2_kernel"); launch_xp_lazy2(st, d_in, p->bt, links, mlen3, moff); }
 		else { KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0x2000u, 0); }
 		{ KernelTimer t(c, "xpress_emit_kernel"); launch_xpress_emit(st, d_in, p->bt, mlen3, moff, xpress_win_bufs(c, p->n_chunks), d_out, d_out_len, d_status); }
 		break;
@@ -565,8 +565,7 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 		uint16_t* codes = static_cast<uint16_t*>(c->codes.p); uint32_t* fbflag = static_cast<uint32_t*>(c->fbflag.p);
 		uint32_t* fb_count = static_cast<uint32_t*>(c->fb_list.p); uint32_t* fb_list = fb_count + 16;
 		{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
-		if (g_finder_mode.load(std::memory_order_relaxed) != 1) { KernelTimer t(c, "xp_lazy_kernel"); launch_xp_lazy(st, d_in, p->bt, links, lasthead, mlen3, moff, 1, 0u, p->n_chunks); }
-		else { KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0xFFFFu, 1); }
+		{ KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0xFFFFu, 1); }
 		{ KernelTimer t(c, "xh_parse_kernel"); launch_xh_parse(st, d_in, p->bt, mlen3, moff, tokbits, counts, extra); }
 		{ KernelTimer t(c, "xh_huff_kernel"); launch_xh_huff(st, p->bt, counts, extra, lens, codes, slot_size, fb_list, fb_count, fbflag); }
 		{ KernelTimer t(c, "xh_fallback_kernel"); launch_xh_fallback(st, d_in, p->bt, fb_list, fb_count, XH_FB_BLOCKS, tokbits, lens, codes, slot_size); }

@@ -525,8 +525,8 @@ __global__ void lzd_clear_kernel(uint32_t* p) { *p = 0; }
 void launch_lzd_segments(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const LzdBufs& b)
 {
 	if (bt.n_units == 0) { return; }
-	static bool attr_set = false;
-	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lzd_seg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZD_LDS); attr_set = true; }
+	static PerDeviceOnce attr;
+	if (attr.needed()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lzd_seg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZD_LDS); attr.done(); }
 	hipLaunchKernelGGL(lzd_clear_kernel, dim3(1), dim3(1), 0, st, b.irregular + bt.n_units);
 	hipLaunchKernelGGL(lzd_seg_kernel, dim3(bt.n_chunks), dim3(LZD_THREADS), LZD_LDS, st, d_in, bt, b.cin, b.segL, b.segE, b.segcnt, b.segstop, b.segoff);
 }
@@ -1786,6 +1786,7 @@ extern "C" void mscomp_amd_debug_lzb_prof(unsigned long long* out) { (void)hipMe
 #define LZB_TM(i)
 #define LZB_CN(i, v)
 #endif
+static PerDeviceOnce g_lzb_attr;                                          // the dynamic-LDS attribute of lz_copy_block_kernel, per device (two launch sites)
 __global__ __launch_bounds__(LZB_NT) void lz_copy_block_kernel(BatchTables bt, const u64* __restrict__ tok_prefix, const uint32_t* __restrict__ tok,
                                                               const u64* __restrict__ ntok, const u64* __restrict__ d_out_len, const int32_t* __restrict__ d_status,
                                                               uint8_t* __restrict__ d_out, uint32_t lzb_min, u64 lzg_min_cap)
@@ -1965,8 +1966,7 @@ void launch_xpress_huff_decompress(hipStream_t st, const uint8_t* d_in, const Ba
 	        hipLaunchKernelGGL(xhc_parse_kernel<2>, dim3(n_slots), dim3(64), 0, st, d_in, bt, tok_prefix, cand_prefix, xb, tok); break;
 	case 4: hipLaunchKernelGGL(xhd_parse_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, tok_prefix, tok, ntok, d_out_len, d_status, xb.mode); break;
 	default: {
-		static bool attr_set = false;
-		if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_copy_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzbLds)); attr_set = true; }
+		if (g_lzb_attr.needed()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_copy_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzbLds)); g_lzb_attr.done(); }
 		hipLaunchKernelGGL(lz_copy_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes(), lzg_min_cap);
 		hipLaunchKernelGGL(lz_copy_block_kernel, dim3(bt.n_units), dim3(LZB_NT), sizeof(LzbLds), st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes(), lzg_min_cap);
 		break;
@@ -1994,8 +1994,7 @@ void launch_xpress_decompress_tokens(hipStream_t st, const uint8_t* d_in, const 
 		return;
 	}
 	if (phase == 0) { hipLaunchKernelGGL(xpt_parse_kernel, dim3(bt.n_units), dim3(64), 0, st, d_in, bt, tok_prefix, tok, ntok, d_out_len, d_status, (const uint32_t*)(x.n_big ? x.done : nullptr)); return; }
-	static bool attr_set = false;
-	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_copy_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzbLds)); attr_set = true; }
+	if (g_lzb_attr.needed()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_copy_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzbLds)); g_lzb_attr.done(); }
 	if (phase == 1) { hipLaunchKernelGGL(lz_copy_kernel, dim3(bt.n_units), dim3(64), 0, st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes(), lzg_min_cap); }
 	else { hipLaunchKernelGGL(lz_copy_block_kernel, dim3(bt.n_units), dim3(LZB_NT), sizeof(LzbLds), st, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out, lzb_min_bytes(), lzg_min_cap); }
 }

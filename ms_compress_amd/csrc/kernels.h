@@ -1,8 +1,18 @@
 // kernels.h -- host-callable launchers of the gfx950 kernels (internal to libmscomp_amd.so).
 #pragma once
 #include "common.h"
+#include <atomic>
 
 namespace msc {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: every launcher keeps one of these per kernel and sets
+// the attribute the first time it launches on a device (bit = device ordinal; two host threads racing set it twice, which is
+// harmless). A process-wide `static bool` left the second GPU of a process without the attribute.
+struct PerDeviceOnce {
+	std::atomic<uint64_t> seen[4] = {};                      // 256 device ordinals
+	bool needed() const { int d = 0; (void)hipGetDevice(&d); return !((seen[(d >> 6) & 3].load(std::memory_order_acquire) >> (d & 63)) & 1u); }
+	void done() { int d = 0; (void)hipGetDevice(&d); seen[(d >> 6) & 3].fetch_or(1ull << (d & 63), std::memory_order_release); }
+};
 
 // ---- LZNT1 (lznt1.hip) ----
 #define LZNT1_SLOT 4352u     // scratch bytes per 4 KiB chunk image (2 B header + <=4096 B payload + emit slack)
@@ -16,6 +26,9 @@ void launch_lznt1_sa_chunks(hipStream_t st, const uint8_t* d_in, const BatchTabl
 void launch_xp_links(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead);
 void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead,
                     uint16_t* mlen3, uint16_t* moff, uint32_t max_off, int clip);
+// the lazy finder (xpress_lazy.hip): Find only where a greedy parse can start a token -- Xpress, every unit at most 64 KiB. Fills the same
+// arrays for a superset of the true token starts; the offsets of all other positions are 0.
+void launch_xp_lazy2(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, uint16_t* mlen3, uint16_t* moff);
 
 // ---- Xpress stream emission (xpress_emit.hip): one wavefront per unit ----
 void set_xpress_emit_mode(int mode);
@@ -26,11 +39,6 @@ struct XpressWinBufs { u64* wtok; u64* wmat; uint32_t* wfar; uint32_t* wecur; ui
 void launch_xpress_emit(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* mlen3, const uint16_t* moff,
                         const XpressWinBufs& wb, uint8_t* d_out, u64* d_out_len, int32_t* d_status);
 
-// ---- the lazy finder (xlazy.hip): Find only where a greedy parse can start a token; fills the same arrays as launch_xp_find for a
-// superset of the true token starts and clears the offsets of all other positions. xh != 0: 0xFFFF window + chunk clipping
-// (any unit); xh == 0: 0x2000 window, every unit at most 64 KiB ----
-void launch_xp_lazy(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead,
-                    uint16_t* mlen3, uint16_t* moff, int xh, uint32_t chunk_base, uint32_t chunk_count);
 void launch_xp_links_range(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead, uint32_t chunk_base, uint32_t chunk_count);
 
 // ---- Xpress+Huffman chunk pipeline (xhuff.hip) ----

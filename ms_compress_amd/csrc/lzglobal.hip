@@ -300,7 +300,7 @@ void launch_lz_copy_global(hipStream_t st, const LzgTables& g, const BatchTables
 		hipLaunchKernelGGL(lzg_dir_kernel, dim3(g.n_tb), dim3(LZG_NT), 0, st, g, tok_prefix, tok, ntok, d_out_len, d_status);
 		break;
 	case 1:
-		{ static bool attr_set = false; if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lzg_expand_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzgLds)); attr_set = true; } }
+		{ static PerDeviceOnce attr; if (attr.needed()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lzg_expand_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzgLds)); attr.done(); } }
 		hipLaunchKernelGGL(lzg_expand_kernel, dim3(g.n_tiles), dim3(LZG_NT), sizeof(LzgLds), st, g, bt, tok_prefix, tok, ntok, d_out_len, d_status, d_out);
 		break;
 	default: {

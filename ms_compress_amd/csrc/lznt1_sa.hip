@@ -403,8 +403,8 @@ __global__ __launch_bounds__(SA_NT) void lznt1_sa_chunk_kernel(const uint8_t* __
 void launch_lznt1_sa_chunks(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* slots, uint32_t* slot_size)
 {
 	if (bt.n_chunks == 0) { return; }
-	static bool attr_set = false;
-	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lznt1_sa_chunk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SaLds)); attr_set = true; }
+	static PerDeviceOnce attr;
+	if (attr.needed()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lznt1_sa_chunk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SaLds)); attr.done(); }
 	hipLaunchKernelGGL(lznt1_sa_chunk_kernel, dim3(bt.n_chunks), dim3(SA_NT), sizeof(SaLds), st, d_in, bt, slots, slot_size);
 }
 

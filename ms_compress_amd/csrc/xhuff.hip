@@ -761,8 +761,8 @@ void launch_xh_fallback(hipStream_t st, const uint8_t* d_in, const BatchTables& 
 {
 	if (bt.n_chunks == 0) { return; }
 	const uint32_t grid = bt.n_chunks < blocks ? bt.n_chunks : blocks;
-	static bool attr_set = false;
-	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xh_fallback_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XH_FB_POOL_BYTES); attr_set = true; }
+	static PerDeviceOnce attr;
+	if (attr.needed()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xh_fallback_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XH_FB_POOL_BYTES); attr.done(); }
 	hipLaunchKernelGGL(xh_fallback_kernel, dim3(grid), dim3(512), XH_FB_POOL_BYTES, st, d_in, bt, fb_list, fb_count, tokbits, lens, codes, chunk_size);
 }
 void launch_xh_encode(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* mlen3, const uint16_t* moff,

@@ -327,33 +327,34 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 #endif
 }
 
+
 void launch_xp_links_range(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead, uint32_t chunk_base, uint32_t chunk_count)
 {
 	if (chunk_count == 0) { return; }
 	const uint32_t lds = XL_LDS_BYTES;
-	static bool attr_set = false;
-	if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_links_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+	static PerDeviceOnce attr;
+	if (attr.needed()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_links_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr.done(); }
 	hipLaunchKernelGGL(xp_links_kernel, dim3(chunk_count), dim3(1024), lds, st, d_in, bt, links, lasthead, chunk_base);
 }
 void launch_xp_links(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead)
 {
 	launch_xp_links_range(st, d_in, bt, links, lasthead, 0u, bt.n_chunks);
 }
-// tile = positions per block: 4096 for Xpress (4 blocks/CU), 8192 for Xpress+Huffman (the 64 KiB window is re-staged
-// half as often; 72 KiB of LDS, still 2 blocks/CU)
+// tile = positions per block: 4096 for Xpress (4 blocks/CU), 8192 for Xpress+Huffman (the 64 KiB window is re-staged half as
+// often; 72 KiB of LDS, still 2 blocks/CU)
 #define XH_TILE_SEL 8192u
 void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead,
                     uint16_t* mlen3, uint16_t* moff, uint32_t max_off, int clip)
 {
 	if (bt.n_chunks == 0) { return; }
-	static bool attr_set = false;
+	static PerDeviceOnce attr;
 	constexpr uint32_t TXP = 4096u, TXH = XH_TILE_SEL;
 	const uint32_t lds_xp = 0x2000u + TXP + 64u + (0x2000u + TXP) * 2u;           // data + all links of the window in LDS
 	const uint32_t lds_xh = 0x10000u + TXH + 64u;                                // data only (2 blocks/CU); links come from L2
-	if (!attr_set) {
+	if (attr.needed()) {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x2000u, 0x2000u, 512u, TXP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xp);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x10000u, 0u, 1024u, TXH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xh);
-		attr_set = true;
+		attr.done();
 	}
 	if (max_off <= 0x2000u) {
 		hipLaunchKernelGGL((xp_find_kernel<0x2000u, 0x2000u, 512u, TXP>), dim3(bt.n_chunks * (65536u / TXP)), dim3(512), lds_xp, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip);

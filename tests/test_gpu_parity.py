@@ -346,10 +346,10 @@ def test_huffman_builder_stage(oracle, gpu_ctx):
 
 
 @pytest.mark.parametrize("fmt", [3, 4])
-def test_lazy_finder_gives_the_same_bytes(oracle, gpu_ctx, fmt):
-    """csrc/xlazy.hip (Find only where a greedy parse can start a token: speculative 64-byte segments + continuation walks) against the
-    oracle on the edge families, the mixed buffer (100 000 zeros: matches longer than 8 KiB and the lagging-Fill resume points of Xpress)
-    and corpus slices. The all-positions finder is the default; this keeps the experimental one exact."""
+def test_both_find_kernels_give_the_same_bytes(oracle, gpu_ctx, fmt):
+    """Find for every position (xp_find_kernel, mscomp_amd_debug_set_finder(2)) against the oracle on the edge families, the mixed
+    buffer (100 000 zeros: matches longer than 8 KiB and the lagging-Fill resume points of Xpress) and corpus slices; the default
+    (the lazy finder of csrc/xpress_lazy.hip for Xpress units up to 64 KiB) runs in every other test."""
     import ms_compress_amd as m
     from ms_compress_amd import corpus
     lib = gpu_ctx.lib
@@ -357,7 +357,7 @@ def test_lazy_finder_gives_the_same_bytes(oracle, gpu_ctx, fmt):
     units += [corpus.file_bytes(i, 300_000).tobytes()[o:o + 65536] for i in (1, 3, 9) for o in (0, 65536, 200000)]
     if fmt == 4:
         units += [cases.mixed_buffer(), corpus.file_bytes(1, 400_000).tobytes()]          # multi-chunk units: windows reach into the previous chunk
-    lib.mscomp_amd_debug_set_finder(0)
+    lib.mscomp_amd_debug_set_finder(2)
     try:
         got, st = m.compress_units(fmt, units, ctx=gpu_ctx)
     finally:
