@@ -318,12 +318,13 @@ static void launch_xz(hipStream_t st, const uint8_t* d_in, const BatchTables& bt
 void launch_xp_lazy2(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, uint16_t* mlen3, uint16_t* moff)
 {
 	if (bt.n_chunks == 0) { return; }
-	static const int variant = [] { const char* e = getenv("MSCOMP_AMD_XZ"); return e ? atoi(e) : 0; }();   // dev switch: tile / segment shapes
+	// shapes measured on BASELINE configs[4] (ms per pass): 16 KiB tiles / 32-byte segments (512 lanes, 2 blocks = 16 waves per CU) 35.3;
+	// 16-byte segments with 1024 lanes at 64 registers 37.9; 8 KiB tiles / 16-byte segments (3 blocks = 24 waves) 39.5; / 8-byte segments 55.5
+	static const int variant = [] { const char* e = getenv("MSCOMP_AMD_XZ"); return e ? atoi(e) : 0; }();   // dev switch
 	switch (variant) {
-	case 1:  launch_xz<16384u, 32u, 4u>(st, d_in, bt, links, mlen3, moff); break;     // 512 lanes, 77 KiB: 2 blocks = 16 waves per CU
-	case 2:  launch_xz<8192u, 16u, 6u>(st, d_in, bt, links, mlen3, moff); break;      // 512 lanes, 52 KiB: 3 blocks = 24 waves per CU
-	case 3:  launch_xz<8192u, 8u, 8u>(st, d_in, bt, links, mlen3, moff); break;       // 1024 lanes, 52 KiB: 2 blocks = 32 waves per CU (64 registers)
-	default: launch_xz<16384u, 16u, 8u>(st, d_in, bt, links, mlen3, moff); break;     // 1024 lanes, 77 KiB: 2 blocks = 32 waves per CU
+	case 1:  launch_xz<16384u, 16u, 8u>(st, d_in, bt, links, mlen3, moff); break;
+	case 2:  launch_xz<8192u, 16u, 6u>(st, d_in, bt, links, mlen3, moff); break;
+	default: launch_xz<16384u, 32u, 4u>(st, d_in, bt, links, mlen3, moff); break;
 	}
 }
 
