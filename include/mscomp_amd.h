@@ -148,6 +148,22 @@ void         mscomp_amd_plan_destroy(mscomp_amd_plan* plan);
 MSCompStatus mscomp_amd_plan_execute(mscomp_amd_plan* plan, const uint8_t* d_in, uint8_t* d_out,
                                      uint64_t* d_out_len, int32_t* d_status);
 
+/* SURVEY.md 8e "Multi-GPU" + 8f-3 "host pipeline" (no counterpart in the reference: ms_compress, mscomp.h:59 / src/mscomp.cpp:113-117, is one
+ * buffer per call on one thread): n independent units given by HOST pointers, compressed on n_dev GPUs of this process. Unit i is exactly one
+ * ms_compress(format, in_ptrs[i], in_lens[i], out_ptrs[i], &out_lens[i]) call with *out_len = out_caps[i] on entry: same bytes, statuses[i] =
+ * MSCOMP_OK or MSCOMP_BUF_ERROR (out_lens[i] = 0 and nothing written behind the capacity then), the uncounted LZNT1 00 00 behind the stream
+ * when the capacity has room. Bytes of a unit's capacity behind its stream are unspecified afterwards.
+ * devices = n_dev device ordinals (NULL: 0 .. n_dev - 1; the same ordinal may appear twice: two ranges share that GPU). The units are cut into
+ * n_dev contiguous ranges with near-equal input bytes (no exchange step, no collective: units are independent); every range runs on its own
+ * host thread with its own context, three streams and double-buffered staging, batches of MSCOMP_AMD_HOST_BATCH_MB (default 512) MiB; units
+ * that lie back to back in the caller's memory travel as one copy. Returns MSCOMP_OK when every range ran (per-unit results in statuses),
+ * MSCOMP_ARG_ERROR for a bad format / device / pointer, MSCOMP_MEM_ERROR / MSCOMP_ERRNO when a range could not run (statuses of units not
+ * reached stay MSCOMP_ERRNO). Contexts and staging are kept per device between calls; mscomp_amd_host_pool_release() frees them. */
+MSCompStatus mscomp_amd_compress_units_host(MSCompFormat format, int n_dev, const int* devices, size_t n_units,
+                                            const uint8_t* const* in_ptrs, const size_t* in_lens, uint8_t* const* out_ptrs, const size_t* out_caps,
+                                            size_t* out_lens, MSCompStatus* statuses);
+void         mscomp_amd_host_pool_release(void);
+
 /* Convenience: create plan + execute + stream-synchronize + destroy. */
 MSCompStatus mscomp_amd_compress_batch(mscomp_amd_ctx* ctx, MSCompFormat format, size_t n_units,
                                        const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len,
@@ -210,6 +226,10 @@ int          mscomp_amd_debug_lzg_open(mscomp_amd_ctx* ctx, uint64_t words, uint
  * start a token (csrc/xpress_lazy.hip); 2 = Find for every position everywhere (xp_find_kernel, what longer streams and Xpress+Huffman
  * always use). The parse kernels get the same answers on every path they walk. Process-wide. */
 void         mscomp_amd_debug_set_finder(int mode);
+/* Test hook: how a host-pointer ms_compress(MSCOMP_LZNT1) of a large buffer (>= 36 MiB) runs. 0 = default (the caller's buffers are mapped
+ * into the GPU's address space, one launch; falls back to 1 when the mapping fails), 1 = always in slices on three streams
+ * (csrc/api.hip lznt1_compress_pipelined; the same as MSCOMP_AMD_ONE_ZEROCOPY=0 in the environment). Same bytes and statuses. Process-wide. */
+void         mscomp_amd_debug_set_one_shot(int mode);
 /* Test hook: the LZNT1 chunk stage has two bit-identical kernels (one wave / four waves per 4 KiB chunk). 0 = default, 1 / 2 = force. */
 void         mscomp_amd_debug_set_lznt1(int mode);
 /* Test hook: LZNT1 decompression finds the chunk headers by walking speculated chains per 48 KiB segment of the input; a segment

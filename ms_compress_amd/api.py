@@ -33,7 +33,7 @@ EXPORTS = [  # every symbol include/mscomp_amd.h declares (tests check the libra
     "ms_deflate_init", "ms_deflate", "ms_deflate_end", "lznt1_deflate_init", "lznt1_deflate", "lznt1_deflate_end",
     "xpress_deflate_init", "xpress_deflate", "xpress_deflate_end", "xpress_inflate_init", "xpress_inflate", "xpress_inflate_end",
     "ms_decompress", "lznt1_decompress", "xpress_decompress", "xpress_huff_decompress", "mscomp_amd_plan_create_decompress", "mscomp_amd_decompress_batch",
-    "mscomp_amd_version", "mscomp_amd_debug_xpress_matches", "mscomp_amd_debug_huff_lengths", "mscomp_amd_debug_lds_lane_order", "mscomp_amd_debug_set_xpress_emit", "mscomp_amd_debug_set_lznt1", "mscomp_amd_debug_set_finder", "mscomp_amd_debug_set_xpress_decoder", "mscomp_amd_debug_lzg_open", "mscomp_amd_set_lznt1_sa_dict", "mscomp_amd_get_lznt1_sa_dict", "mscomp_amd_debug_lzd_walked",
+    "mscomp_amd_version", "mscomp_amd_debug_xpress_matches", "mscomp_amd_debug_huff_lengths", "mscomp_amd_debug_lds_lane_order", "mscomp_amd_debug_set_xpress_emit", "mscomp_amd_debug_set_lznt1", "mscomp_amd_compress_units_host", "mscomp_amd_host_pool_release", "mscomp_amd_debug_set_finder", "mscomp_amd_debug_set_one_shot", "mscomp_amd_debug_set_xpress_decoder", "mscomp_amd_debug_lzg_open", "mscomp_amd_set_lznt1_sa_dict", "mscomp_amd_get_lznt1_sa_dict", "mscomp_amd_debug_lzd_walked",
 ]
 
 
@@ -120,6 +120,12 @@ def load_library():
     lib.mscomp_amd_debug_set_xpress_decoder.restype = None
     lib.mscomp_amd_debug_set_finder.argtypes = [C.c_int]
     lib.mscomp_amd_debug_set_finder.restype = None
+    lib.mscomp_amd_compress_units_host.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mscomp_amd_compress_units_host.restype = C.c_int
+    lib.mscomp_amd_host_pool_release.argtypes = []
+    lib.mscomp_amd_host_pool_release.restype = None
+    lib.mscomp_amd_debug_set_one_shot.argtypes = [C.c_int]
+    lib.mscomp_amd_debug_set_one_shot.restype = None
     lib.mscomp_amd_debug_set_lznt1.argtypes = [C.c_int]
     lib.mscomp_amd_debug_set_lznt1.restype = None
     lib.mscomp_amd_debug_lzd_walked.argtypes = [C.c_void_p]
@@ -309,3 +315,21 @@ def compress_units(fmt, units, ctx=None, capacities=None, decompress=False):
     return res, [int(x) for x in h_st[: len(units)]]
 
 
+
+
+def compress_units_host(fmt, in_arrays, out_arrays, devices=(0,)):
+    """mscomp_amd_compress_units_host: units given as numpy uint8 arrays (host memory, any layout), outputs written into the numpy uint8
+    arrays of out_arrays (capacity = their length), on the GPUs `devices` (a range per entry; an ordinal may repeat). Returns
+    (status of the call, out_lens uint64 array, statuses int32 array). Nothing is copied on the Python side."""
+    lib = load_library()
+    n = len(in_arrays)
+    assert len(out_arrays) == n
+    ip = (C.c_void_p * max(1, n))(*[a.ctypes.data for a in in_arrays])
+    il = (C.c_size_t * max(1, n))(*[a.size for a in in_arrays])
+    op = (C.c_void_p * max(1, n))(*[a.ctypes.data for a in out_arrays])
+    oc = (C.c_size_t * max(1, n))(*[a.size for a in out_arrays])
+    ol = np.zeros(max(1, n), dtype=np.uint64)
+    st = np.full(max(1, n), -9, dtype=np.int32)
+    dv = (C.c_int * len(devices))(*[int(d) for d in devices])
+    rc = lib.mscomp_amd_compress_units_host(int(fmt), len(devices), dv, n, ip, il, op, oc, ol.ctypes.data, st.ctypes.data)
+    return rc, ol[:n], st[:n]

@@ -27,6 +27,7 @@ static std::atomic<uint64_t> g_mode_epoch{1};
 static std::atomic<int> g_finder_mode{1};              // 1 = default (Xpress units up to 64 KiB: the lazy finder, xpress_lazy.hip), 2 = Find for every position everywhere
 static int lznt1_sa_env() { const char* e = getenv("MSCOMP_AMD_LZNT1_SA_DICT"); return (e && *e && *e != '0') ? 1 : 0; }
 static std::atomic<int> g_lznt1_sa{lznt1_sa_env()};    // 1 = LZNT1 compresses with the suffix-array dictionary flavour (lznt1_sa.hip; the reference's MSCOMP_WITH_LZNT1_SA_DICT build)
+static std::atomic<int> g_one_zero_copy{[] { const char* e = getenv("MSCOMP_AMD_ONE_ZEROCOPY"); return (e && *e == '0') ? 0 : 1; }()};   // large host-pointer LZNT1 calls: 1 = caller buffers mapped, one launch (default), 0 = slices on three streams
 static std::atomic<int> g_xpd_mode{0};                 // Xpress decompression: 0 = tokens a flag word at a time + copy kernels (default; large streams by segments), 1 = xpd_kernel (a token at a time, bytes in the same wave), 2 = as 0 without the segments
 struct DevBuf {
 	void* p = nullptr; size_t cap = 0;
@@ -120,6 +121,17 @@ struct KernelTimer {
 	{ if (c->profiling) { r.a = get_event(c); r.b = get_event(c); (void)hipEventRecord(r.a, c->stream); } }
 	~KernelTimer() { if (c->profiling) { (void)hipEventRecord(r.b, c->stream); c->recs.push_back(r); } }
 };
+
+// Bytes an OPTIONAL fast-path scratch buffer may take: the environment's cap, and never more than half of what the device has free
+// right now (what the buffer already holds counts as free: reserve() reuses it). The fast paths have fallbacks that need no scratch,
+// so a plan never fails for them (the constants above assume a 288 GB device that is otherwise empty; a caller may hold most of it).
+uint64_t optional_scratch_budget(uint64_t env_cap, size_t already_held)
+{
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return env_cap; }
+	const uint64_t half = ((uint64_t)free_b + already_held) / 2;
+	return env_cap < half ? env_cap : half;
+}
 
 uint32_t chunks_of(MSCompFormat f, bool decompress, uint64_t n)
 {
@@ -287,15 +299,17 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 				if (out_cap[i] > 65536u) { scr += most + most / 4 + 2; }   // a buffer of several chunks: its candidates keep their tokens (no second walk)
 			}
 			tp[n_units] = slots; tp[2 * n_units + 1] = cands; tp[3 * n_units + 2] = scr;
-			{	// ... if that scratch is affordable (MSCOMP_AMD_XHC_SCR_MAX_MB, default 32 GiB of the 288; 0 = always walk twice)
-				static const uint64_t scr_budget = [] { const char* e = getenv("MSCOMP_AMD_XHC_SCR_MAX_MB"); const long long v = e ? atoll(e) : 32768; return (uint64_t)(v < 0 ? 0 : v) << 20; }();
-				if (scr * XHC_SCR * 4 > scr_budget) { for (size_t i = 0; i <= n_units; ++i) { tp[2 * (n_units + 1) + i] = 0; } scr = 0; }
-				p->xhc_scr = scr;
-			}
 			if (cands > 0x7FFFFFF0u) { p->tables.release(); delete p; return MSCOMP_ARG_ERROR; }
 			p->xhc_slots = (uint32_t)cands;
 			okd = p->tokpre.reserve(tp.size() * 8) && c->dz_tok.reserve(slots * 4 + 256) && c->dz_ntok.reserve((n_units + 1) * 8) &&
-			      c->dz_xhc.reserve(((size_t)n_units + 1) * 8 + (size_t)cands * (4 * 4 + 3 * 8) + 64) && (scr == 0 || c->dz_scr.reserve(scr * XHC_SCR * 4 + 64));
+			      c->dz_xhc.reserve(((size_t)n_units + 1) * 8 + (size_t)cands * (4 * 4 + 3 * 8) + 64);
+			{	// ... if that scratch is affordable: at most MSCOMP_AMD_XHC_SCR_MAX_MB (default 32 GiB; 0 = always walk twice) and at most half of
+				// what the device has free right now; a reservation that fails anyway switches the path off (the second walk needs no scratch)
+				static const uint64_t scr_env = [] { const char* e = getenv("MSCOMP_AMD_XHC_SCR_MAX_MB"); const long long v = e ? atoll(e) : 32768; return (uint64_t)(v < 0 ? 0 : v) << 20; }();
+				const uint64_t need = scr * XHC_SCR * 4 + 64, scr_budget = optional_scratch_budget(scr_env, c->dz_scr.cap);
+				if (scr && (need > scr_budget || !okd || !c->dz_scr.reserve(need))) { for (size_t i = 0; i <= n_units; ++i) { tp[2 * (n_units + 1) + i] = 0; } scr = 0; }
+				p->xhc_scr = scr;
+			}
 			if (okd && (hipMemcpyAsync(p->tokpre.p, tp.data(), tp.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
 			            hipStreamSynchronize(c->stream) != hipSuccess)) { p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_ERRNO; }
 		}
@@ -316,7 +330,8 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 		if (okd && (format == MSCOMP_XPRESS || format == MSCOMP_XPRESS_HUFF)) {
 			// units with room for LZG_MIN_CAP bytes or more get their bytes from all CUs (lzglobal.hip): 4 bytes of scratch per byte of capacity;
 			// when that is more than the budget (MSCOMP_AMD_LZG_MAX_MB, default 64 GiB of the 288; 0 switches the path off) the block-per-unit kernel takes them
-			static const uint64_t budget = [] { const char* e = getenv("MSCOMP_AMD_LZG_MAX_MB"); const long long v = e ? atoll(e) : 65536; return (uint64_t)(v < 0 ? 0 : v) << 20; }();
+			static const uint64_t budget_env = [] { const char* e = getenv("MSCOMP_AMD_LZG_MAX_MB"); const long long v = e ? atoll(e) : 65536; return (uint64_t)(v < 0 ? 0 : v) << 20; }();
+			const uint64_t budget = optional_scratch_budget(budget_env, c->lzg_words.cap);   // ... and never more than half of the free HBM: the block kernel needs none of it
 			std::vector<uint32_t> big;
 			uint64_t words = 0;
 			bool too_large = false;                                       // (32-bit word indices: a unit with room for 4 GiB keeps the whole plan on the block kernel, which every such unit then takes)
@@ -346,10 +361,12 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 				}
 				tbp[nb] = tb; tlp[nb] = tl; wdp[nb] = wd;
 				if (tb < 0x7FFFFFF0ull && tl < 0x7FFFFFF0ull) {
-					okd = p->lzg_tab.reserve(tab.size() * 8) && c->lzg_bsum.reserve(tb * 8 + 64) && c->lzg_dir.reserve(tl * 8 + 64) && c->lzg_words.reserve(wd * 4 + LZG_PASSES * 4 + tl + 64);
-					if (okd && (hipMemcpyAsync(p->lzg_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+					// an allocation that fails here only switches this (optional) path off: the block-per-unit kernel takes the units instead
+					const bool got = p->lzg_tab.reserve(tab.size() * 8) && c->lzg_bsum.reserve(tb * 8 + 64) && c->lzg_dir.reserve(tl * 8 + 64) && c->lzg_words.reserve(wd * 4 + LZG_PASSES * 4 + tl + 64);
+					if (got && (hipMemcpyAsync(p->lzg_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
 					            hipStreamSynchronize(c->stream) != hipSuccess)) { p->lzg_tab.release(); p->tokpre.release(); p->tables.release(); delete p; return MSCOMP_ERRNO; }
-					if (okd) { p->lzg_big = (uint32_t)nb; p->lzg_tb = (uint32_t)tb; p->lzg_tiles = (uint32_t)tl; p->lzg_words = wd; }
+					if (got) { p->lzg_big = (uint32_t)nb; p->lzg_tb = (uint32_t)tb; p->lzg_tiles = (uint32_t)tl; p->lzg_words = wd; }
+					else { p->lzg_tab.release(); (void)hipGetLastError(); }
 				}
 			}
 		}
@@ -747,6 +764,7 @@ int mscomp_amd_debug_lzg_open(mscomp_amd_ctx* c, uint64_t words, uint32_t* out)
 }
 void mscomp_amd_debug_set_xpress_decoder(int mode) { g_xpd_mode.store(mode, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 void mscomp_amd_debug_set_finder(int mode) { g_finder_mode.store(mode, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
+void mscomp_amd_debug_set_one_shot(int mode) { g_one_zero_copy.store(mode == 1 ? 0 : 1, std::memory_order_relaxed); }
 void mscomp_amd_debug_set_lznt1(int mode) { set_lznt1_mode(mode); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 
 // Hardware self-check (see util.hip): lanes whose returning LDS atomic was NOT served in lane order, summed over
@@ -832,7 +850,7 @@ struct OneShotTls {
 // 1.7 ms pageable); without it the copies still work.
 // Slices of about 24 MiB (6 144 chunks: three rounds of the chunk kernel's 2 048 resident blocks; with 4 MiB slices the kernels ran at a
 // third of their batch rate and the call took 4.9 instead of 2.7 ms), equal in size, at least two.
-static const size_t ONE_SLICE = (getenv("MSCOMP_AMD_ONE_SLICE_MB") ? (size_t)atoi(getenv("MSCOMP_AMD_ONE_SLICE_MB")) : 24u) << 20;
+static const size_t ONE_SLICE = [] { const char* e = getenv("MSCOMP_AMD_ONE_SLICE_MB"); const long v = e ? atol(e) : 24; return (size_t)(v >= 1 && v <= 4096 ? v : 24) << 20; }();   // (a value that is no number of MiB in 1..4096 is ignored)
 static MSCompStatus lznt1_compress_pipelined(OneShotTls& tls, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len)
 {
 	mscomp_amd_ctx* c = tls.ctx;
@@ -934,8 +952,8 @@ static MSCompStatus one_shot(MSCompFormat format, bool decompress, const uint8_t
 	DeviceGuard g(c->device);
 	const size_t cap = *out_len;
 	if (!decompress && format == MSCOMP_LZNT1 && in_len >= ONE_SLICE + ONE_SLICE / 2) {
-		static const bool zero_copy = [] { const char* e = getenv("MSCOMP_AMD_ONE_ZEROCOPY"); return !(e && *e == '0'); }();   // (0: always the sliced path below)
-		if (zero_copy) { const MSCompStatus z = lznt1_zero_copy(tls, false, in, in_len, out, out_len); if ((int)z != -100) { return z; } }
+		// (MSCOMP_AMD_ONE_ZEROCOPY=0 / mscomp_amd_debug_set_one_shot(1): always the sliced path below)
+		if (g_one_zero_copy.load(std::memory_order_relaxed)) { const MSCompStatus z = lznt1_zero_copy(tls, false, in, in_len, out, out_len); if ((int)z != -100) { return z; } }
 		return lznt1_compress_pipelined(tls, in, in_len, out, out_len);
 	}
 	// The device copy of the output is sized by what the format can PRODUCE, never by a generous caller capacity (legal in the

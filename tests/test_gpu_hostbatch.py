@@ -1,0 +1,131 @@
+"""-m gpu: mscomp_amd_compress_units_host (include/mscomp_amd.h; SURVEY.md 8e + 8f-3) -- host pointers in, host pointers out, one or several
+device ranges in ONE process. Every unit is one ms_compress call of the reference: bytes against the reference's digests
+(tests/golden/corpus_full.json) and against the checker, MSCOMP_BUF_ERROR for short capacities with nothing written behind them, the
+uncounted LZNT1 00 00. Two ranges on the SAME GPU run everywhere (two worker threads, two contexts, pipelined batches); two ranges on
+two GPUs run where the box has them (skipped below 2 devices: the driver's 8-GPU node executes it)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "corpus_full.json")))
+KEY = {2: "lznt1", 3: "xpress_units64k", 4: "xpress_huff"}
+GUARD = 0x5A
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def _corpus_job(fmt, names):
+    """(inputs, per-file unit counts): LZNT1 / Xpress+Huffman one unit per file, Xpress the file cut into 64 KiB units (views of one array)"""
+    from ms_compress_amd import corpus
+    ins, counts = [], []
+    for nm in names:
+        data = np.ascontiguousarray(corpus.by_name(nm))
+        if fmt == 3:
+            units = [data[o:o + 65536] for o in range(0, len(data), 65536)]
+        else:
+            units = [data]
+        ins += units; counts.append(len(units))
+    return ins, counts
+
+
+def _check_files(fmt, names, counts, outs, lens, st):
+    u = 0
+    for nm, k in zip(names, counts):
+        assert bool((st[u:u + k] == 0).all()), nm
+        blob = b"".join(bytes(outs[u + i][: int(lens[u + i])]) for i in range(k))
+        g = GOLD[nm][KEY[fmt]]
+        assert len(blob) == g["len"] and sha(blob) == g["sha256"], (fmt, nm)
+        u += k
+
+
+@pytest.mark.parametrize("fmt", [2, 3, 4])
+@pytest.mark.parametrize("devices", [(0,), (0, 0), (0, 0, 0)])
+def test_files_through_host_pointers(gpu_ctx, fmt, devices, monkeypatch):
+    """five corpus files (69 MB) in small batches (several per range: the pipeline really alternates its two buffer sets); separate output
+    arrays per unit (one download each) -- against the reference's digests"""
+    import ms_compress_amd as m
+    monkeypatch.setenv("MSCOMP_AMD_HOST_BATCH_MB", "8")          # (read once per process: the first test decides; small either way)
+    names = ["xml", "ooffice", "sao", "dickens", "samba"]
+    ins, counts = _corpus_job(fmt, names)
+    outs = [np.full(m.max_compressed_size(fmt, a.size) + 2, GUARD, dtype=np.uint8) for a in ins]
+    rc, lens, st = m.compress_units_host(fmt, ins, outs, devices=devices)
+    assert rc == 0
+    _check_files(fmt, names, counts, outs, lens, st)
+    if fmt == 2:                                                  # the uncounted End_of_buffer bytes behind every stream (lznt1_compress.cpp:270)
+        for o, l in zip(outs, lens):
+            assert o[int(l)] == 0 and o[int(l) + 1] == 0
+
+
+@pytest.mark.parametrize("fmt", [2, 3, 4])
+def test_contiguous_layout_and_short_capacities(oracle, gpu_ctx, fmt):
+    """outputs laid out capacity after capacity in ONE array (the layout mscomp_amd_plan_layout gives: one download per batch), edge-case
+    units, and capacities that are exact / one short / zero: statuses and bytes of the checker, guards behind every capacity untouched"""
+    import ms_compress_amd as m
+    rng = np.random.default_rng(7)
+    units = [u for u in cases.edge_cases()[::5] if len(u) < 200000] + [cases.mixed_buffer()[:150000], b"", b"a"]
+    exp = [oracle.oracle_compress(fmt, u)[1] for u in units]
+    caps = []
+    for i, e in enumerate(exp):
+        caps.append([len(e), max(0, len(e) - 1), m.max_compressed_size(fmt, len(units[i])) + 2, 0][i % 4])
+    ins = [np.frombuffer(u, dtype=np.uint8) if len(u) else np.zeros(0, dtype=np.uint8) for u in units]
+    blob = np.full(sum(caps) + 64, GUARD, dtype=np.uint8)
+    outs, pos = [], 0
+    for c in caps:
+        outs.append(blob[pos:pos + c]); pos += c
+    rc, lens, st = m.compress_units_host(fmt, ins, outs, devices=(0, 0))
+    assert rc == 0
+    for i, (u, e, c) in enumerate(zip(units, exp, caps)):
+        if c >= len(e):
+            assert st[i] == 0 and int(lens[i]) == len(e) and bytes(outs[i][: len(e)]) == e, (fmt, i, len(u), c)
+        else:
+            assert st[i] == m.MSCOMP_BUF_ERROR and int(lens[i]) == 0, (fmt, i, len(u), c)
+    assert bool((blob[pos:] == GUARD).all())
+    # separate arrays with guards: nothing behind a capacity is touched, whatever the status
+    outs2 = [np.full(c + 32, GUARD, dtype=np.uint8) for c in caps]
+    rc, lens2, st2 = m.compress_units_host(fmt, ins, [o[:c] for o, c in zip(outs2, caps)], devices=(0,))
+    assert rc == 0 and np.array_equal(st2, st) and np.array_equal(lens2, lens)
+    for o, c in zip(outs2, caps):
+        assert bool((o[c:] == GUARD).all())
+
+
+def test_argument_errors(gpu_ctx):
+    import ms_compress_amd as m
+    a = np.zeros(100, dtype=np.uint8); o = np.zeros(200, dtype=np.uint8)
+    assert m.compress_units_host(1, [a], [o])[0] == m.MSCOMP_ARG_ERROR            # no such format (mscomp.cpp:115)
+    assert m.compress_units_host(2, [a], [o], devices=(99,))[0] == m.MSCOMP_ARG_ERROR
+    rc, lens, st = m.compress_units_host(2, [], [])
+    assert rc == 0 and len(lens) == 0
+
+
+def test_two_gpus_in_one_process(gpu_ctx):
+    """SURVEY 8e on real hardware: two contexts on two devices of one process (the per-device function attributes, the lane-order check
+    and the worker pool are per device). Needs two GPUs: skipped on the one-GPU box, runs on the driver's multi-GPU node."""
+    import torch
+    import ms_compress_amd as m
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    names = ["xml", "ooffice", "sao", "dickens", "samba", "osdb"]
+    for fmt in (2, 3, 4):
+        ins, counts = _corpus_job(fmt, names)
+        outs = [np.full(m.max_compressed_size(fmt, a.size) + 2, GUARD, dtype=np.uint8) for a in ins]
+        rc, lens, st = m.compress_units_host(fmt, ins, outs, devices=(0, 1))
+        assert rc == 0
+        _check_files(fmt, names, counts, outs, lens, st)
+    # and the batch interface directly: a context per device, the same plan on both
+    data = cases.mixed_buffer()
+    for fmt in (2, 3, 4):
+        res = []
+        for dev in (0, 1):
+            ctx = m.Context(device=dev)
+            out, st = m.compress_units(fmt, [data, data[:70000]], ctx=ctx)
+            ctx.close()
+            res.append(out)
+        assert res[0] == res[1]

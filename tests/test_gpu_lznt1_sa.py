@@ -79,8 +79,9 @@ def test_switching_back_replays_the_default_flavour(oracle, gpu_ctx):
 
 
 def test_host_pointer_one_shot_calls(oracle, sa_mode):
-    """ms_compress with host pointers (mscomp.h; the thread's cached plans notice the switch), small and sliced (> 48 MiB: uploads, kernels and
-    downloads on three streams, csrc/api.hip lznt1_compress_pipelined): the flavour's bytes through the drop-in entry point itself."""
+    """ms_compress with host pointers (mscomp.h; the thread's cached plans notice the switch), small and large (>= 36 MiB: the caller's
+    buffers mapped, one launch -- csrc/api.hip lznt1_zero_copy; the sliced path is tests/test_gpu_hostptr.py's): the flavour's bytes
+    through the drop-in entry point itself."""
     import ms_compress_amd as m
     from ms_compress_amd import corpus
     small = bytes(np.random.default_rng(4).choice(np.frombuffer(b"abc", np.uint8), 50000))
