@@ -12,7 +12,8 @@ replicated 16x (192 files, 3 391 017 280 B), cut into independent units, split o
 `sharding.shard_ranges` (contiguous ranges balanced by bytes, no data-path collective: SURVEY.md 8e) -- STRONG scaling:
 the job is fixed, a rank holds 1/N of it in HBM. A "step" is ONE pass of the hot path over the rank's shard, inputs
 resident in HBM. value = bytes of the whole job x K / max-over-ranks time of the K steps (barrier + synchronize on
-both sides). The headline codec is LZNT1 (one unit per file, 4 KiB chunks inside: 827 936 chunks); Xpress (51 824
+both sides). After the timed region every rank checks what its first replica of the 12 files compressed to against the
+digests of the REAL reference (tests/golden/corpus_full.json) -- `parity_checked` -- and refuses to print a number otherwise. The headline codec is LZNT1 (one unit per file, 4 KiB chunks inside: 827 936 chunks); Xpress (51 824
 independent 64 KiB units) and Xpress+Huffman (one unit per file, 64 KiB chunks with the previous chunk as window) run on
 the same batch right after and are reported under extra.config5, reduced over the ranks the same way.
 
@@ -39,14 +40,14 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 REPLICAS = 16                # BASELINE.json configs[4]
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"              # the committed profiles the PMC / SQ figures are looked up in; a missing file falls back to r02 and says so
 # the kernel SYMBOL behind the library's timer name of each codec's dominant kernel (template instance included, so that the
 # PMC figures of the Xpress and the Xpress+Huffman match finder are never mixed up)
 SYMBOLS = {
     (2, "lznt1_chunk_kernel"): "msc::lznt1_chunk4_kernel",
     (3, "xp_find_kernel"): "msc::xp_find_kernel<8192u, 8192u, 512u, 4096u>",
     (4, "xp_find_kernel"): "msc::xp_find_kernel<65536u, 0u, 1024u, 8192u>",
-    (3, "xp_lazy2_kernel"): "msc::xp_lazy2_kernel",
+    (3, "xp_lazy2_kernel"): "msc::xp_lazy2_kernel<16384u, 32u, 4u>",
 }
 
 
@@ -161,6 +162,36 @@ class Job:
         self.d_in = self.d_out = None
 
 
+GOLD_KEY = {2: "lznt1", 3: "xpress_units64k", 4: "xpress_huff"}
+
+
+def parity_gate(m, job, fmt, cor, first_unit):
+    """The in-run parity gate: SHA-256 of what this rank's FIRST replica of the 12 files compressed to, file by file, against
+    the digests the real reference gave for them (tests/golden/corpus_full.json, written by tools/make_golden_full.py from oracle/_ref).
+    Outside the timed region. True / False, or None when the data is not the synthetic corpus or the shard does not start at a replica."""
+    import hashlib
+    import torch
+    from ms_compress_amd import corpus
+    if corpus.source() != "synthetic":
+        return None
+    per_file = [1 if fmt != 3 else (int(l) + 65535) // 65536 for l in cor.flen]
+    nu = sum(per_file)
+    if first_unit % nu != 0 or job.n < nu:
+        return None
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "corpus_full.json")))
+    d_packed, d_poff = m.compact_batch(job.ctx, job.out_off[:nu], job.caps[:nu], job.d_out, job.d_len)
+    torch.cuda.synchronize()
+    poff = d_poff.cpu().numpy()
+    first = d_packed[: int(poff[nu])].cpu().numpy()
+    u, ok = 0, True
+    for i, name in enumerate(corpus.NAMES):
+        a, b = int(poff[u]), int(poff[u + per_file[i]])
+        g = gold[name][GOLD_KEY[fmt]]
+        ok = ok and (b - a == g["len"]) and hashlib.sha256(first[a:b].tobytes()).hexdigest() == g["sha256"]
+        u += per_file[i]
+    return bool(ok)
+
+
 def timed(job, steps, warmup, sharding):
     """EXACTLY `steps` steps between barrier + synchronize on both sides; HIP events around every kernel on its launch stream"""
     import torch
@@ -182,10 +213,13 @@ def timed(job, steps, warmup, sharding):
 
 # ---------------------------------------------------------------- roofline ----------------------------------------------------------------
 def _profile_doc(name):
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "%s_%s.json" % (PROFILE_TAG, name))))
-    except Exception:
-        return None
+    """(document, tag it came from): the current round's committed profile, else the round before's (and the line says which)"""
+    for tag in (PROFILE_TAG, "r02"):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, name)))), tag
+        except Exception:
+            continue
+    return None, None
 
 
 def pmc_traffic(fmt, timer_name, workload_key):
@@ -193,23 +227,27 @@ def pmc_traffic(fmt, timer_name, workload_key):
     (profiles/r02_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench command, FETCH_SIZE
     doubled per the gfx950 note of the microarch guide). Collected offline -- a live run cannot read PMCs -- and keyed by the exact
     kernel symbol (template arguments included) AND the workload, so it is attached only to the launch it was measured on."""
-    doc = _profile_doc("pmc_traffic")
+    doc, tag = _profile_doc("pmc_traffic")
     sym = SYMBOLS.get((fmt, timer_name))
     if not doc or not sym:
-        return None
+        return None, None
     rec = doc.get("by_codec", {}).get(workload_key, {}).get(CODEC_OF[fmt], {}).get(sym)
-    return rec["hbm_bytes_per_launch_corrected"] if rec else None
+    return (rec["hbm_bytes_per_launch_corrected"], tag) if rec else (None, None)
 
 
 def secondary_bound(fmt, timer_name, workload_key):
     """What actually limits the kernel (the HBM fraction of these latency / issue-bound integer kernels says little): busiest
     pipe and wait shares from the committed SQ-counter passes (profiles/r02_sq_counters.json)."""
-    doc = _profile_doc("sq_counters")
+    doc, tag = _profile_doc("sq_counters")
     sym = SYMBOLS.get((fmt, timer_name))
     if not doc or not sym:
         return None
     rec = doc.get("workloads", {}).get("single_gpu", {}).get(sym)       # (SQ counters are collected on the single-GPU legs: shares, not totals)
-    return rec["derived"] if rec and rec.get("codec") == CODEC_OF[fmt] else None
+    if not (rec and rec.get("codec") == CODEC_OF[fmt]):
+        return None
+    out = dict(rec["derived"])
+    out["from"] = "profiles/%s_sq_counters.json, workload single_gpu%s" % (tag, "" if workload_key == "single_gpu" else " (NOT this workload: shares of wave time carry over, totals do not)")
+    return out
 
 
 def roofline(fmt, prof, in_bytes, out_bytes, steps, workload_key):
@@ -223,8 +261,10 @@ def roofline(fmt, prof, in_bytes, out_bytes, steps, workload_key):
     # algorithmic bytes: 1 B HBM read + CR B HBM write per input byte, for the units one launch processes
     alg = (in_bytes + out_bytes) / launches_per_step
     ach = alg / (per_launch_ms * 1e-3) / 1e9
+    traffic, traffic_tag = pmc_traffic(fmt, dom, workload_key)
     return {"bound": "hbm", "kernel": SYMBOLS.get((fmt, dom), dom), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(fmt, dom, workload_key),
+            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "traffic_from": ("profiles/%s_pmc_traffic.json (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)" % traffic_tag) if traffic else None,
             "hbm_read_frac": round(in_bytes / launches_per_step / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "kernel_ms_per_launch": round(per_launch_ms, 4), "launches_per_step": launches_per_step,
             "kernel_share_of_gpu_time": round(ms / tot_ms, 3) if tot_ms else None,
@@ -244,23 +284,44 @@ def _cpu_timed(fn, fmt, units, caps, cores, budget_s):
     return 1 + more, dt
 
 
+def _malloc_tuning():
+    """the reference's LZNT1 encoder reallocs its output as it grows and does not scale across threads under glibc's
+    defaults (every shrink / grow of a large block is an mmap_sem round trip: 23 MB/s on 8 threads against 30 MB/s on one, 138 MB/s with
+    the two tunables raised). The same tunables MALLOC_TOP_PAD_ / MALLOC_TRIM_THRESHOLD_ set, through mallopt, for this process's CPU legs."""
+    import ctypes
+    try:
+        libc = ctypes.CDLL(None)
+        ok = libc.mallopt(-2, 64 << 20) == 1 and libc.mallopt(-1, 512 << 20) == 1        # M_TOP_PAD, M_TRIM_THRESHOLD
+        return "mallopt(M_TOP_PAD = 64 MiB, M_TRIM_THRESHOLD = 512 MiB) set for the CPU legs (SURVEY 8d)" if ok else "mallopt refused: glibc defaults"
+    except Exception:
+        return "glibc defaults (mallopt not available)"
+
+
 def cpu_baseline(fmt, blob, budget_s=10.0):
     """The reference's own CPU encoder (oracle/_ref, compiled from /root/reference) -- or our C port when that file did not
-    travel -- on this host's cores, over a bounded sample of the SAME workload (prefix of the batch, split on 64 KiB-aligned
-    boundaries so that every thread does independent ms_compress calls). Reported baseline, not the target."""
+    travel -- on this host's cores, over a bounded sample of the SAME workload (prefix of the batch, cut on 64 KiB-aligned
+    boundaries into one slice per thread, so that every thread does one independent ms_compress call per pass), and on ONE thread
+    over the first slice. Reported baseline, not the target."""
     from oracle import loader
     ref = loader.load_ref()
     kind = "reference" if ref is not None else "port"
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    host_cores = os.cpu_count() or 1
+    threads = max(1, min(host_cores, 256))            # (oracle/mscomp_oracle.c orc_time_units: at most 256 threads)
+    malloc = _malloc_tuning()
     per = 4 << 20                                  # 4 MiB per thread: ~0.1-0.15 s of single-core work per pass
-    sample = min(len(blob), per * cores) // 65536 * 65536
+    piece = max(65536, min(per, len(blob) // threads) // 65536 * 65536)
+    sample = piece * threads
     data = blob[:sample].tobytes()
-    piece = max(65536, sample // cores // 65536 * 65536)
     slices = [data[o:o + piece] for o in range(0, sample, piece)]
+    assert len(slices) == threads
     caps = [loader.load_oracle().orc_max_compressed_size(fmt, len(x)) + 2 for x in slices]
-    passes, dt = _cpu_timed(ref.ms_compress if ref is not None else None, fmt, slices, caps, len(slices), budget_s)
-    return {"value": round(sample * passes / dt / 1e6, 1), "unit": "MB/s", "cores": len(slices), "kind": kind,
-            "sample": "%d passes over the first %d B of the batch, %d threads x %d B independent ms_compress calls" % (passes, sample, len(slices), piece)}
+    fn = ref.ms_compress if ref is not None else None
+    passes, dt = _cpu_timed(fn, fmt, slices, caps, threads, budget_s)
+    p1, dt1 = _cpu_timed(fn, fmt, slices[:1], caps[:1], 1, min(2.0, budget_s / 4))
+    return {"value": round(sample * passes / dt / 1e6, 1), "unit": "MB/s", "cores": threads, "host_cores": host_cores, "kind": kind,
+            "single_thread": {"value": round(piece * p1 / dt1 / 1e6, 1), "unit": "MB/s", "sample": "%d passes over the first %d B, one thread" % (p1, piece)},
+            "malloc": malloc,
+            "sample": "%d passes over the first %d B of the batch, %d threads x %d B: one independent ms_compress call per thread and pass" % (passes, sample, threads, piece)}
 
 
 def cpu_decompress_baseline(fmt, blob, budget_s=3.0, whole=None):
@@ -270,7 +331,7 @@ def cpu_decompress_baseline(fmt, blob, budget_s=3.0, whole=None):
     from oracle import loader
     ref = loader.load_ref()
     kind = "reference" if ref is not None else "port"
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    cores = max(1, min(os.cpu_count() or 1, 256))
     unit = (4 << 20) if fmt == 2 else 65536
     per_thread = 4 << 20
     sample = min(len(blob), per_thread * cores) // unit * unit
@@ -322,6 +383,29 @@ def decompress_leg(m, ctx, fmt, blob, in_off, in_len, desc, steps, sharding):
     return res
 
 
+def end_to_end_leg(m, fmt, blob, in_off, in_len, desc, reps=3):
+    """Host pointers in, host pointers out, wall clock (SURVEY.md 8d "end-to-end"): the units as views of one pageable numpy array,
+    the outputs capacity after capacity in another, through mscomp_amd_compress_units_host on this GPU (uploads, kernels and downloads
+    of 512 MiB batches overlapped; one upload per run of adjacent units). One untimed call first (contexts, scratch, staging), then the
+    median of `reps`. Never `value` (that is HBM-resident)."""
+    ins = [blob[int(o):int(o) + int(l)] for o, l in zip(in_off, in_len)]
+    caps = [m.max_compressed_size(fmt, int(l)) + 2 for l in in_len]
+    out = np.zeros(sum(caps) + 64, dtype=np.uint8)
+    outs, pos = [], 0
+    for c in caps:
+        outs.append(out[pos:pos + c]); pos += c
+    ts = []
+    for r in range(reps + 1):
+        t0 = time.perf_counter()
+        rc, lens, st = m.compress_units_host(fmt, ins, outs, devices=(0,))
+        ts.append(time.perf_counter() - t0)
+        assert rc == 0 and bool((st == 0).all()), "the end-to-end leg reported an error status"
+    t = sorted(ts[1:])[len(ts[1:]) // 2]
+    n = int(np.sum(in_len))
+    return {"MB_per_s": round(n / t / 1e6, 1), "ms": round(t * 1e3, 3), "out_bytes": int(lens.sum()),
+            "what": "mscomp_amd_compress_units_host, %s: pageable host memory in and out, wall clock, median of %d calls" % (desc, reps)}
+
+
 def sharded_leg(m, ctx, cor, fmt, rank, world, steps, warmup, sharding, dev):
     """One codec over the config-5 job: this rank's contiguous unit range, timed; whole-job figures by MAX / SUM over the ranks."""
     off, ln, desc = config5_units(cor, fmt)
@@ -330,12 +414,15 @@ def sharded_leg(m, ctx, cor, fmt, rank, world, steps, warmup, sharding, dev):
     job = Job(m, ctx, fmt, d_in, my_off, my_len)
     dt, prof = timed(job, steps, warmup, sharding)
     out_bytes = job.out_bytes()
+    parity = parity_gate(m, job, fmt, cor, int(s))
+    if parity is False:
+        sys.exit("bench.py: the %s output of this run differs from the reference's (tests/golden/corpus_full.json): no number is reported" % CODEC_OF[fmt])
     job_dt, job_bytes = sharding.reduce_job(dt, job.in_bytes * steps, device=dev)
     _, job_out = sharding.reduce_job(0.0, out_bytes, device=dev)
     assert job_bytes == int(ln.sum()) * steps, "the shards do not cover the job"
     res = {"MB_per_s": round(job_bytes / job_dt / 1e6, 1), "MiB_per_s": round(job_bytes / job_dt / 2 ** 20, 1), "ms_per_step": round(job_dt / steps * 1e3, 4),
            "steps": steps, "workload": desc, "units": int(len(ln)), "units_rank0": int(e - s), "bytes_rank0": job.in_bytes,
-           "compression_ratio": round(job_out / int(ln.sum()), 4),
+           "compression_ratio": round(job_out / int(ln.sum()), 4), "parity_checked": parity,
            "roofline": roofline(fmt, prof, job.in_bytes, out_bytes, steps, "config5_n%d" % world)}
     job.close()
     return res
@@ -385,6 +472,7 @@ def main():
                    "parallelism": "shard-per-gpu x%d (sharding.shard_ranges: contiguous unit ranges balanced by bytes, no collective on the data path)" % world,
                    "MiB_per_s": head["MiB_per_s"]},
         "roofline": head["roofline"],
+        "parity_checked": {args.codec: head["parity_checked"]},
     }
     if args.oversubscribe:
         res["oversubscribed"] = "TEST RUN: %d ranks shared %d GPU(s); not an %d-GPU measurement" % (world, torch.cuda.device_count(), world)
@@ -396,6 +484,7 @@ def main():
         for codec in ("lznt1", "xpress", "xpress_huff"):
             if codec != args.codec:
                 c5[codec] = sharded_leg(m, ctx, cor, m.FORMATS[codec], rank, world, steps2, 1, sharding, rdev)
+                res["parity_checked"][codec] = c5[codec]["parity_checked"]
                 if rank == 0 and world == 1 and not args.no_cpu:
                     c5[codec]["cpu_baseline"] = cpu_baseline(m.FORMATS[codec], cor.blob())
         extra["config5"] = c5
@@ -411,6 +500,8 @@ def main():
             single[codec] = {"MB_per_s": round(j2.in_bytes * n2 / t2 / 1e6, 1), "ms_per_step": round(t2 / n2 * 1e3, 4), "steps": n2,
                              "workload": d2, "compression_ratio": round(ob / j2.in_bytes, 4), "roofline": roofline(f2, p2, j2.in_bytes, ob, n2, "single_gpu")}
             j2.close()
+            single[codec]["end_to_end"] = end_to_end_leg(m, f2, b2, o2, l2, d2)
+            assert single[codec]["end_to_end"]["out_bytes"] == ob, "the host-pointer path and the HBM-resident path disagree on the output size"
         extra["single_gpu"] = single
         # the suffix-array dictionary flavour of LZNT1 (csrc/lznt1_sa.hip) on the 12 files; HIP events per kernel as everywhere
         b2, o2, l2, d2 = single_gpu_workload(cor, "silesia_files")
