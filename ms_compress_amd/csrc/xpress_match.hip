@@ -43,6 +43,9 @@ __device__ __forceinline__ uint32_t ldg32_safe(const uint8_t* __restrict__ d, u6
 __device__ unsigned long long g_xl_prof[8];
 extern "C" void mscomp_amd_debug_xl_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xl_prof), 64); unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xl_prof), z, 64); }
 #endif
+#ifndef XL_FLIGHT
+#define XL_FLIGHT 8u                               // exchanges of the consumer wave in flight (full tiles)
+#endif
 #define XL_NC 1u                                   // consumer waves (hash classes); the other 16-XL_NC waves produce hashes
 #define XL_NP (16u - XL_NC)
 #define XL_NQ ((64u + XL_NP - 1u) / XL_NP)         // batches of 64 positions per producer wave and tile
@@ -127,14 +130,14 @@ __global__ __launch_bounds__(1024) void xp_links_kernel(const uint8_t* __restric
 			const uint16_t* const hs = s_hash + ((t - 1u) & 1u) * 4096u;
 			if (XL_NC == 1u && tn == 4096u) {
 				// full tile, single consumer: nothing to mask -- per batch one hash read, one exchange, one link store
-				for (uint32_t b0 = 0; b0 < 64u; b0 += 8u) {
-					uint32_t h[8], old[8];
+				for (uint32_t b0 = 0; b0 < 64u; b0 += XL_FLIGHT) {
+					uint32_t h[XL_FLIGHT], old[XL_FLIGHT];
 					#pragma unroll
-					for (int j = 0; j < 8; ++j) { h[j] = hs[(b0 + j) * 64u + lane]; }
+					for (uint32_t j = 0; j < XL_FLIGHT; ++j) { h[j] = hs[(b0 + j) * 64u + lane]; }
 					#pragma unroll
-					for (int j = 0; j < 8; ++j) { old[j] = __hip_atomic_exchange(&s_head[h[j]], pbase + (b0 + j) * 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+					for (uint32_t j = 0; j < XL_FLIGHT; ++j) { old[j] = __hip_atomic_exchange(&s_head[h[j]], pbase + (b0 + j) * 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 					#pragma unroll
-					for (int j = 0; j < 8; ++j) { lk[pbase + (b0 + j) * 64u + lane] = (uint16_t)old[j]; }
+					for (uint32_t j = 0; j < XL_FLIGHT; ++j) { lk[pbase + (b0 + j) * 64u + lane] = (uint16_t)old[j]; }
 				}
 			} else
 			for (uint32_t b0 = 0; b0 * 64u < tn; b0 += 8u) {
