@@ -402,7 +402,7 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 	if (ok && format == MSCOMP_LZNT1) { ok = c->slots.reserve((size_t)p->n_chunks * LZNT1_SLOT + 64); }
 	if (ok && format != MSCOMP_LZNT1) {
 		const size_t per = (size_t)p->n_chunks * 65536u * sizeof(uint16_t) + 64;
-		ok = c->links.reserve(per) && c->mlen3.reserve(per) && c->moff.reserve(per) && c->lasthead.reserve(per / 2 + 64);
+		ok = c->links.reserve(per) && c->mlen3.reserve(2 * per) && c->lasthead.reserve(per / 2 + 64);      // (mlen3: 4 bytes per position, both halves of the match word)
 		if (ok && format == MSCOMP_XPRESS) {
 			const size_t nw = (size_t)p->n_chunks * 1024u + 64;
 			ok = c->wtok.reserve(nw * 8) && c->wmat.reserve(nw * 8) && c->wfar.reserve(nw * 4);
@@ -566,7 +566,7 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 	}
 	case MSCOMP_XPRESS: {
 		uint16_t* links = static_cast<uint16_t*>(c->links.p); uint16_t* lasthead = static_cast<uint16_t*>(c->lasthead.p);
-		uint16_t* mlen3 = static_cast<uint16_t*>(c->mlen3.p); uint16_t* moff = static_cast<uint16_t*>(c->moff.p);
+		uint16_t* mlen3 = static_cast<uint16_t*>(c->mlen3.p); uint16_t* moff = mlen3 + 1;   /* one word per position: length - 3 | offset << 16 (common.h S16) */
 		{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
 		// units of one link chunk: Find only where a greedy parse can start a token, window and links in LDS; longer streams: every position
 		if (g_finder_mode.load(std::memory_order_relaxed) != 2 && p->max_unit <= 65536u) { KernelTimer t(c, "xp_lazy2_kernel"); launch_xp_lazy2(st, d_in, p->bt, links, mlen3, moff); }
@@ -576,7 +576,7 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 	}
 	case MSCOMP_XPRESS_HUFF: {
 		uint16_t* links = static_cast<uint16_t*>(c->links.p); uint16_t* lasthead = static_cast<uint16_t*>(c->lasthead.p);
-		uint16_t* mlen3 = static_cast<uint16_t*>(c->mlen3.p); uint16_t* moff = static_cast<uint16_t*>(c->moff.p);
+		uint16_t* mlen3 = static_cast<uint16_t*>(c->mlen3.p); uint16_t* moff = mlen3 + 1;   /* one word per position: length - 3 | offset << 16 (common.h S16) */
 		u64* tokbits = static_cast<u64*>(c->tokbits.p); uint32_t* counts = static_cast<uint32_t*>(c->counts.p);
 		uint32_t* extra = static_cast<uint32_t*>(c->extra.p); uint8_t* lens = static_cast<uint8_t*>(c->lens.p);
 		uint16_t* codes = static_cast<uint16_t*>(c->codes.p); uint32_t* fbflag = static_cast<uint32_t*>(c->fbflag.p);
@@ -719,12 +719,13 @@ MSCompStatus mscomp_amd_debug_xpress_matches(mscomp_amd_ctx* c, const uint8_t* d
 	if (s != MSCOMP_OK) { return s; }
 	DeviceGuard g(c->device);
 	uint16_t* links = static_cast<uint16_t*>(c->links.p); uint16_t* lasthead = static_cast<uint16_t*>(c->lasthead.p);
-	uint16_t* mlen3 = static_cast<uint16_t*>(c->mlen3.p); uint16_t* moff = static_cast<uint16_t*>(c->moff.p);
+	uint16_t* mlen3 = static_cast<uint16_t*>(c->mlen3.p); uint16_t* moff = mlen3 + 1;   /* one word per position: length - 3 | offset << 16 (common.h S16) */
 	launch_xp_links(c->stream, d_in, p->bt, links, lasthead);
 	launch_xp_find(c->stream, d_in, p->bt, links, lasthead, mlen3, moff, max_off, clip);
 	bool ok = hipStreamSynchronize(c->stream) == hipSuccess;
-	ok = ok && hipMemcpy(h_len3, mlen3, in_len * 2, hipMemcpyDeviceToHost) == hipSuccess;
-	ok = ok && hipMemcpy(h_off, moff, in_len * 2, hipMemcpyDeviceToHost) == hipSuccess;
+	std::vector<uint32_t> words(in_len + 1);
+	ok = ok && hipMemcpy(words.data(), mlen3, in_len * 4, hipMemcpyDeviceToHost) == hipSuccess;
+	for (size_t i = 0; ok && i < in_len; ++i) { h_len3[i] = (uint16_t)words[i]; h_off[i] = (uint16_t)(words[i] >> 16); }
 	mscomp_amd_plan_destroy(p);
 	return ok ? MSCOMP_OK : MSCOMP_ERRNO;
 }

@@ -77,6 +77,18 @@ __device__ __forceinline__ uint32_t lds_ld32(const uint8_t* base, uint32_t off)
 	return __builtin_amdgcn_alignbyte(a[1], a[0], off & 3u);
 }
 
+// ---- per-position match results of the Xpress-family finders --------------------------------------------
+// ONE 32-bit word per position: len - 3 in the low half, the offset in the high half (0 = no match). The kernels see the two halves
+// as two arrays of uint16_t with a stride of two (`mlen3[i]`, `moff[i]`): a finder that stores a position's match touches ONE 4-byte
+// word (the lazy finder's stores are scattered: two separate arrays cost two 32-byte sectors of HBM writes per match, 40 GB per pass of
+// BASELINE configs[4]), and the parse kernels find both halves in the same cache line.
+struct S16 {
+	uint16_t* p;
+	__host__ __device__ S16(const uint16_t* q) : p(const_cast<uint16_t*>(q)) {}
+	__device__ __forceinline__ uint16_t& operator[](u64 i) const { return p[2u * i]; }
+	__device__ __forceinline__ S16 operator+(u64 k) const { return S16(p + 2u * k); }
+};
+
 // ---- batch tables (uploaded once per plan) ------------------------------------------------------------
 // unit u owns chunks [chunk_prefix[u], chunk_prefix[u+1]); input = in_off/in_len, output = out_off/out_cap.
 struct BatchTables {

@@ -72,7 +72,7 @@ __device__ __forceinline__ ChunkGeom chunk_geom(const BatchTables& bt, uint32_t 
 // chunk, entered at `cur`; off / L are this lane's candidate (0 = none; L = len-3 as capped by the finder). Writes the
 // window's token mask and the final lengths of the taken matches; returns the parse position after the window.
 __device__ __forceinline__ uint32_t xh_parse_window(const ChunkGeom& g, const uint8_t* __restrict__ d, uint32_t lane, uint32_t wbase,
-                                                    uint32_t cur, uint32_t off, uint32_t L, uint16_t* __restrict__ mlen3c, u64* __restrict__ tokc,
+                                                    uint32_t cur, uint32_t off, uint32_t L, S16 mlen3c, u64* __restrict__ tokc,
                                                     u64& tokmask_out, uint32_t& L_out)
 {
 	const uint32_t wend = (wbase + 64u < g.cn) ? wbase + 64u : g.cn;
@@ -188,7 +188,7 @@ extern "C" void mscomp_amd_debug_xp_prof(unsigned long long* out) { (void)hipMem
 #define XP_T(i)
 #endif
 __global__ __launch_bounds__(256) void xh_parse_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
-                                                      uint16_t* __restrict__ mlen3, const uint16_t* __restrict__ moff,
+                                                      S16 mlen3, S16 moff,
                                                       u64* __restrict__ tokbits, uint32_t* __restrict__ counts, uint32_t* __restrict__ extra)
 {
 	__shared__ uint32_t s_cnt[512];
@@ -199,8 +199,8 @@ __global__ __launch_bounds__(256) void xh_parse_kernel(const uint8_t* __restrict
 	const ChunkGeom g = chunk_geom(bt, lc);
 	const uint8_t* __restrict__ d = d_in + bt.in_off[g.u];
 	const u64 gbase = (u64)lc * 65536u;
-	uint16_t* __restrict__ mlen3c = mlen3 + gbase;
-	const uint16_t* __restrict__ moffc = moff + gbase;
+	S16 mlen3c = mlen3 + gbase;
+	S16 moffc = moff + gbase;
 	u64* __restrict__ tokc = tokbits + (u64)lc * 1024u;
 	for (uint32_t i = tid; i < 512u; i += 256u) { s_cnt[i] = 0; }
 	const uint32_t nwin = (g.cn + 63u) >> 6;
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(512) void xh_fallback_kernel(const uint8_t* __restr
 // encode
 // ===================================================================================================================
 __global__ __launch_bounds__(64) void xh_encode_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
-                                                      const uint16_t* __restrict__ mlen3, const uint16_t* __restrict__ moff,
+                                                      S16 mlen3, S16 moff,
                                                       const u64* __restrict__ tokbits, const uint8_t* __restrict__ lens_in, const uint16_t* __restrict__ codes_in,
                                                       const uint32_t* __restrict__ fbflag,
                                                       const u64* __restrict__ prefix, uint8_t* __restrict__ d_out)

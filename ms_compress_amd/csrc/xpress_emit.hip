@@ -92,7 +92,7 @@ __device__ __forceinline__ void xe_emit_tokens(uint8_t* __restrict__ out, u64 ca
 }
 
 __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
-                                                        const uint16_t* __restrict__ mlen3, const uint16_t* __restrict__ moff,
+                                                        S16 mlen3, S16 moff,
                                                         uint8_t* __restrict__ d_out, u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
 {
 	const uint32_t lane = threadIdx.x;
@@ -440,7 +440,7 @@ __device__ __forceinline__ uint32_t xe_pack_F(u64 F, u64 end2) { return F == end
 
 // record a walked window: final lengths (u16, 0xFFFF = see the window's far length), masks, byte counts, state after it
 __device__ __forceinline__ void xe_store_window(uint32_t lane, u64 wbase, u64 n, u64 gw, uint32_t w, uint32_t off, uint32_t L, u64 tm, u64 mk,
-                                                u64 cur, u64 F, u64 end2, uint16_t* __restrict__ mlen3u, u64* __restrict__ wtoku, u64* __restrict__ wmatu,
+                                                u64 cur, u64 F, u64 end2, S16 mlen3u, u64* __restrict__ wtoku, u64* __restrict__ wmatu,
                                                 uint32_t* __restrict__ wfaru, uint32_t* s_ecur, uint32_t* s_eF, uint32_t* s_sum)
 {
 	const bool is_m = (mk >> lane) & (u64)1;
@@ -462,7 +462,7 @@ __device__ __forceinline__ void xe_store_window(uint32_t lane, u64 wbase, u64 n,
 // seam: lead bits, lead complete, tail bits, tail valid, lead nibble, tail pending, tail low nibble, tokens;
 // seampos: slot of the flag word open at the segment's end, position of its pending nibble byte.
 __device__ __forceinline__ void xe_emit_segment(uint32_t lane, u64 sb, uint32_t w0, uint32_t w1, u64 n, u64 cap, const uint8_t* __restrict__ d,
-                                                uint8_t* __restrict__ out, const uint16_t* __restrict__ mlen3u, const uint16_t* __restrict__ moffu,
+                                                uint8_t* __restrict__ out, S16 mlen3u, S16 moffu,
                                                 const u64* wtoku, const u64* wmatu, const uint32_t* wfaru, const uint32_t* s_nr, const uint32_t* s_sr,
                                                 u64 Nsb, u64 Ssb, uint16_t* s_off, uint16_t* s_len, uint8_t* s_byte, u64* s_mask,
                                                 uint32_t* seam, u64* seampos)
@@ -592,7 +592,7 @@ extern "C" void mscomp_amd_debug_xe2_prof(unsigned long long* out) { (void)hipMe
 #endif
 template <uint32_t NW>                                         // waves per unit: 4 or 16 (segments of 1024 / NW windows)
 __global__ __launch_bounds__(NW * 64u) void xpress_emit2_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
-                                                          uint16_t* __restrict__ mlen3, const uint16_t* __restrict__ moff,
+                                                          S16 mlen3, S16 moff,
                                                           u64* __restrict__ wtok, u64* __restrict__ wmat, uint32_t* __restrict__ wfar,
                                                           uint8_t* __restrict__ d_out, u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
 {
@@ -612,8 +612,8 @@ __global__ __launch_bounds__(NW * 64u) void xpress_emit2_kernel(const uint8_t* _
 	const uint8_t* __restrict__ d = d_in + bt.in_off[u];
 	uint8_t* __restrict__ out = d_out + bt.out_off[u];
 	const u64 mbase = (u64)bt.chunk_prefix[u] * 65536u;           // this unit's slice of the per-position match arrays
-	uint16_t* __restrict__ mlen3u = mlen3 + mbase;
-	const uint16_t* __restrict__ moffu = moff + mbase;
+	S16 mlen3u = mlen3 + mbase;
+	S16 moffu = moff + mbase;
 	u64* __restrict__ wtoku = wtok + (mbase >> 6); u64* __restrict__ wmatu = wmat + (mbase >> 6); uint32_t* __restrict__ wfaru = wfar + (mbase >> 6);
 	const u64 end2 = n >= 2u ? n - 2u : 0u;
 	const u64 nwin = (n + 63u) >> 6;
@@ -793,8 +793,8 @@ __device__ __forceinline__ void xe3_scan_sb(uint32_t lane, uint32_t nsb, const u
 	if (lane == 0) { tot[0] = nc; tot[1] = rc; tot[2] = sc0; tot[3] = sc1; }
 }
 
-__global__ __launch_bounds__(1024) void xe3_walk_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, uint16_t* __restrict__ mlen3,
-                                                       const uint16_t* __restrict__ moff, Xe3 x)
+__global__ __launch_bounds__(1024) void xe3_walk_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, S16 mlen3,
+                                                       S16 moff, Xe3 x)
 {
 	__shared__ uint32_t s_ecur[1024], s_eF[1024], s_sum[1024];
 	__shared__ uint16_t s_in_off[16][256];
@@ -806,8 +806,8 @@ __global__ __launch_bounds__(1024) void xe3_walk_kernel(const uint8_t* __restric
 	const u64 n = bt.in_len[u];
 	const uint8_t* __restrict__ d = d_in + bt.in_off[u];
 	const u64 mbase = (u64)bt.chunk_prefix[u] * 65536u;
-	uint16_t* __restrict__ mlen3u = mlen3 + mbase;
-	const uint16_t* __restrict__ moffu = moff + mbase;
+	S16 mlen3u = mlen3 + mbase;
+	S16 moffu = moff + mbase;
 	const u64 gwu = mbase >> 6;                                    // first window record of the unit
 	const u64 end2 = n >= 2u ? n - 2u : 0u;
 	const u64 nwin = (n + 63u) >> 6;
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(1024) void xe3_walk_kernel(const uint8_t* __restric
 // after a window equals the recorded one, then re-scan the super-block. Returns without touching anything when the
 // speculation was right. used[2 lc], used[2 lc + 1] remember the entry state this was decided on.
 __device__ __forceinline__ void xe3_repair_seam(const uint8_t* __restrict__ d, u64 n, u64 end2, uint32_t lane, uint32_t lc, u64 sb, uint32_t nsb,
-                                                uint16_t* __restrict__ mlen3u, const uint16_t* __restrict__ moffu, u64 gwu, const Xe3& x, uint32_t* __restrict__ used)
+                                                S16 mlen3u, S16 moffu, u64 gwu, const Xe3& x, uint32_t* __restrict__ used)
 {
 	const u64 wprev = (sb - 1u) * 64u;
 	const uint32_t pc = __hip_atomic_load(&x.wecur[gwu + sb - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -906,8 +906,8 @@ __device__ __forceinline__ void xe3_repair_seam(const uint8_t* __restrict__ d, u
 
 // all seams between super-blocks at once, one wave each (a repair that does not re-synchronise inside its super-block
 // changes that super-block's end state: xe3_fix_kernel notices and cascades)
-__global__ __launch_bounds__(64) void xe3_seam_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, uint16_t* __restrict__ mlen3,
-                                                     const uint16_t* __restrict__ moff, Xe3 x, uint32_t* __restrict__ used)
+__global__ __launch_bounds__(64) void xe3_seam_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, S16 mlen3,
+                                                     S16 moff, Xe3 x, uint32_t* __restrict__ used)
 {
 	const uint32_t lane = threadIdx.x;
 	const uint32_t lc = blockIdx.x;
@@ -925,8 +925,8 @@ __global__ __launch_bounds__(64) void xe3_seam_kernel(const uint8_t* __restrict_
 
 // per unit (one wave): cascade check of the seams (serial, but it only reads two words per super-block unless a repair
 // moved an end state), then the prefix of tokens / long matches / bytes over the super-blocks, 64 of them per step
-__global__ __launch_bounds__(64) void xe3_fix_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, uint16_t* __restrict__ mlen3,
-                                                    const uint16_t* __restrict__ moff, Xe3 x, uint32_t* __restrict__ used,
+__global__ __launch_bounds__(64) void xe3_fix_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, S16 mlen3,
+                                                    S16 moff, Xe3 x, uint32_t* __restrict__ used,
                                                     u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
 {
 	const uint32_t lane = threadIdx.x;
@@ -993,8 +993,8 @@ __global__ __launch_bounds__(64) void xe3_fix_kernel(const uint8_t* __restrict__
 	}
 }
 
-__global__ __launch_bounds__(1024) void xe3_emit_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, const uint16_t* __restrict__ mlen3,
-                                                       const uint16_t* __restrict__ moff, Xe3 x, uint8_t* __restrict__ d_out)
+__global__ __launch_bounds__(1024) void xe3_emit_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, S16 mlen3,
+                                                       S16 moff, Xe3 x, uint8_t* __restrict__ d_out)
 {
 	__shared__ uint32_t s_nr[1024], s_sr[1024];
 	__shared__ uint16_t s_in_off[16][256];

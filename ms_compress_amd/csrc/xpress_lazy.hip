@@ -57,7 +57,7 @@ extern "C" void mscomp_amd_debug_xz_prof(unsigned long long* out) { (void)hipMem
 // LDS: data [XZ_WIN + TILE + XZ_PAD] | links u16 [XZ_WIN + TILE] | claim bits [TILE / 32] | list [XZ_LIST] | counters [4] | long-match cache [XZ_CACHE] u64
 template <uint32_t TILE, uint32_t SEG, uint32_t WPE>   // WPE: waves per SIMD the register budget allows (HIP's second launch bound)
 __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t* __restrict__ d_in, BatchTables bt, const uint16_t* __restrict__ links,
-                                                             uint16_t* __restrict__ mlen3, uint16_t* __restrict__ moff)
+                                                             S16 mlen3, S16 moff)
 {
 	constexpr uint32_t NT = TILE / SEG;
 	static_assert(NT >= XZ_WIN / 16u, "the window is moved down by 512 lanes");
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 	const uint32_t cn = (uint32_t)n64;                       // <= 65536
 	const uint8_t* __restrict__ d = d_in + bt.in_off[u];
 	const uint16_t* __restrict__ lk = links + (u64)lc * 65536u;
-	uint16_t* __restrict__ ml = mlen3 + (u64)lc * 65536u;
-	uint16_t* __restrict__ mo = moff + (u64)lc * 65536u;
+	S16 ml = mlen3 + (u64)lc * 65536u;
+	S16 mo = moff + (u64)lc * 65536u;
 
 	if (tid < 4u) { s_cnt[tid] = 0u; }
 	if (tid < XZ_CACHE) { s_cache[tid] = 0ull; }
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 			const uint32_t ln = te - tb;                                                    // links of the tile (chunk arrays start at multiples of 128 KiB)
 			for (uint32_t r = tid * 8u; r < ln; r += NT * 8u) { *reinterpret_cast<uint4*>(s_links + XZ_WIN + r) = *reinterpret_cast<const uint4*>(lk + tb + r); }
 			for (uint32_t i = tid; i < TILE / 32u; i += NT) { s_bits[i] = 0u; }
-			uint4* __restrict__ moz = reinterpret_cast<uint4*>(mo + tb);                       // offsets of unvisited positions read as "no match"
-			for (uint32_t i = tid; i * 8u < ln; i += NT) { moz[i] = make_uint4(0u, 0u, 0u, 0u); }
+			uint4* __restrict__ moz = reinterpret_cast<uint4*>(ml.p + 2u * tb);                // words (length | offset << 16) of unvisited positions read as "no match"
+			for (uint32_t i = tid; i * 4u < ln; i += NT) { moz[i] = make_uint4(0u, 0u, 0u, 0u); }
 		}
 		__syncthreads();
 
@@ -196,8 +196,7 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 						const uint32_t bl = best >> 16;
 						if (bl >= 3u) {
 							const uint32_t dist = 0xFFFFu - (best & 0xFFFFu);
-							ml[p] = (uint16_t)(bl - 3u);
-							mo[p] = (uint16_t)dist;
+							*reinterpret_cast<uint32_t*>(&ml[p]) = (bl - 3u) | (dist << 16);      // one word: length - 3 | offset << 16
 							XZ_CNT(3, 1)
 							if (bl >= 48u && lim > 48u && !single) { st = XZ_EXT; x = p - dist; dl = 48u; }    // how long is it really (the walk needs its end)
 							else { elen = bl; st = XZ_DONE2; }

@@ -190,7 +190,7 @@ extern "C" void mscomp_amd_debug_xf_prof(unsigned long long* out) { (void)hipMem
 template <uint32_t WINDOW, uint32_t LINKW, uint32_t NT, uint32_t XP_TILE>   // LINKW: how many positions before the tile have their links in LDS
 __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                      const uint16_t* __restrict__ links, const uint16_t* __restrict__ lasthead,
-                                                     uint16_t* __restrict__ mlen3, uint16_t* __restrict__ moff,
+                                                     S16 mlen3, S16 moff,
                                                      uint32_t max_off, int clip)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -321,8 +321,7 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 		}
 		const bool m = best >= 3u;
 		const u64 gi = (u64)lc * 65536u + o;
-		mlen3[gi] = (uint16_t)(m ? best - 3u : 0u);
-		moff[gi] = (uint16_t)(m ? boff : 0u);
+		*reinterpret_cast<uint32_t*>(&mlen3[gi]) = m ? (best - 3u) | (boff << 16) : 0u;      // one word: length - 3 | offset << 16 (moff is its upper half)
 		XF_CNT(4, m ? 1 : 0)
 	}
 #ifdef XF_PROFILE
