@@ -503,6 +503,21 @@ def main():
             single[codec]["end_to_end"] = end_to_end_leg(m, f2, b2, o2, l2, d2)
             assert single[codec]["end_to_end"]["out_bytes"] == ob, "the host-pointer path and the HBM-resident path disagree on the output size"
         extra["single_gpu"] = single
+        # What ONE rank of an 8-GPU run of this job holds (2 of the 16 replicas, 423 877 160 B): its rate against an eighth of the
+        # one-GPU rate is the strong-scaling efficiency the partition itself allows at N = 8 (no exchange step exists; what is lost is the
+        # tail of kernels whose duration is their slowest chunk). Not an 8-GPU measurement -- none is possible on this box.
+        r8 = {}
+        for codec in ("lznt1", "xpress", "xpress_huff"):
+            f2 = m.FORMATS[codec]
+            off, ln, _ = config5_units(cor, f2)
+            nu = len(ln) // REPLICAS * 2
+            j2 = Job(m, ctx, f2, cor.device_range(0, 2 * cor.total), off[:nu], ln[:nu])
+            t2, _p2 = timed(j2, steps2, 1, sharding)
+            full = head if codec == args.codec else extra["config5"][codec]
+            r8[codec] = {"MB_per_s": round(j2.in_bytes * steps2 / t2 / 1e6, 1), "ms_per_step": round(t2 / steps2 * 1e3, 4), "bytes": j2.in_bytes,
+                         "rate_vs_whole_job_on_one_gpu": round((j2.in_bytes * steps2 / t2 / 1e6) / full["MB_per_s"], 3)}
+            j2.close()
+        extra["one_rank_of_8"] = r8
         # the suffix-array dictionary flavour of LZNT1 (csrc/lznt1_sa.hip) on the 12 files; HIP events per kernel as everywhere
         b2, o2, l2, d2 = single_gpu_workload(cor, "silesia_files")
         ctx.lib.mscomp_amd_set_lznt1_sa_dict(1)

@@ -50,8 +50,10 @@ __device__ __forceinline__ uint32_t xz_ldg32(const uint8_t* __restrict__ d, u64 
 __device__ unsigned long long g_xz_prof[8];
 extern "C" void mscomp_amd_debug_xz_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xz_prof), 64); unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xz_prof), z, 64); }
 #define XZ_CNT(i, v) xz_acc[i] += (v);
+#define XZ_T(i) { const unsigned long long t_ = __builtin_readcyclecounter(); xz_acc[4 + (i)] += t_ - xz_prev; xz_prev = t_; }   /* wave cycles: [4] staging, [5] walks, [6] waiting for the block */
 #else
 #define XZ_CNT(i, v)
+#define XZ_T(i)
 #endif
 
 // LDS: data [XZ_WIN + TILE + XZ_PAD] | links u16 [XZ_WIN + TILE] | claim bits [TILE / 32] | list [XZ_LIST] | counters [4] | long-match cache [XZ_CACHE] u64
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 	if (tid < XZ_CACHE) { s_cache[tid] = 0ull; }
 	for (uint32_t i = tid; i < XZ_LIST; i += NT) { s_list[i] = 0xFFFFFFFFu; }
 #ifdef XZ_PROFILE
-	unsigned long long xz_acc[8] = {0};
+	unsigned long long xz_acc[8] = {0}, xz_prev = __builtin_readcyclecounter();
 #endif
 
 	for (uint32_t tb = 0; tb < cn; tb += TILE) {             // tile = chunk positions [tb, te)
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 		__syncthreads();
 
 		// ---- rounds: round 0 = my segment + my parked walk; later rounds = walks parked while the tile was worked on (resume points)
+		XZ_T(0)
 		bool swept = false;
 		for (uint32_t round = 0;; ++round) {
 			const bool do_sweep = s_cnt[1] != 0u && !swept;      // the list overflowed (never seen): every position of this and all later tiles is evaluated
@@ -254,32 +257,36 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 						st = single ? XZ_IDLE : XZ_NEW;
 					}
 				}
-				// ---- NEW: claim q, start its Find
+				// ---- NEW: claim q, start its Find. The claim (a returning LDS atomic), the position's own 16 bytes and its first link
+				// are asked for TOGETHER and waited for once; a lane whose claim fails has read 24 bytes in vain
 				if (__ballot(st == XZ_NEW)) {
-					if (st == XZ_NEW) {
+					const bool isnew = st == XZ_NEW, intile = isnew && q < te;
+					const uint32_t qq = intile ? q : tb;
+					const uint32_t qw = qq - tb + XZ_WIN;
+					const uint32_t bit = 1u << (qq & 31u);
+					uint32_t old = 0xFFFFFFFFu;
+					if (intile) { old = atomicOr(&s_bits[(qq - tb) >> 5], bit); }
+					const uint4 own_n = lds_ld128(s_data, qw);
+					const uint32_t x_n = s_links[qw];
+					if (isnew) {
 						st = XZ_IDLE;
-						if (q >= te) {
+						if (!intile) {
 							if (q < cn) {                                  // leaves the tile: parked for the next one
 								const uint32_t slot = atomicAdd(&s_cnt[0], 1u);
 								if (slot < XZ_LIST) { s_list[slot] = q; } else { s_cnt[1] = 1u; }
 							}
-						} else {
-							const uint32_t bit = 1u << (q & 31u);
-							const uint32_t old = atomicOr(&s_bits[(q - tb) >> 5], bit);
-							if (!(old & bit)) {
-								XZ_CNT(1, 1)
-								p = q;
-								lim = cn - p - 1u;                         // never count the buffer's final byte (XpressDictionary.h:88-93)
-								if (p + 2u >= cn) { elen = 1u; st = XZ_DONE2; }      // the unit's last two bytes are literals (xpress_compress.cpp:266)
-								else {
-									cap = lim < 48u ? lim : 48u;
-									const uint32_t pw = p - tb + XZ_WIN;
-									own = lds_ld128(s_data, pw);
-									x = s_links[pw];
-									best = 0u; chain = 11u; dl = 0u;
-									fetch = x != 0xFFFFu && p - x <= XZ_WIN;
-									st = fetch ? XZ_FIND : XZ_DONE;
-								}
+						} else if (!(old & bit)) {
+							XZ_CNT(1, 1)
+							p = q;
+							lim = cn - p - 1u;                             // never count the buffer's final byte (XpressDictionary.h:88-93)
+							if (p + 2u >= cn) { elen = 1u; st = XZ_DONE2; }          // the unit's last two bytes are literals (xpress_compress.cpp:266)
+							else {
+								cap = lim < 48u ? lim : 48u;
+								own = own_n;
+								x = x_n;
+								best = 0u; chain = 11u; dl = 0u;
+								fetch = x != 0xFFFFu && p - x <= XZ_WIN;
+								st = fetch ? XZ_FIND : XZ_DONE;
 							}
 						}
 					}
@@ -292,7 +299,9 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 					fetch = false;
 				}
 			}
+			XZ_T(1)
 			__syncthreads();
+			XZ_T(2)
 			// another round when walks for THIS tile were parked meanwhile
 			bool again = false;
 			for (uint32_t slot = tid; slot < XZ_LIST; slot += NT) { const uint32_t e = s_list[slot]; again = again || (e != 0xFFFFFFFFu && e < te); }
@@ -302,6 +311,7 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 	}
 #ifdef XZ_PROFILE
 	for (int i_ = 0; i_ < 4; ++i_) { if (xz_acc[i_]) { atomicAdd(&g_xz_prof[i_], xz_acc[i_]); } }
+	if (lane == 0) { for (int i_ = 4; i_ < 7; ++i_) { atomicAdd(&g_xz_prof[i_], xz_acc[i_]); } }
 #endif
 }
 

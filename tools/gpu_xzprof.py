@@ -24,7 +24,7 @@ for name in names:
         plan.execute(d_in, d_out, d_len, d_st); torch.cuda.synchronize()
         if has_prof:
             buf = (C.c_ulonglong * 8)(); lib.mscomp_amd_debug_xz_prof(buf)
-            if hasattr(lib, "mscomp_amd_debug_xz_cyc"): lib.mscomp_amd_debug_xz_cyc(buf); lib.mscomp_amd_debug_xz_prof(buf)
+
         ctx.profile_enable(True)
         for _ in range(3): plan.execute(d_in, d_out, d_len, d_st)
         torch.cuda.synchronize()
@@ -32,10 +32,9 @@ for name in names:
         res[mode] = {k: v[0] / v[1] for k, v in prof.items()}
         if has_prof and mode == 1:
             lib.mscomp_amd_debug_xz_prof(buf); c = [x / 3 for x in buf]
-            res["cnt"] = "wave-steps/64pos %.2f  claimed/pos %.3f  candidates/pos %.2f  matches/pos %.3f  queued pairs/pos %.2f  lane occupancy %.2f" % (c[0] / n, c[1] / n, c[2] / n, c[3] / n, c[4] / n, c[1] / max(c[0], 1))
-            if hasattr(lib, "mscomp_amd_debug_xz_cyc"):
-                cy = (C.c_ulonglong * 8)(); lib.mscomp_amd_debug_xz_cyc(cy); t = [x / 3 for x in cy]; tot = sum(t[:7]) or 1
-                res["cnt"] += "\n      wave cycles: staging %.2f  claim %.2f  first %.2f  walk+queue %.2f  store+ext %.2f  tail %.2f  barrier wait %.2f  (total %.0f Mcycles, %.0f per 64 pos)" % tuple([x / tot for x in t[:7]] + [tot / 1e6, tot / (n / 64)])
+            tot = (c[4] + c[5] + c[6]) or 1
+            res["cnt"] = "wave-steps/64pos %.2f  claimed/pos %.3f  compares/pos %.2f  matches/pos %.3f  lane occupancy %.2f | wave cycles: staging %.2f walks %.2f waiting for the block %.2f (%.0f per 64 pos)" % (
+                c[0] / n, c[1] / n, c[2] / n, c[3] / n, (c[2] + c[1]) / max(c[0], 1), c[4] / tot, c[5] / tot, c[6] / tot, tot / (n / 64))
         plan.close()
     lib.mscomp_amd_debug_set_finder(1)
     print("%-8s %9d B %5d units: find %.3f ms  lazy2 %.3f ms  (emit %.3f / %.3f) %s" % (name, n, len(lens), res[2].get("xp_find_kernel", 0), res[1].get("xp_lazy2_kernel", 0),
