@@ -87,6 +87,7 @@ struct S16 {
 	__host__ __device__ S16(const uint16_t* q) : p(const_cast<uint16_t*>(q)) {}
 	__device__ __forceinline__ uint16_t& operator[](u64 i) const { return p[2u * i]; }
 	__device__ __forceinline__ S16 operator+(u64 k) const { return S16(p + 2u * k); }
+	__device__ __forceinline__ uint32_t word(u64 i) const { return *reinterpret_cast<const uint32_t*>(p + 2u * i); }   // both halves of position i (called on the LENGTH view: p is word aligned)
 };
 
 // ---- batch tables (uploaded once per plan) ------------------------------------------------------------

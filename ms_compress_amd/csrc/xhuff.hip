@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void xh_parse_kernel(const uint8_t* __restrict
 	int xtra = 0;                                                  // raw length bytes of my tokens (per lane, reduced at the end)
 #define XP_BURST_LOAD(gb) { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
 		const uint32_t q_ = (gb) + (uint32_t)k_ * 64u + lane; const uint32_t c_ = q_ < g.cn ? q_ : g.cn - 1u; \
-		g_off[k_] = moffc[c_]; g_len[k_] = mlen3c[c_]; g_byte[k_] = d[g.cbase + c_]; } }
+		{ const uint32_t w_ = mlen3c.word(c_); g_off[k_] = w_ >> 16; g_len[k_] = w_ & 0xFFFFu; } g_byte[k_] = d[g.cbase + c_]; } }
 #define XP_BURST_STORE(buf) { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
 		s_in_off[wv][buf][k_ * 64 + lane] = (uint16_t)g_off[k_]; s_in_len[wv][buf][k_ * 64 + lane] = (uint16_t)g_len[k_]; s_in_byte[wv][buf][k_ * 64 + lane] = (uint8_t)g_byte[k_]; } }
 	{
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(64) void xh_encode_kernel(const uint8_t* __restrict
 	uint32_t g_off[8], g_len[8], g_byte[8]; u64 g_tok = 0;
 #define XE_BURST_LOAD(gb) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { \
 		const uint32_t q_ = (gb) + (uint32_t)k_ * 64u + lane; const uint32_t c_ = q_ < g.cn ? q_ : g.cn - 1u; \
-		g_off[k_] = moff[gbase + c_]; g_len[k_] = mlen3[gbase + c_]; g_byte[k_] = d[c_]; } \
+		{ const uint32_t w_ = mlen3.word(gbase + c_); g_off[k_] = w_ >> 16; g_len[k_] = w_ & 0xFFFFu; } g_byte[k_] = d[c_]; } \
 		g_tok = (lane < 8u && ((gb) >> 6) + lane < nwin) ? tokbits[(u64)lc * 1024u + ((gb) >> 6) + lane] : (u64)0; }
 #define XE_BURST_STORE(buf) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { \
 		s_in_off[buf][k_ * 64 + lane] = (uint16_t)g_off[k_]; s_in_len[buf][k_ * 64 + lane] = (uint16_t)g_len[k_]; s_in_byte[buf][k_ * 64 + lane] = (uint8_t)g_byte[k_]; } \

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 	uint32_t g_off[8], g_len[8], g_byte[8];
 #define XE_BURST_LOAD(gbase) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { \
 		const u64 q_ = (gbase) + (u64)k_ * 64u + lane; const u64 c_ = q_ < n ? q_ : n - 1u; \
-		g_off[k_] = moff[mbase + c_]; g_len[k_] = mlen3[mbase + c_]; g_byte[k_] = d[c_]; } }
+		{ const uint32_t w_ = mlen3.word(mbase + c_); g_off[k_] = w_ >> 16; g_len[k_] = w_ & 0xFFFFu; } g_byte[k_] = d[c_]; } }
 #define XE_BURST_STORE(buf) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { \
 		s_in_off[buf][k_ * 64 + lane] = (uint16_t)g_off[k_]; s_in_len[buf][k_ * 64 + lane] = (uint16_t)g_len[k_]; s_in_byte[buf][k_ * 64 + lane] = (uint8_t)g_byte[k_]; } }
 	if (n) { XE_BURST_LOAD((u64)0) }
@@ -470,7 +470,7 @@ __device__ __forceinline__ void xe_emit_segment(uint32_t lane, u64 sb, uint32_t 
 	uint32_t g_off[4], g_len[4], g_byte[4];
 #define XE4_LOAD(gb) { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
 		const u64 q_ = (gb) + (u64)k_ * 64u + lane; const u64 c_ = q_ < n ? q_ : n - 1u; \
-		g_off[k_] = moffu[c_]; g_len[k_] = mlen3u[c_]; g_byte[k_] = d[c_]; } }
+		{ const uint32_t w_ = mlen3u.word(c_); g_off[k_] = w_ >> 16; g_len[k_] = w_ & 0xFFFFu; } g_byte[k_] = d[c_]; } }
 #define XE4_STORE() { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
 		s_off[k_ * 64 + lane] = (uint16_t)g_off[k_]; s_len[k_ * 64 + lane] = (uint16_t)g_len[k_]; s_byte[k_ * 64 + lane] = (uint8_t)g_byte[k_]; } }
 	if (w0 >= w1) { if (lane == 0) { seam[7] = 0; seam[4] = 0xFFu; seam[5] = 0; } return; }
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(NW * 64u) void xpress_emit2_kernel(const uint8_t* _
 	uint32_t g_off[4], g_len[4], g_byte[4];
 #define XE2_LOAD(gb) { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
 		const u64 q_ = (gb) + (u64)k_ * 64u + lane; const u64 c_ = q_ < n ? q_ : n - 1u; \
-		g_off[k_] = moffu[c_]; g_len[k_] = mlen3u[c_]; g_byte[k_] = d[c_]; } }
+		{ const uint32_t w_ = mlen3u.word(c_); g_off[k_] = w_ >> 16; g_len[k_] = w_ & 0xFFFFu; } g_byte[k_] = d[c_]; } }
 #define XE2_STORE() { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
 		s_in_off[wv][k_ * 64 + lane] = (uint16_t)g_off[k_]; s_in_len[wv][k_ * 64 + lane] = (uint16_t)g_len[k_]; s_in_byte[wv][k_ * 64 + lane] = (uint8_t)g_byte[k_]; } }
 
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(1024) void xe3_walk_kernel(const uint8_t* __restric
 	const uint32_t w0 = wv * 64u, w1 = (w0 + 64u < nsb) ? w0 + 64u : nsb;
 	uint32_t g_off[4], g_len[4];
 #define XE3_LOAD(gb) { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
-		const u64 q_ = (gb) + (u64)k_ * 64u + lane; const u64 c_ = q_ < n ? q_ : n - 1u; g_off[k_] = moffu[c_]; g_len[k_] = mlen3u[c_]; } }
+		const u64 q_ = (gb) + (u64)k_ * 64u + lane; const u64 c_ = q_ < n ? q_ : n - 1u; { const uint32_t w_ = mlen3u.word(c_); g_off[k_] = w_ >> 16; g_len[k_] = w_ & 0xFFFFu; } } }
 #define XE3_STORE() { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) { \
 		s_in_off[wv][k_ * 64 + lane] = (uint16_t)g_off[k_]; s_in_len[wv][k_ * 64 + lane] = (uint16_t)g_len[k_]; } }
 	if (w0 < w1) {                                                // ---- speculative walk of my segment

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 	const uint8_t* __restrict__ d = d_in + bt.in_off[u];
 	const uint16_t* __restrict__ lk = links + (u64)lc * 65536u;
 	S16 ml = mlen3 + (u64)lc * 65536u;
-	S16 mo = moff + (u64)lc * 65536u;
+	(void)moff;                                              // (the offset is the upper half of the word `ml` points at)
 
 	if (tid < 4u) { s_cnt[tid] = 0u; }
 	if (tid < XZ_CACHE) { s_cache[tid] = 0ull; }
