@@ -512,10 +512,11 @@ def main():
             off, ln, _ = config5_units(cor, f2)
             nu = len(ln) // REPLICAS * 2
             j2 = Job(m, ctx, f2, cor.device_range(0, 2 * cor.total), off[:nu], ln[:nu])
-            t2, _p2 = timed(j2, steps2, 1, sharding)
+            t2, p2 = timed(j2, steps2, 1, sharding)
             full = head if codec == args.codec else extra["config5"][codec]
             r8[codec] = {"MB_per_s": round(j2.in_bytes * steps2 / t2 / 1e6, 1), "ms_per_step": round(t2 / steps2 * 1e3, 4), "bytes": j2.in_bytes,
-                         "rate_vs_whole_job_on_one_gpu": round((j2.in_bytes * steps2 / t2 / 1e6) / full["MB_per_s"], 3)}
+                         "rate_vs_whole_job_on_one_gpu": round((j2.in_bytes * steps2 / t2 / 1e6) / full["MB_per_s"], 3),
+                         "kernels_ms_per_step": {k: round(v[0] / steps2, 4) for k, v in sorted(p2.items(), key=lambda kv: -kv[1][0])}}
             j2.close()
         extra["one_rank_of_8"] = r8
         # the suffix-array dictionary flavour of LZNT1 (csrc/lznt1_sa.hip) on the 12 files; HIP events per kernel as everywhere

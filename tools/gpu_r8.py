@@ -1,0 +1,17 @@
+"""Dev helper (GPU box): what one rank of an 8-GPU run holds (2 replicas, 424 MB), per-kernel ms next to an eighth of the whole job's."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import ms_compress_amd as m
+from ms_compress_amd import corpus, sharding
+import bench
+ctx = m.Context(); cor = bench.Corpus(corpus, torch.device("cuda", 0))
+for codec in sys.argv[1:] or ["lznt1", "xpress", "xpress_huff"]:
+    f = m.FORMATS[codec]
+    off, ln, _ = bench.config5_units(cor, f)
+    for reps in (2, 16):
+        nu = len(ln) // 16 * reps
+        j = bench.Job(m, ctx, f, cor.device_range(0, reps * cor.total), off[:nu], ln[:nu])
+        t, p = bench.timed(j, 3, 1, sharding)
+        print(codec, reps, "replicas: %.3f ms/step = %.3f ms per replica" % (t / 3 * 1e3, t / 3 * 1e3 / reps), {k: round(v[0] / 3 / reps, 4) for k, v in sorted(p.items(), key=lambda kv: -kv[1][0])}, flush=True)
+        j.close()
