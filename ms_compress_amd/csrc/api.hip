@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <condition_variable>
 #include <hip/hip_runtime.h>
 #include <new>
 #include <string>
@@ -151,7 +152,7 @@ uint32_t chunks_of(MSCompFormat f, bool decompress, uint64_t n)
 
 extern "C" {
 
-const char* mscomp_amd_version(void) { return "mscomp_amd 0.2 (gfx950, HIP; LZNT1 / Xpress / Xpress+Huffman compressors and decompressors, LZNT1 streaming compressor)"; }
+const char* mscomp_amd_version(void) { return "mscomp_amd 0.3 (gfx950, HIP; LZNT1 / Xpress / Xpress+Huffman compressors and decompressors, LZNT1 streaming, host batches over several GPUs)"; }
 
 size_t lznt1_max_compressed_size(size_t n)       { return n + 3 + 2 * ((n + 4095) / 4096); }
 size_t xpress_max_compressed_size(size_t n)      { return n + 4 + 4 * (n / 32); }
@@ -842,6 +843,46 @@ struct OneShotTls {
 
 } // namespace
 
+// Page-locking of caller buffers for the large host-pointer calls. hipHostRegister refuses a range that overlaps a registered one, and a range
+// one thread unregisters while another thread's copy of the same pages is in flight would pull the pages from under that copy (two threads may
+// legally compress the SAME input at once: the reference only forbids aliasing in / out). So registrations go through this table: the same range
+// is shared (counted), an overlapping but different range waits until the other call has released its own, and a range that cannot be registered
+// at all (locked-memory limits) is simply not pinned -- the copies then go through the runtime's staging buffers.
+struct HostPins {
+	struct Ent { const uint8_t* b; size_t n; int refs; };
+	std::mutex mu; std::condition_variable cv; std::vector<Ent> ents;
+	bool pin(const void* ptr, size_t n)                       // true: the range is page-locked (and mapped) until unpin
+	{
+		if (!ptr || !n) { return false; }
+		const uint8_t* b = static_cast<const uint8_t*>(ptr);
+		std::unique_lock<std::mutex> lk(mu);
+		for (;;) {
+			bool overlap = false;
+			for (auto& e : ents) {
+				if (e.b == b && e.n == n) { ++e.refs; return true; }
+				if (b < e.b + e.n && e.b < b + n) { overlap = true; }
+			}
+			if (!overlap) { break; }
+			cv.wait(lk);
+		}
+		if (hipHostRegister(const_cast<uint8_t*>(b), n, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return false; }
+		ents.push_back(Ent{ b, n, 1 });
+		return true;
+	}
+	void unpin(const void* ptr, size_t n)
+	{
+		const uint8_t* b = static_cast<const uint8_t*>(ptr);
+		std::unique_lock<std::mutex> lk(mu);
+		for (size_t i = 0; i < ents.size(); ++i) {
+			if (ents[i].b == b && ents[i].n == n) {
+				if (--ents[i].refs == 0) { (void)hipHostUnregister(const_cast<uint8_t*>(b)); ents.erase(ents.begin() + (long)i); cv.notify_all(); }
+				return;
+			}
+		}
+	}
+};
+static HostPins g_pins;
+
 // one large host buffer through the GPU with the link busy in both directions while the kernels run. LZNT1 chunks
 // are independent and the output is their concatenation (lznt1_compress.cpp:262), so the buffer is cut into slices of 1024 chunks:
 // slice k + 1 is on its way up (stream h2d) and slice k - 1 on its way down (stream d2h) while slice k is compressed (the
@@ -863,9 +904,8 @@ static MSCompStatus lznt1_compress_pipelined(OneShotTls& tls, const uint8_t* in,
 	uint8_t* d_in = static_cast<uint8_t*>(c->one_in.p); uint8_t* d_out = static_cast<uint8_t*>(c->one_out.p);
 	uint64_t* d_len = static_cast<uint64_t*>(tls.d_meta.p); int32_t* d_st = reinterpret_cast<int32_t*>(d_len + ns);
 	const size_t most = lznt1_max_compressed_size(in_len) + 2, out_span = cap < most ? cap : most;
-	const bool reg_in = hipHostRegister(const_cast<uint8_t*>(in), in_len, hipHostRegisterDefault) == hipSuccess;
-	const bool reg_out = out_span && hipHostRegister(out, out_span, hipHostRegisterDefault) == hipSuccess;
-	(void)hipGetLastError();
+	const bool reg_in = g_pins.pin(in, in_len);
+	const bool reg_out = out_span && g_pins.pin(out, out_span);
 	MSCompStatus rs = MSCOMP_OK;
 	for (size_t k = 0; k < ns && rs == MSCOMP_OK; ++k) {
 		const size_t o = k * SL, len = in_len - o < SL ? in_len - o : SL;
@@ -896,8 +936,8 @@ static MSCompStatus lznt1_compress_pipelined(OneShotTls& tls, const uint8_t* in,
 	}
 	(void)hipStreamSynchronize(tls.h2d); (void)hipStreamSynchronize(tls.exec);
 	if (hipStreamSynchronize(tls.d2h) != hipSuccess && rs == MSCOMP_OK) { rs = MSCOMP_ERRNO; }
-	if (reg_in) { (void)hipHostUnregister(const_cast<uint8_t*>(in)); }
-	if (reg_out) { (void)hipHostUnregister(out); }
+	if (reg_in) { g_pins.unpin(in, in_len); }
+	if (reg_out) { g_pins.unpin(out, out_span); }
 	if (rs != MSCOMP_OK) { return rs; }
 	if (!fits) { return MSCOMP_BUF_ERROR; }
 	if (cap - total >= 2) { out[total] = 0; out[total + 1] = 0; }   // the uncounted End_of_buffer bytes (lznt1_compress.cpp:270)
@@ -917,8 +957,8 @@ static MSCompStatus lznt1_zero_copy(OneShotTls& tls, bool decompress, const uint
 	const size_t cap = *out_len;
 	const size_t most = decompress ? (in_len / 3 + 1) * 4096 : lznt1_max_compressed_size(in_len) + 2, out_span = cap < most ? cap : most;   // (what the format can produce: see one_shot)
 	if (!out_span || !c->one_meta.reserve(64)) { return (MSCompStatus)-100; }
-	if (hipHostRegister(const_cast<uint8_t*>(in), in_len, hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return (MSCompStatus)-100; }
-	if (hipHostRegister(out, out_span, hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); (void)hipHostUnregister(const_cast<uint8_t*>(in)); return (MSCompStatus)-100; }
+	if (!g_pins.pin(in, in_len)) { return (MSCompStatus)-100; }
+	if (!g_pins.pin(out, out_span)) { g_pins.unpin(in, in_len); return (MSCompStatus)-100; }
 	void* din = nullptr; void* dout = nullptr;
 	MSCompStatus rs = MSCOMP_OK;
 	struct { uint64_t len; int32_t st; int32_t pad; } meta = { 0, MSCOMP_ERRNO, 0 };
@@ -930,7 +970,7 @@ static MSCompStatus lznt1_zero_copy(OneShotTls& tls, bool decompress, const uint
 		if (rs == MSCOMP_OK) { rs = mscomp_amd_plan_execute(p, static_cast<const uint8_t*>(din), static_cast<uint8_t*>(dout), d_len, d_st); }
 		if (rs == MSCOMP_OK && (hipMemcpyAsync(&meta, d_len, sizeof meta, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) { rs = MSCOMP_ERRNO; }
 	}
-	(void)hipHostUnregister(const_cast<uint8_t*>(in)); (void)hipHostUnregister(out);
+	g_pins.unpin(in, in_len); g_pins.unpin(out, out_span);
 	if (rs != MSCOMP_OK) { return rs; }
 	if (meta.st != MSCOMP_OK) { return (MSCompStatus)meta.st; }
 	*out_len = (size_t)meta.len;

@@ -1044,7 +1044,10 @@ __global__ __launch_bounds__(64) void xps_emit_kernel(const uint8_t* __restrict_
 	XPT_RING_START(W.ip)
 	xpt_walk<true>(s_in, ab, endq, loaded, nxt, W, lim, bt.out_cap[u], tok + tok_prefix[u], lane);
 	// the same walk as the one that was counted, now with the tests that need the output offset: anything else than the counted end is a failed test
-	const bool same = W.ip == seg[k].e_ip && W.tc == seg[k].tbase + seg[k].ntok && W.op == seg[k].obase + seg[k].nout && (W.running ? seg[k].kind == 0u : (seg[k].kind == 1u && W.status == 0));
+	// (... including the pending length nibble the walk leaves with: it seeds the next segment's walk, and a record rewritten by a later round while
+	// this segment was read could agree on everything else)
+	const uint32_t e_hp = W.have_half ? W.hp : 0xFFFFFFFFu;
+	const bool same = W.ip == seg[k].e_ip && W.tc == seg[k].tbase + seg[k].ntok && W.op == seg[k].obase + seg[k].nout && (W.running ? (seg[k].kind == 0u && e_hp == seg[k].e_hp) : (seg[k].kind == 1u && W.status == 0));
 	if (!same && lane == 0) { x.done[u] = 0; }                            // the one-wave walk takes the stream after all
 }
 

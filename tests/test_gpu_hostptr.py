@@ -100,6 +100,30 @@ def test_four_threads_compress_large_buffers_at_once(gpu_ctx):
     assert not bad, bad
 
 
+def test_two_threads_compress_the_same_input_at_once(gpu_ctx, mozilla):
+    """legal in the reference (only in / out must not alias): both calls page-lock the SAME input range -- the registration is shared and
+    outlives the first call to finish (csrc/api.hip HostPins); through the mapped path and through the slices"""
+    import ms_compress_amd as m
+    lib = m.load_library()
+    g = GOLD["mozilla"]["lznt1"]
+    for sliced in (0, 1):
+        lib.mscomp_amd_debug_set_one_shot(sliced)
+        bad = []
+
+        def work():
+            cap = lib.ms_max_compressed_size(2, len(mozilla)) + 2
+            for _ in range(3):
+                st, ol, out = _call(lib, 2, mozilla, cap, 0)
+                if not (st == 0 and ol == g["len"] and sha(out[:ol]) == g["sha256"]):
+                    bad.append((st, ol))
+        try:
+            ts = [threading.Thread(target=work) for _ in range(3)]
+            [t.start() for t in ts]; [t.join() for t in ts]
+        finally:
+            lib.mscomp_amd_debug_set_one_shot(0)
+        assert not bad, (sliced, bad)
+
+
 @pytest.mark.parametrize("fmt,key", [(3, "xpress"), (4, "xpress_huff")])
 def test_whole_file_host_pointer_xpress_formats(gpu_ctx, fmt, key):
     """one 21 MB buffer through ms_compress with host pointers: bytes of the reference, exact capacity, one short -> MSCOMP_BUF_ERROR"""
