@@ -33,7 +33,7 @@ EXPORTS = [  # every symbol include/mscomp_amd.h declares (tests check the libra
     "ms_deflate_init", "ms_deflate", "ms_deflate_end", "lznt1_deflate_init", "lznt1_deflate", "lznt1_deflate_end",
     "xpress_deflate_init", "xpress_deflate", "xpress_deflate_end", "xpress_inflate_init", "xpress_inflate", "xpress_inflate_end",
     "ms_decompress", "lznt1_decompress", "xpress_decompress", "xpress_huff_decompress", "mscomp_amd_plan_create_decompress", "mscomp_amd_decompress_batch",
-    "mscomp_amd_version", "mscomp_amd_debug_xpress_matches", "mscomp_amd_debug_huff_lengths", "mscomp_amd_debug_lds_lane_order", "mscomp_amd_debug_set_xpress_emit", "mscomp_amd_debug_set_lznt1", "mscomp_amd_compress_units_host", "mscomp_amd_host_pool_release", "mscomp_amd_debug_set_finder", "mscomp_amd_debug_set_one_shot", "mscomp_amd_debug_set_xpress_decoder", "mscomp_amd_debug_lzg_open", "mscomp_amd_set_lznt1_sa_dict", "mscomp_amd_get_lznt1_sa_dict", "mscomp_amd_debug_lzd_walked",
+    "mscomp_amd_version", "mscomp_amd_debug_xpress_matches", "mscomp_amd_debug_huff_lengths", "mscomp_amd_debug_lds_lane_order", "mscomp_amd_debug_set_xpress_emit", "mscomp_amd_debug_set_lznt1", "mscomp_amd_compress_units_host", "mscomp_amd_decompress_units_host", "mscomp_amd_host_pool_release", "mscomp_amd_debug_set_finder", "mscomp_amd_debug_set_one_shot", "mscomp_amd_debug_set_xpress_decoder", "mscomp_amd_debug_lzg_open", "mscomp_amd_set_lznt1_sa_dict", "mscomp_amd_get_lznt1_sa_dict", "mscomp_amd_debug_lzd_walked",
 ]
 
 
@@ -122,6 +122,8 @@ def load_library():
     lib.mscomp_amd_debug_set_finder.restype = None
     lib.mscomp_amd_compress_units_host.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mscomp_amd_compress_units_host.restype = C.c_int
+    lib.mscomp_amd_decompress_units_host.argtypes = lib.mscomp_amd_compress_units_host.argtypes
+    lib.mscomp_amd_decompress_units_host.restype = C.c_int
     lib.mscomp_amd_host_pool_release.argtypes = []
     lib.mscomp_amd_host_pool_release.restype = None
     lib.mscomp_amd_debug_set_one_shot.argtypes = [C.c_int]
@@ -317,7 +319,12 @@ def compress_units(fmt, units, ctx=None, capacities=None, decompress=False):
 
 
 
-def compress_units_host(fmt, in_arrays, out_arrays, devices=(0,)):
+def decompress_units_host(fmt, in_arrays, out_arrays, devices=(0,)):
+    """mscomp_amd_decompress_units_host: like compress_units_host for the decoders (capacity of unit i = len(out_arrays[i]))."""
+    return compress_units_host(fmt, in_arrays, out_arrays, devices=devices, decompress=True)
+
+
+def compress_units_host(fmt, in_arrays, out_arrays, devices=(0,), decompress=False):
     """mscomp_amd_compress_units_host: units given as numpy uint8 arrays (host memory, any layout), outputs written into the numpy uint8
     arrays of out_arrays (capacity = their length), on the GPUs `devices` (a range per entry; an ordinal may repeat). Returns
     (status of the call, out_lens uint64 array, statuses int32 array). Nothing is copied on the Python side."""
@@ -331,5 +338,6 @@ def compress_units_host(fmt, in_arrays, out_arrays, devices=(0,)):
     ol = np.zeros(max(1, n), dtype=np.uint64)
     st = np.full(max(1, n), -9, dtype=np.int32)
     dv = (C.c_int * len(devices))(*[int(d) for d in devices])
-    rc = lib.mscomp_amd_compress_units_host(int(fmt), len(devices), dv, n, ip, il, op, oc, ol.ctypes.data, st.ctypes.data)
+    fn = lib.mscomp_amd_decompress_units_host if decompress else lib.mscomp_amd_compress_units_host
+    rc = fn(int(fmt), len(devices), dv, n, ip, il, op, oc, ol.ctypes.data, st.ctypes.data)
     return rc, ol[:n], st[:n]

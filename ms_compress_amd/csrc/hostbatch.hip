@@ -93,7 +93,7 @@ Worker* take_worker(int dev)
 void give_worker(Worker* w) { std::lock_guard<std::mutex> lk(g_pool_mu); g_pool.push_back(w); }
 
 struct Job {
-	MSCompFormat format; size_t n;
+	MSCompFormat format; bool decompress; size_t n;
 	const uint8_t* const* in_ptrs; const size_t* in_lens; uint8_t* const* out_ptrs; const size_t* out_caps; size_t* out_lens; MSCompStatus* statuses;
 };
 struct Batch { size_t b0, b1; std::vector<uint64_t> in_off, in_len, out_off, out_cap; uint64_t in_total, out_total; bool out_mirror; mscomp_amd_plan* plan; };
@@ -121,7 +121,15 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 		}
 		b.b1 = i; b.in_total = in_pos;
 		uint64_t out_pos = 0;                                      // outputs: the caller's layout when it is capacity after capacity (one download), else 16-byte aligned starts
-		for (size_t k = b.b0; k < b.b1; ++k) { b.out_off.push_back(out_pos); b.out_cap.push_back(j.out_caps[k]); out_pos += b.out_mirror ? j.out_caps[k] : ((j.out_caps[k] + 15u) & ~(uint64_t)15u); }
+		// (a compressor's device capacity is what the format can produce, never a generous caller capacity -- *out_len = 1 << 40 is legal in the
+		// reference and must not become an allocation; a unit that fits that bound gets the status and bytes it would get with any larger capacity)
+		std::vector<uint64_t> dcap(b.b1 - b.b0);
+		for (size_t k = b.b0; k < b.b1; ++k) {
+			uint64_t c = j.out_caps[k];
+			if (!j.decompress) { const uint64_t most = (uint64_t)ms_max_compressed_size(j.format, j.in_lens[k]) + 2u; if (most < c) { c = most; b.out_mirror = false; } }
+			dcap[k - b.b0] = c;
+		}
+		for (size_t k = b.b0; k < b.b1; ++k) { const uint64_t c = dcap[k - b.b0]; b.out_off.push_back(out_pos); b.out_cap.push_back(c); out_pos += b.out_mirror ? c : ((c + 15u) & ~(uint64_t)15u); }
 		b.out_total = out_pos;
 		batches.push_back(std::move(b));
 	}
@@ -144,7 +152,7 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 		}
 		auto span = [&](size_t i) -> size_t {                      // bytes of unit i to bring home: the stream, and for LZNT1 the two uncounted 00 00 behind it
 			size_t len = (size_t)h_len[i];
-			if (j.format == MSCOMP_LZNT1 && j.out_caps[b.b0 + i] - len >= 2) { len += 2; }
+			if (!j.decompress && j.format == MSCOMP_LZNT1 && j.out_caps[b.b0 + i] - len >= 2) { len += 2; }
 			return len;
 		};
 		if (b.out_mirror && last_ok != n) {
@@ -180,7 +188,8 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 		if (rs == MSCOMP_OK && hipEventRecord(w->ev_up[slot], w->up) != hipSuccess) { rs = MSCOMP_ERRNO; }
 		if (rs != MSCOMP_OK) { break; }
 		// (the plan's tables go up on the kernel stream and wait for it: batch k - 1 is in the kernels meanwhile, batch k on its way up)
-		rs = mscomp_amd_plan_create(w->ctx, j.format, n, b.in_off.data(), b.in_len.data(), b.out_off.data(), b.out_cap.data(), &b.plan);
+		rs = j.decompress ? mscomp_amd_plan_create_decompress(w->ctx, j.format, n, b.in_off.data(), b.in_len.data(), b.out_off.data(), b.out_cap.data(), &b.plan)
+		                  : mscomp_amd_plan_create(w->ctx, j.format, n, b.in_off.data(), b.in_len.data(), b.out_off.data(), b.out_cap.data(), &b.plan);
 		if (rs != MSCOMP_OK) { break; }
 		uint64_t* d_len = static_cast<uint64_t*>(w->d_meta[slot]); int32_t* d_st = reinterpret_cast<int32_t*>(d_len + n);
 		if (hipStreamWaitEvent(w->ex, w->ev_up[slot], 0) != hipSuccess) { rs = MSCOMP_ERRNO; break; }
@@ -202,9 +211,9 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 
 extern "C" {
 
-MSCompStatus mscomp_amd_compress_units_host(MSCompFormat format, int n_dev, const int* devices, size_t n_units,
-                                            const uint8_t* const* in_ptrs, const size_t* in_lens, uint8_t* const* out_ptrs, const size_t* out_caps,
-                                            size_t* out_lens, MSCompStatus* statuses)
+static MSCompStatus units_host(MSCompFormat format, bool decompress, int n_dev, const int* devices, size_t n_units,
+                               const uint8_t* const* in_ptrs, const size_t* in_lens, uint8_t* const* out_ptrs, const size_t* out_caps,
+                               size_t* out_lens, MSCompStatus* statuses)
 {
 	if (format != MSCOMP_LZNT1 && format != MSCOMP_XPRESS && format != MSCOMP_XPRESS_HUFF) { return MSCOMP_ARG_ERROR; }      // mscomp.cpp:115
 	if (n_dev < 1 || n_dev > 64 || (n_units && (!in_ptrs || !in_lens || !out_ptrs || !out_caps || !out_lens || !statuses))) { return MSCOMP_ARG_ERROR; }
@@ -229,7 +238,7 @@ MSCompStatus mscomp_amd_compress_units_host(MSCompFormat format, int n_dev, cons
 		cuts[r] = k < n_units ? k : n_units;
 	}
 	cuts[n_dev] = n_units;
-	const Job job = { format, n_units, in_ptrs, in_lens, out_ptrs, out_caps, out_lens, statuses };
+	const Job job = { format, decompress, n_units, in_ptrs, in_lens, out_ptrs, out_caps, out_lens, statuses };
 	std::vector<MSCompStatus> res(n_dev, MSCOMP_OK);
 	std::vector<std::thread> threads;
 	auto body = [&](int r) {
@@ -245,6 +254,22 @@ MSCompStatus mscomp_amd_compress_units_host(MSCompFormat format, int n_dev, cons
 	(void)hipSetDevice(prev);
 	for (int r = 0; r < n_dev; ++r) { if (res[r] != MSCOMP_OK) { return res[r]; } }
 	return MSCOMP_OK;
+}
+
+MSCompStatus mscomp_amd_compress_units_host(MSCompFormat format, int n_dev, const int* devices, size_t n_units,
+                                            const uint8_t* const* in_ptrs, const size_t* in_lens, uint8_t* const* out_ptrs, const size_t* out_caps,
+                                            size_t* out_lens, MSCompStatus* statuses)
+{
+	return units_host(format, false, n_dev, devices, n_units, in_ptrs, in_lens, out_ptrs, out_caps, out_lens, statuses);
+}
+
+// the same for the decoders: unit i is one ms_decompress(format, in_ptrs[i], in_lens[i], out_ptrs[i], &out_lens[i]) call with *out_len = out_caps[i]
+// (mscomp.h:79): statuses[i] = MSCOMP_OK / MSCOMP_BUF_ERROR / MSCOMP_DATA_ERROR as the reference's one-shot decoder returns them
+MSCompStatus mscomp_amd_decompress_units_host(MSCompFormat format, int n_dev, const int* devices, size_t n_units,
+                                              const uint8_t* const* in_ptrs, const size_t* in_lens, uint8_t* const* out_ptrs, const size_t* out_caps,
+                                              size_t* out_lens, MSCompStatus* statuses)
+{
+	return units_host(format, true, n_dev, devices, n_units, in_ptrs, in_lens, out_ptrs, out_caps, out_lens, statuses);
 }
 
 // releases the pooled workers (contexts, streams, staging) of every device; safe while no call is running

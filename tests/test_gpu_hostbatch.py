@@ -96,6 +96,53 @@ def test_contiguous_layout_and_short_capacities(oracle, gpu_ctx, fmt):
         assert bool((o[c:] == GUARD).all())
 
 
+@pytest.mark.parametrize("fmt", [2, 3, 4])
+def test_decoders_through_host_pointers(oracle, gpu_ctx, fmt):
+    """mscomp_amd_decompress_units_host: valid, cut and corrupted streams and short capacities, two ranges on one GPU: statuses and bytes of the
+    checker (one ms_decompress call per unit), guards behind every capacity untouched"""
+    import random
+    import ms_compress_amd as m
+    rnd = random.Random(40 + fmt)
+    units = [u for u in cases.edge_cases()[::7] if 0 < len(u) < 150000] + [cases.mixed_buffer()[:200000]]
+    comp = [oracle.oracle_compress(fmt, u)[1] for u in units]
+    streams, caps = [], []
+    for u, c in zip(units, comp):
+        streams.append(c); caps.append(len(u))
+        streams.append(c); caps.append(max(0, len(u) - 1))
+        if len(c) > 8:
+            streams.append(c[: len(c) // 2]); caps.append(len(u))
+            b = bytearray(c); b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+            streams.append(bytes(b)); caps.append(len(u) + 5)
+    ins = [np.frombuffer(s, dtype=np.uint8) for s in streams]
+    outs = [np.full(c + 16, GUARD, dtype=np.uint8) for c in caps]
+    rc, lens, st = m.decompress_units_host(fmt, ins, [o[:c] for o, c in zip(outs, caps)], devices=(0, 0))
+    assert rc == 0
+    for i, (s_, c) in enumerate(zip(streams, caps)):
+        so, oo, undefined = oracle.oracle_decompress_ex(fmt, s_, c)
+        if undefined:
+            continue
+        assert st[i] == so and (so != 0 or (int(lens[i]) == len(oo) and bytes(outs[i][: len(oo)]) == oo)), (fmt, i, len(s_), c, st[i], so)
+        assert bool((outs[i][c:] == GUARD).all())
+
+
+def test_generous_capacities_do_not_become_allocations(oracle, gpu_ctx):
+    """*out_len far beyond what the format can produce is legal in the reference: the device copy is sized by ms_max_compressed_size (no way to
+    hand over a terabyte array through numpy: the C entry is called with capacities larger than the arrays, whose real size still holds any stream)"""
+    import ctypes as C
+    import ms_compress_amd as m
+    lib = m.load_library()
+    data = np.frombuffer(cases.mixed_buffer()[:100000], dtype=np.uint8)
+    for fmt in (2, 3, 4):
+        exp = oracle.oracle_compress(fmt, data.tobytes())[1]
+        out = np.full(m.max_compressed_size(fmt, data.size) + 64, GUARD, dtype=np.uint8)
+        ip = (C.c_void_p * 1)(data.ctypes.data); il = (C.c_size_t * 1)(data.size)
+        op = (C.c_void_p * 1)(out.ctypes.data); oc = (C.c_size_t * 1)(1 << 40)
+        ol = (C.c_size_t * 1)(0); st = (C.c_int * 1)(-9)
+        dv = (C.c_int * 1)(0)
+        assert lib.mscomp_amd_compress_units_host(fmt, 1, dv, 1, ip, il, op, oc, ol, st) == 0
+        assert st[0] == 0 and ol[0] == len(exp) and bytes(out[: len(exp)]) == exp
+
+
 def test_argument_errors(gpu_ctx):
     import ms_compress_amd as m
     a = np.zeros(100, dtype=np.uint8); o = np.zeros(200, dtype=np.uint8)
