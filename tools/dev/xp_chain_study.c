@@ -15,7 +15,7 @@ int main(int argc, char** argv)
 	int32_t* link = malloc(N * 4); int32_t* head = malloc(32768 * 4);
 	uint8_t* blen = malloc(N); uint32_t* boff = malloc(N * 4); uint8_t* ncand = malloc(N);
 	double pairs = 0, rounds = 0, improv = 0, nice = 0, witers = 0, pos = 0, has1 = 0, filt4 = 0, wit_first2 = 0, cand_hist[13] = {0};
-	double compares_to_best = 0;
+	double compares_to_best = 0, lenh[6] = {0};
 	for (size_t ub = 0; ub < N; ub += unit) {
 		size_t n = N - ub < unit ? N - ub : unit; const uint8_t* u = d + ub;
 		for (int i = 0; i < 32768; ++i) head[i] = -1;
@@ -36,6 +36,7 @@ int main(int argc, char** argv)
 						if (memcmp(u + x + fo, u + p + fo, 4) == 0) filt4++;
 						uint32_t l = 0; while (l < cap && u[x + l] == u[p + l]) l++;
 						rounds += 1 + (l >= 16 && cap > 16) + (l >= 32 && cap > 32);
+						lenh[l < 3 ? 0 : l < 8 ? 1 : l < 16 ? 2 : l < 32 ? 3 : l < 48 ? 4 : 5]++;
 						if (l > best) { best = l; bo = p - x; improv++; compares_to_best = compares_to_best; if (best >= 48) { nice++; break; } }
 						x = link[ub + x]; chain--;
 					}
@@ -66,6 +67,7 @@ int main(int argc, char** argv)
 	}
 	printf("%-9s mode %d: pos %.0f pairs/pos %.2f (has>=1: %.2f) rounds/pair %.2f improv/pos %.2f nice/pos %.3f filt4pass/pair %.2f lane_eff %.2f witers/wave %.2f | tok/pos %.3f lit/tok %.2f pairs/tok %.2f emptywin %.3f\n",
 	       strrchr(argv[1], '/') + 1, mode, pos, pairs / pos, has1 / pos, rounds / pairs, improv / pos, nice / pos, filt4 / pairs, pairs / (64 * witers), witers / (pos / 64), tok / pos, lit / tok, tokpairs / tok, emptyw / wcnt);
+	printf("   pair length shares: <3 %.3f  3-7 %.3f  8-15 %.3f  16-31 %.3f  32-47 %.3f  48 %.3f\n", lenh[0] / pairs, lenh[1] / pairs, lenh[2] / pairs, lenh[3] / pairs, lenh[4] / pairs, lenh[5] / pairs);
 	printf("   cand hist:"); for (int i = 0; i <= 11; ++i) printf(" %d:%.3f", i, cand_hist[i] / pos); printf("\n");
 	return 0;
 }
