@@ -32,6 +32,9 @@ namespace msc {
 #define XZ_PAD   144u                     // bytes staged behind the tile: a lane extends a capped match up to 112 + 16 bytes itself
 #define XZ_LIST  512u                     // parked walks (positions) of a whole unit: slots are handed out by a counter that only grows, slot i belongs to lane i
 #define XZ_CACHE 4u                       // ends of long matches kept for the other positions inside them
+#ifndef XZ_FREP
+#define XZ_FREP 3u                        // chain candidates a lane may finish per step (the DONE / NEW blocks run once per step)
+#endif
 #define XZ_OWN_EXT 112u                   // a lane compares up to here itself, 16 bytes a step; beyond, the wave compares 256 bytes a step from global memory
 
 enum { XZ_IDLE = 0, XZ_NEW = 1, XZ_FIND = 2, XZ_FIND2 = 3, XZ_DONE = 4, XZ_EXT = 5, XZ_DONE2 = 6, XZ_COOP = 7 };
@@ -155,6 +158,8 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 				if (!__ballot(st != XZ_IDLE)) { break; }
 				XZ_CNT(0, 1)
 				// ---- FIND: one 16-byte compare of one chain candidate (its first 16 bytes against my own in registers)
+				#pragma unroll 1
+				for (uint32_t rep = 0; rep < XZ_FREP; ++rep) {
 				if (__ballot(st == XZ_FIND)) {
 					if (st == XZ_FIND) {
 						XZ_CNT(2, 1)
@@ -168,8 +173,15 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 							fetch = nlk != 0xFFFFu && chain != 0u && (p - nlk) <= XZ_WIN && (best >> 16) < 48u;
 							x = nlk;
 							st = fetch ? XZ_FIND : XZ_DONE;
+							if (fetch && rep + 1u < XZ_FREP) {
+								const uint32_t xw = x - tb + XZ_WIN;
+								cand = lds_ld128(s_data, xw);
+								nlk = s_links[xw];
+								fetch = false;
+							}
 						}
 					}
+				} else { break; }
 				}
 				// ---- FIND2 / EXT: 16 more bytes of the same candidate (both sides from LDS)
 				if (__ballot(st == XZ_FIND2 || st == XZ_EXT)) {

@@ -11,6 +11,7 @@ import bench
 codec = sys.argv[1]; mode = int(sys.argv[2]); kind = sys.argv[3] if len(sys.argv) > 3 else "config5"; steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 ctx = m.Context()
 ctx.lib.mscomp_amd_debug_set_finder(mode)
+if os.environ.get('MSCOMP_AB_LZ'): ctx.lib.mscomp_amd_debug_set_lznt1(int(os.environ['MSCOMP_AB_LZ']))
 dev = torch.device("cuda", 0)
 cor = bench.Corpus(corpus, dev)
 fmt = m.FORMATS[codec]

@@ -5,11 +5,14 @@ import numpy as np, torch
 import ms_compress_amd as m
 from ms_compress_amd import corpus, sharding
 import bench
-ctx = m.Context(); cor = bench.Corpus(corpus, torch.device("cuda", 0))
+ctx = m.Context()
+if os.environ.get('MSCOMP_AB_FINDER'): ctx.lib.mscomp_amd_debug_set_finder(int(os.environ['MSCOMP_AB_FINDER']))
+if os.environ.get('MSCOMP_AB_EMIT'): ctx.lib.mscomp_amd_debug_set_xpress_emit(int(os.environ['MSCOMP_AB_EMIT']))
+cor = bench.Corpus(corpus, torch.device("cuda", 0))
 for codec in sys.argv[1:] or ["lznt1", "xpress", "xpress_huff"]:
     f = m.FORMATS[codec]
     off, ln, _ = bench.config5_units(cor, f)
-    for reps in (2, 16):
+    for reps in [int(x) for x in os.environ.get('MSCOMP_AB_REPS', '2,16').split(',')]:
         nu = len(ln) // 16 * reps
         j = bench.Job(m, ctx, f, cor.device_range(0, reps * cor.total), off[:nu], ln[:nu])
         t, p = bench.timed(j, 3, 1, sharding)
