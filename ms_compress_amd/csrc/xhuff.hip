@@ -292,13 +292,13 @@ struct HuffLds {
 };
 
 // What xh_huff_kernel needs of it: the counts stay in registers (8 per lane) and the results (lens, codes) take the heap's
-// place once the tree is built -- 8.2 KiB instead of 11.8 KiB: 19 chunks in flight per CU instead of 13.
+// place once the tree is built, the leaf weights are 8 registers per lane -- 6.2 KiB instead of 11.8 KiB: 24 chunks in flight per
+// CU instead of 13.
 struct HuffLdsFast {
 	union {
 		__attribute__((aligned(16))) uint2 heap[516];
 		struct { __attribute__((aligned(16))) uint8_t lens[512]; __attribute__((aligned(16))) uint16_t codes[512]; };
 	};
-	uint32_t wleaf[512];
 	uint16_t parent[1024];
 };
 
@@ -362,15 +362,18 @@ template <class H> __device__ __forceinline__ uint2 hh_pop(H& h, uint32_t hl_old
 	return top;
 }
 
-// CreateCodes lengths from h.wleaf (= max(count, 1) << 8 per symbol, :69, written by the caller) -> h.lens (one wave)
-template <class H> __device__ void huff_lengths_fast(H& h, uint32_t lane)
+// CreateCodes lengths -> h.lens (one wave). wl[k] = leaf weight of symbol lane + 64 k = max(count, 1) << 8 (:69), in registers.
+template <class H> __device__ void huff_lengths_fast(H& h, uint32_t lane, uint32_t (&wl)[8])
 {
 	__syncthreads();
 	for (;;) {
 		for (uint32_t i = lane; i < 1024u; i += 64u) { h.parent[i] = 0; }
 		for (uint32_t i = lane; i < 516u; i += 64u) { h.heap[i] = i ? make_uint2(HH_SENT, 0) : make_uint2(0, 0); }
 		__syncthreads();
-		for (uint32_t i = 1; i <= 512u; ++i) { hh_push(h, i, make_uint2(h.wleaf[i - 1u], i), lane); }   // :74
+		#pragma unroll
+		for (uint32_t k = 0; k < 8u; ++k) {                         // :74, symbols in order
+			for (uint32_t j = 0; j < 64u; ++j) { hh_push(h, k * 64u + j + 1u, make_uint2((uint32_t)__builtin_amdgcn_readlane((int)wl[k], (int)j), k * 64u + j + 1u), lane); }
+		}
 		uint32_t hl = 512, nn = 512;
 		while (hl > 1u) {                                           // :78-85
 			const uint2 ea = hh_pop(h, hl, lane); --hl;
@@ -393,7 +396,8 @@ template <class H> __device__ void huff_lengths_fast(H& h, uint32_t lane)
 		}
 		if (!__ballot(too_long)) { break; }
 		__syncthreads();
-		for (uint32_t i = lane; i < 512u; i += 64u) { h.wleaf[i] = (1u + (h.wleaf[i] >> 9)) << 8; }    // :100-105
+		#pragma unroll
+		for (uint32_t k = 0; k < 8u; ++k) { wl[k] = (1u + (wl[k] >> 9)) << 8; }                        // :100-105
 		__syncthreads();
 	}
 	__syncthreads();
@@ -435,10 +439,10 @@ __global__ __launch_bounds__(64) void xh_huff_kernel(BatchTables bt, const uint3
 	const uint32_t lane = threadIdx.x;
 	const uint32_t lc = blockIdx.x;
 	const ChunkGeom g = chunk_geom(bt, lc);
-	uint32_t mycnt[8];                                            // counts of the symbols lane + 64 k
+	uint32_t mycnt[8], wl[8];                                     // counts / leaf weights of the symbols lane + 64 k
 	#pragma unroll
-	for (uint32_t k = 0; k < 8u; ++k) { const uint32_t c = counts[(u64)lc * 512u + lane + 64u * k]; mycnt[k] = c; h.wleaf[lane + 64u * k] = (c ? c : 1u) << 8; }
-	huff_lengths_fast(h, lane);
+	for (uint32_t k = 0; k < 8u; ++k) { const uint32_t c = counts[(u64)lc * 512u + lane + 64u * k]; mycnt[k] = c; wl[k] = (c ? c : 1u) << 8; }
+	huff_lengths_fast(h, lane, wl);
 	// xh_calc_compressed_len (:181-188): 16 + sum (len + offset bits) * count, rounded to 16-bit words, + raw length bytes
 	uint32_t bits = 0;
 	#pragma unroll
@@ -461,8 +465,10 @@ __global__ __launch_bounds__(64) void xh_huff_debug_kernel(const uint32_t* __res
 {
 	__shared__ HuffLdsFast h;
 	const uint32_t lane = threadIdx.x;
-	for (uint32_t i = lane; i < 512u; i += 64u) { const uint32_t c = counts[(u64)blockIdx.x * 512u + i]; h.wleaf[i] = (c ? c : 1u) << 8; }
-	huff_lengths_fast(h, lane);
+	uint32_t wl[8];
+	#pragma unroll
+	for (uint32_t k = 0; k < 8u; ++k) { const uint32_t c = counts[(u64)blockIdx.x * 512u + lane + 64u * k]; wl[k] = (c ? c : 1u) << 8; }
+	huff_lengths_fast(h, lane, wl);
 	reinterpret_cast<uint2*>(lens_out + (u64)blockIdx.x * 512u)[lane] = reinterpret_cast<const uint2*>(h.lens)[lane];
 }
 void launch_xh_huff_debug(hipStream_t st, const uint32_t* counts, uint8_t* lens, uint32_t n)
