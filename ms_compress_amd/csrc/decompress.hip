@@ -1064,9 +1064,9 @@ void launch_xpress_decompress_tokens(hipStream_t st, const uint8_t* d_in, const 
 // together (counts and canonical ranks by ballots), then all lanes walk the symbols; codes of up to 9 bits resolve with one LDS
 // read (symbol << 4 | length). The walk needs the output only as a running length, so it writes 32-bit tokens (a literal, or
 // offset | length << 16; a match longer than 32766 is cut into matches with the same offset, which copy the same bytes) and
-// keeps 7 KiB of LDS: 23 buffers per CU instead of the 2 that a 64 KiB output window allows. The bytes are produced afterwards
+// keeps 4.1 KiB of LDS: 32 buffers per CU instead of the 2 that a 64 KiB output window allows. The bytes are produced afterwards
 // by lz_copy_kernel, in parallel.
-#define XHD_INB  2048u
+#define XHD_INB  1024u                 // input ring: two blocks of this size (the walk looks at most 320 bytes ahead); 4.1 KiB of LDS per wave -> 32 waves per CU
 struct XhdLds {
 	__attribute__((aligned(16))) uint8_t in[2u * XHD_INB];
 	uint16_t fast[512];                 // 9-bit prefix -> symbol << 4 | length (0: longer code)
@@ -1093,11 +1093,11 @@ __global__ __launch_bounds__(64) void xhd_parse_kernel(const uint8_t* __restrict
 	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
 	const uint8_t* ab = src - a0;
 	const uint32_t endq = a0 + n;                                        // units are below 4 GiB - 4096
-	uint32_t loaded = 0;                                                 // blocks of 2048 input bytes brought to LDS so far (the last two are resident)
-	// a block is loaded when the walk gets there (one HBM round trip per 2 KiB of input: nothing next to ~5000 symbols); values that
+	uint32_t loaded = 0;                                                 // blocks of XHD_INB input bytes brought to LDS so far (the last two are resident)
+	// a block is loaded when the walk gets there (one HBM round trip per KiB of input: nothing next to ~2500 symbols); values that
 	// live across the walk in registers (a prefetched block) made the compiler wait for memory and shuffle them on every symbol
 	#define XHD_BLOCK() { uint8_t* b_ = S.in + (loaded & 1u) * XHD_INB; __syncthreads(); \
-		_Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) { const u64 q_ = (u64)loaded * XHD_INB + ((uint32_t)i_ * 64u + lane) * 16u; \
+		_Pragma("unroll") for (int i_ = 0; i_ < (int)(XHD_INB / 1024u); ++i_) { const u64 q_ = (u64)loaded * XHD_INB + ((uint32_t)i_ * 64u + lane) * 16u; \
 			*reinterpret_cast<uint4*>(b_ + ((uint32_t)i_ * 64u + lane) * 16u) = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } \
 		++loaded; __syncthreads(); }
 	// loaded * 2048 never lies behind the walk, so the distance to it is a plain 32-bit difference (units end below 4 GiB - 4096)
@@ -1312,11 +1312,11 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 	const uint32_t a0 = (uint32_t)((uintptr_t)src & 15u);
 	const uint8_t* ab = src - a0;
 	const uint32_t endq = a0 + n;                                        // units are below 4 GiB - 4096
-	uint32_t loaded = 0;                                                 // blocks of 2048 input bytes brought to LDS so far (the last two are resident)
-	// a block is loaded when the walk gets there (one HBM round trip per 2 KiB of input: nothing next to ~5000 symbols); values that
+	uint32_t loaded = 0;                                                 // blocks of XHD_INB input bytes brought to LDS so far (the last two are resident)
+	// a block is loaded when the walk gets there (one HBM round trip per KiB of input: nothing next to ~2500 symbols); values that
 	// live across the walk in registers (a prefetched block) made the compiler wait for memory and shuffle them on every symbol
 	#define XHD_BLOCK() { uint8_t* b_ = S.in + (loaded & 1u) * XHD_INB; __syncthreads(); \
-		_Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) { const u64 q_ = (u64)loaded * XHD_INB + ((uint32_t)i_ * 64u + lane) * 16u; \
+		_Pragma("unroll") for (int i_ = 0; i_ < (int)(XHD_INB / 1024u); ++i_) { const u64 q_ = (u64)loaded * XHD_INB + ((uint32_t)i_ * 64u + lane) * 16u; \
 			*reinterpret_cast<uint4*>(b_ + ((uint32_t)i_ * 64u + lane) * 16u) = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } \
 		++loaded; __syncthreads(); }
 	// loaded * 2048 never lies behind the walk, so the distance to it is a plain 32-bit difference (units end below 4 GiB - 4096)
