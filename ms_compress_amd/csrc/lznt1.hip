@@ -41,7 +41,9 @@ __device__ unsigned long long g_lz_prof[16];
 
 #define LZ_TBL_BITS 11
 #define LZ_TBL      (1u << LZ_TBL_BITS)
+#ifndef LZ_SELF
 #define LZ_SELF     4u       // candidates each lane scans by itself before the wave cooperates
+#endif
 
 __device__ __forceinline__ uint32_t lz_hash(uint32_t key24) { return (key24 * 0x9E3779B1u) >> (32 - LZ_TBL_BITS); }
 
