@@ -158,30 +158,35 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 				if (!__ballot(st != XZ_IDLE)) { break; }
 				XZ_CNT(0, 1)
 				// ---- FIND: one 16-byte compare of one chain candidate (its first 16 bytes against my own in registers)
+				// (written with selects, not nested branches: the compiler's exec-mask bookkeeping for the nested form was as long as the
+				// arithmetic; the only branch left guards the loads of the next candidate)
 				#pragma unroll 1
 				for (uint32_t rep = 0; rep < XZ_FREP; ++rep) {
-				if (__ballot(st == XZ_FIND)) {
-					if (st == XZ_FIND) {
-						XZ_CNT(2, 1)
-						const uint32_t l = xz_diff16(cand, own);
-						if (l == 16u && cap > 16u) { dl = 16u; st = XZ_FIND2; }
-						else {
-							const uint32_t lc2 = l < cap ? l : cap;
-							const uint32_t key = (lc2 << 16) | (0xFFFFu - (p - x));
-							best = best > key ? best : key;
-							--chain;
-							fetch = nlk != 0xFFFFu && chain != 0u && (p - nlk) <= XZ_WIN && (best >> 16) < 48u;
-							x = nlk;
-							st = fetch ? XZ_FIND : XZ_DONE;
-							if (fetch && rep + 1u < XZ_FREP) {
-								const uint32_t xw = x - tb + XZ_WIN;
-								cand = lds_ld128(s_data, xw);
-								nlk = s_links[xw];
-								fetch = false;
-							}
-						}
+					const bool f = st == XZ_FIND;
+					if (!__ballot(f)) { break; }
+					XZ_CNT(2, f ? 1 : 0)
+					// the candidate AFTER this one (its place is known: my candidate's link) is asked for before this one is compared,
+					// so its LDS round trip runs under the compare
+					const bool pf = f && nlk != 0xFFFFu && chain > 1u && (p - nlk) <= XZ_WIN;
+					uint4 cand2 = cand; uint32_t nlk2 = nlk;
+					if (pf) {
+						const uint32_t xw = nlk - tb + XZ_WIN;
+						cand2 = lds_ld128(s_data, xw);
+						nlk2 = s_links[xw];
 					}
-				} else { break; }
+					const uint32_t l = xz_diff16(cand, own);
+					const bool to2 = f && l == 16u && cap > 16u;
+					const bool upd = f && !to2;
+					const uint32_t lc2 = l < cap ? l : cap;
+					const uint32_t key = (lc2 << 16) | (0xFFFFu - (p - x));
+					best = (upd && key > best) ? key : best;
+					chain -= upd ? 1u : 0u;
+					const bool more = upd && pf && (best >> 16) < 48u;
+					x = upd ? nlk : x;
+					dl = to2 ? 16u : dl;
+					st = to2 ? (uint32_t)XZ_FIND2 : (upd ? (more ? (uint32_t)XZ_FIND : (uint32_t)XZ_DONE) : st);
+					if (upd) { fetch = false; }
+					if (more) { cand = cand2; nlk = nlk2; }
 				}
 				// ---- FIND2 / EXT: 16 more bytes of the same candidate (both sides from LDS)
 				if (__ballot(st == XZ_FIND2 || st == XZ_EXT)) {
