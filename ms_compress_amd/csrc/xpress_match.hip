@@ -44,7 +44,7 @@ __device__ unsigned long long g_xl_prof[8];
 extern "C" void mscomp_amd_debug_xl_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xl_prof), 64); unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_xl_prof), z, 64); }
 #endif
 #ifndef XL_FLIGHT
-#define XL_FLIGHT 16u                              // exchanges of the consumer wave in flight (full tiles; 8: 7.32 ms per pass of BASELINE configs[4], 16: 7.00)
+#define XL_FLIGHT 32u                              // exchanges of the consumer wave in flight (full tiles; 8: 7.32 ms per pass of BASELINE configs[4], 16: 7.00, 32: 6.77)
 #endif
 #define XL_NC 1u                                   // consumer waves (hash classes); the other 16-XL_NC waves produce hashes
 #define XL_NP (16u - XL_NC)
