@@ -367,6 +367,44 @@ def test_both_find_kernels_give_the_same_bytes(oracle, gpu_ctx, fmt):
         assert s == 0 and g == exp, "unit %d (%d bytes)" % (i, len(u))
 
 
+def test_lazy_xpress_finder_tiles_runs_and_parked_walks(oracle, gpu_ctx):
+    """The lazy Xpress finder (csrc/xpress_lazy.hip, units up to 64 KiB) at the places its state machine has special cases: unit sizes
+    around its 16 KiB tiles (walks parked at a tile end and taken up in the next), runs longer than a lane extends itself (112 bytes:
+    the wave takes over; the long-match cache), matches longer than 8 KiB (the eight resume points of the lagging Fill) starting at
+    awkward offsets, candidates that match exactly 16 / 32 / 48 bytes (the compare's second and third block), and the all-positions
+    kernel (debug finder 2) on the same units."""
+    import random
+    import ms_compress_amd as m
+    rnd = random.Random(77)
+    text = b"".join(rnd.choice(cases.WORDS) for _ in range(30000))
+    noise = bytes(rnd.getrandbits(8) for _ in range(70000))
+    units = []
+    for n in (16383, 16384, 16385, 16400, 32767, 32768, 32769, 49151, 49152, 49153, 65535, 65536):
+        units += [text[:n], cases.family("lz", n, rnd), cases.family("two", n, rnd)]
+    for start in (0, 1, 5, 16380, 16384, 30000):                          # a long run that begins before / at / behind a tile boundary
+        for run in (100, 113, 128, 129, 300, 8190, 8192, 8193, 8200, 9000, 20000, 40000):
+            u = bytearray(noise[:65536])
+            end = min(65536, start + 40 + run)
+            u[start + 40:end] = bytes([0x41]) * (end - start - 40)
+            units.append(bytes(u[:min(65536, end + 3000)]))
+    for k in (15, 16, 17, 31, 32, 33, 47, 48, 49, 50, 111, 112, 113, 127):   # a repeat of exactly k bytes, then a different byte
+        pat = noise[1000:1000 + k]
+        u = bytearray(noise[:3000]) + pat + b"\x01" + bytearray(noise[5000:6000]) + pat + b"\x02" + bytearray(noise[7000:9000]) + pat + b"\x03"
+        units.append(bytes(u))
+    periodic = (noise[:37] * 2000)[:65536]
+    units += [periodic, periodic[:16384 + 5], bytes(65536), bytes(16384), bytes(16385)]
+    lib = gpu_ctx.lib
+    for finder in (1, 2):
+        lib.mscomp_amd_debug_set_finder(finder)
+        try:
+            got, st = m.compress_units(3, units, ctx=gpu_ctx)
+        finally:
+            lib.mscomp_amd_debug_set_finder(1)
+        for i, (u, g, s) in enumerate(zip(units, got, st)):
+            es, exp = oracle.oracle_compress(3, u)
+            assert s == 0 and g == exp, "finder %d unit %d (%d bytes)" % (finder, i, len(u))
+
+
 def _lznt1_tokens(chunk_image):
     """(position, length, offset) of every token of ONE compressed LZNT1 chunk image (lznt1_decompress.cpp:37-121); offset 0 = literal"""
     hdr = chunk_image[0] | (chunk_image[1] << 8)
