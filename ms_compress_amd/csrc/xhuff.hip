@@ -319,7 +319,7 @@ struct HuffLdsFast {
 // The DS instructions of a wave execute in program order, so "read t, overwrite its slot, read the children" needs no wait in
 // between -- only the compiler has to keep the order (HH_ORDER: no instruction, a scheduling fence).
 // (One lane replaying the heap level by level: 3.1 ms for the 3 239 chunks of the bench corpus; this: 1.4 ms, bound by
-// instruction issue -- 13 single-purpose waves per CU, ~200 instructions per merge step.)
+// instruction issue -- 13 single-purpose waves per CU at the time, 24 now, ~200 instructions per merge step.)
 #define HH_SENT 0xFFFFFFFFu
 #define HH_ORDER() asm volatile("" ::: "memory")
 template <class H> __device__ __forceinline__ void hh_push(H& h, uint32_t hl_new, uint2 e, uint32_t lane)     // hl_new = slot of the new entry (heap length after the push)
