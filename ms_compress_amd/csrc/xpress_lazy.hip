@@ -18,9 +18,10 @@
 //   * a walk that leaves the tile is parked in a small list in LDS and goes on when the next tile is staged;
 //   * the ONE-lazy-Fill-per-token rule (xpress_compress.cpp:269) makes up to 7 positions behind a match longer than 8 KiB forced
 //     literals and resumes the parse behind them: the 8 possible resume points behind every such match are parked as walks too.
-// Every lane is its own state machine -- NEW (claim, own 16 bytes, first link) -> FIND (one 16-byte compare of one chain candidate per
-// step) -> DONE (store, extend a capped match, next position) -- and the wave runs the three blocks once per step, so lanes on short
-// chains do not wait for lanes on long ones (the all-positions walk ran at 0.45 lane occupancy).
+// Every lane is its own state machine -- NEW (claim, own 16 bytes, first link) -> FIND (16-byte compares of chain candidates, up to
+// XZ_FREP per step; the next candidate's bytes and link are asked for before the current one is compared) -> DONE (store, extend a capped
+// match, next position) -- and the wave runs the blocks once per step, so lanes on short chains do not wait for lanes on long ones
+// (the all-positions walk ran at 0.45 lane occupancy).
 // What is stored for a position is what xp_find_kernel stores (length capped at 48, offset); offsets of unvisited positions are 0.
 #include "common.h"
 #include "kernels.h"
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 			const uint32_t sweep_end = (tb + tid * SEG + SEG < te) ? tb + tid * SEG + SEG : te;
 
 			// ---- the state machine. One step = FIND (a compare), then DONE (store / extend / next position), then NEW (claim + start).
-			// The candidate's 16 bytes and its link are fetched at the END of a step (`cand`, `nlk`), so that the LDS round trip
+			// A walk's FIRST candidate (16 bytes and link) is fetched at the END of the step that claimed it (`cand`, `nlk`), so that the LDS round trip
 			// overlaps the other blocks of the next step.
 			uint32_t st = XZ_IDLE, p = 0, q = 0, best = 0, x = 0, dl = 0, cap = 0, lim = 0, chain = 0, elen = 0, nlk = 0;
 			uint4 own = make_uint4(0, 0, 0, 0), cand = make_uint4(0, 0, 0, 0);
