@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 REPLICAS = 16                # BASELINE.json configs[4]
-PROFILE_TAG = "r03"              # the committed profiles the PMC / SQ figures are looked up in; a missing file falls back to r02 and says so
+PROFILE_TAG = "r04"              # the committed profiles the PMC / SQ figures are looked up in; a missing file falls back to r03 and says so
 # the kernel SYMBOL behind the library's timer name of each codec's dominant kernel (template instance included, so that the
 # PMC figures of the Xpress and the Xpress+Huffman match finder are never mixed up)
 SYMBOLS = {
@@ -165,20 +165,61 @@ class Job:
 GOLD_KEY = {2: "lznt1", 3: "xpress_units64k", 4: "xpress_huff"}
 
 
+def _host_reference_digests(fmt, cor):
+    """(length, sha256) of what the reference's CPU encoder (oracle/_ref; our C restatement when that file did not travel) writes for each of
+    the 12 files as this job cuts them -- one ms_compress call per file, for Xpress one per 64 KiB unit with the streams concatenated. Used by
+    the parity gate when the data is NOT the synthetic corpus (no committed digests exist for it). Host threads, outside the timed region."""
+    import hashlib
+    from oracle import loader
+    ref = loader.load_ref()
+    fn = ref.ms_compress if ref is not None else None
+    blob = cor.blob()
+    if fmt == 3:
+        offs, lens = [], []
+        for o, l in zip(cor.foff, cor.flen):
+            st = np.arange(0, int(l), 65536, dtype=np.uint64)
+            offs.append(st + o); lens.append(np.minimum(65536, int(l) - st).astype(np.uint64))
+        uoff, ulen = np.concatenate(offs), np.concatenate(lens)
+    else:
+        uoff, ulen = cor.foff, cor.flen
+    caps = np.array([loader.load_oracle().orc_max_compressed_size(fmt, int(x)) + 2 for x in ulen], np.uint64)
+    order = np.argsort(-ulen.astype(np.int64), kind="stable")                      # longest first: the makespan is the largest file's
+    _, st, ln, out, ooff = loader.time_units_ex(fn, fmt, blob, uoff[order], ulen[order], caps[order], max(1, min(os.cpu_count() or 1, 256)), 1, keep_output=True)
+    assert bool((st == 0).all()), "the host reference reported an error status"
+    where = np.empty(len(order), np.int64); where[order] = np.arange(len(order))
+    res, u = [], 0
+    for l in cor.flen:
+        k = 1 if fmt != 3 else (int(l) + 65535) // 65536
+        h, total = hashlib.sha256(), 0
+        for i in range(u, u + k):
+            j = int(where[i]); a = int(ooff[j]); n = int(ln[j])
+            h.update(out[a:a + n].tobytes()); total += n
+        res.append((total, h.hexdigest())); u += k
+    return res
+
+
+_HOST_DIGESTS = {}
+
+
 def parity_gate(m, job, fmt, cor, first_unit):
     """The in-run parity gate: SHA-256 of what this rank's FIRST replica of the 12 files compressed to, file by file, against
-    the digests the real reference gave for them (tests/golden/corpus_full.json, written by tools/make_golden_full.py from oracle/_ref).
-    Outside the timed region. True / False, or None when the data is not the synthetic corpus or the shard does not start at a replica."""
+    the reference's. Synthetic corpus: the digests the real reference gave (tests/golden/corpus_full.json, written by tools/make_golden_full.py
+    from oracle/_ref). Any other data (SILESIA_DIR): the reference's encoder is run on the host, here, on the same files (oracle/_ref travels
+    with the repository). Outside the timed region. True / False, or None when the shard does not start at a replica."""
     import hashlib
     import torch
     from ms_compress_amd import corpus
-    if corpus.source() != "synthetic":
-        return None
     per_file = [1 if fmt != 3 else (int(l) + 65535) // 65536 for l in cor.flen]
     nu = sum(per_file)
     if first_unit % nu != 0 or job.n < nu:
         return None
-    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "corpus_full.json")))
+    if corpus.source() == "synthetic":
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "corpus_full.json")))
+        want = [(gold[name][GOLD_KEY[fmt]]["len"], gold[name][GOLD_KEY[fmt]]["sha256"]) for name in corpus.NAMES]
+    else:
+        if fmt not in _HOST_DIGESTS:
+            _HOST_DIGESTS[fmt] = _host_reference_digests(fmt, cor)
+        want = _HOST_DIGESTS[fmt]
     d_packed, d_poff = m.compact_batch(job.ctx, job.out_off[:nu], job.caps[:nu], job.d_out, job.d_len)
     torch.cuda.synchronize()
     poff = d_poff.cpu().numpy()
@@ -186,8 +227,7 @@ def parity_gate(m, job, fmt, cor, first_unit):
     u, ok = 0, True
     for i, name in enumerate(corpus.NAMES):
         a, b = int(poff[u]), int(poff[u + per_file[i]])
-        g = gold[name][GOLD_KEY[fmt]]
-        ok = ok and (b - a == g["len"]) and hashlib.sha256(first[a:b].tobytes()).hexdigest() == g["sha256"]
+        ok = ok and (b - a == want[i][0]) and hashlib.sha256(first[a:b].tobytes()).hexdigest() == want[i][1]
         u += per_file[i]
     return bool(ok)
 
@@ -214,7 +254,7 @@ def timed(job, steps, warmup, sharding):
 # ---------------------------------------------------------------- roofline ----------------------------------------------------------------
 def _profile_doc(name):
     """(document, tag it came from): the current round's committed profile, else the round before's (and the line says which)"""
-    for tag in (PROFILE_TAG, "r02"):
+    for tag in (PROFILE_TAG, "r03"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, name)))), tag
         except Exception:
@@ -224,7 +264,7 @@ def _profile_doc(name):
 
 def pmc_traffic(fmt, timer_name, workload_key):
     """HBM bytes per launch of the kernel behind `timer_name` for this codec, from the committed PMC passes
-    (profiles/r02_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench command, FETCH_SIZE
+    (profiles/<tag>_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same bench command, FETCH_SIZE
     doubled per the gfx950 note of the microarch guide). Collected offline -- a live run cannot read PMCs -- and keyed by the exact
     kernel symbol (template arguments included) AND the workload, so it is attached only to the launch it was measured on."""
     doc, tag = _profile_doc("pmc_traffic")
@@ -237,17 +277,18 @@ def pmc_traffic(fmt, timer_name, workload_key):
 
 def secondary_bound(fmt, timer_name, workload_key):
     """What actually limits the kernel (the HBM fraction of these latency / issue-bound integer kernels says little): busiest
-    pipe and wait shares from the committed SQ-counter passes (profiles/r02_sq_counters.json)."""
+    pipe and wait shares from the committed SQ-counter passes (profiles/<tag>_sq_counters.json)."""
     doc, tag = _profile_doc("sq_counters")
     sym = SYMBOLS.get((fmt, timer_name))
     if not doc or not sym:
         return None
-    rec = doc.get("workloads", {}).get("single_gpu", {}).get(sym)       # (SQ counters are collected on the single-GPU legs: shares, not totals)
-    if not (rec and rec.get("codec") == CODEC_OF[fmt]):
-        return None
-    out = dict(rec["derived"])
-    out["from"] = "profiles/%s_sq_counters.json, workload single_gpu%s" % (tag, "" if workload_key == "single_gpu" else " (NOT this workload: shares of wave time carry over, totals do not)")
-    return out
+    for wl in (workload_key, "single_gpu"):          # this workload's own counters when they were collected, else the single-GPU leg's (shares carry over, totals do not)
+        rec = doc.get("workloads", {}).get(wl, {}).get(sym)
+        if rec and rec.get("codec") == CODEC_OF[fmt]:
+            out = dict(rec["derived"])
+            out["from"] = "profiles/%s_sq_counters.json, workload %s%s" % (tag, wl, "" if wl == workload_key else " (NOT this workload: shares of wave time carry over, totals do not)")
+            return out
+    return None
 
 
 def roofline(fmt, prof, in_bytes, out_bytes, steps, workload_key):
@@ -297,31 +338,54 @@ def _malloc_tuning():
         return "glibc defaults (mallopt not available)"
 
 
-def cpu_baseline(fmt, blob, budget_s=10.0):
-    """The reference's own CPU encoder (oracle/_ref, compiled from /root/reference) -- or our C port when that file did not
-    travel -- on this host's cores, over a bounded sample of the SAME workload (prefix of the batch, cut on 64 KiB-aligned
-    boundaries into one slice per thread, so that every thread does one independent ms_compress call per pass), and on ONE thread
-    over the first slice. Reported baseline, not the target."""
+def cpu_baseline(fmt, cor, budget_s=10.0, sa_dict=False):
+    """The reference's own CPU encoder (oracle/_ref, compiled from /root/reference) -- or our C port when that file did not travel -- on
+    this host's cores over THE LEG'S OWN UNIT LIST (SURVEY.md 8d "exactly the same unit list"), bounded: Xpress = the independent 64 KiB
+    units of the first replica (3 239 ms_compress calls per pass, handed to the threads one at a time); LZNT1 / Xpress+Huffman = whole files,
+    one ms_compress call each, as many replicas of the 12 files as there are threads to take them (at most the job's 16), longest first --
+    with whole files as units the pass lasts as long as the largest file on one core, whatever the core count. And on ONE thread over the
+    first unit(s). sa_dict: LZNT1 by the reference compiled with MSCOMP_WITH_LZNT1_SA_DICT (oracle/_ref/libMSCompression_sa.so) over the
+    12 files. Reported baseline, not the target."""
     from oracle import loader
-    ref = loader.load_ref()
+    ref = (loader.load_ref_sa() if sa_dict else loader.load_ref())
+    if sa_dict and ref is None:
+        return None
     kind = "reference" if ref is not None else "port"
     host_cores = os.cpu_count() or 1
-    threads = max(1, min(host_cores, 256))            # (oracle/mscomp_oracle.c orc_time_units: at most 256 threads)
+    threads = max(1, min(host_cores, 256))            # (oracle/mscomp_oracle.c orc_time_units*: at most 256 threads)
     malloc = _malloc_tuning()
-    per = 4 << 20                                  # 4 MiB per thread: ~0.1-0.15 s of single-core work per pass
-    piece = max(65536, min(per, len(blob) // threads) // 65536 * 65536)
-    sample = piece * threads
-    data = blob[:sample].tobytes()
-    slices = [data[o:o + piece] for o in range(0, sample, piece)]
-    assert len(slices) == threads
-    caps = [loader.load_oracle().orc_max_compressed_size(fmt, len(x)) + 2 for x in slices]
+    blob = cor.blob()
+    if fmt == 3:
+        offs, lens = [], []
+        for o, l in zip(cor.foff, cor.flen):
+            st = np.arange(0, int(l), 65536, dtype=np.uint64)
+            offs.append(st + o); lens.append(np.minimum(65536, int(l) - st).astype(np.uint64))
+        uoff, ulen = np.concatenate(offs), np.concatenate(lens)
+        what = "the %d independent 64 KiB units of the first replica (configs[2]'s unit list), one ms_compress call each" % len(ulen)
+    else:
+        reps = 1 if sa_dict else max(1, min(REPLICAS, threads // 12))
+        uoff, ulen = np.tile(cor.foff, reps), np.tile(cor.flen, reps)
+        order = np.argsort(-ulen.astype(np.int64), kind="stable")
+        uoff, ulen = uoff[order], ulen[order]
+        what = "%d replica(s) of the 12 files = %d whole-file units of the job, one ms_compress call each, longest first" % (reps, len(ulen))
+    caps = np.array([loader.load_oracle().orc_max_compressed_size(fmt, int(x)) + 2 for x in ulen], np.uint64)
     fn = ref.ms_compress if ref is not None else None
-    passes, dt = _cpu_timed(fn, fmt, slices, caps, threads, budget_s)
-    p1, dt1 = _cpu_timed(fn, fmt, slices[:1], caps[:1], 1, min(2.0, budget_s / 4))
-    return {"value": round(sample * passes / dt / 1e6, 1), "unit": "MB/s", "cores": threads, "host_cores": host_cores, "kind": kind,
-            "single_thread": {"value": round(piece * p1 / dt1 / 1e6, 1), "unit": "MB/s", "sample": "%d passes over the first %d B, one thread" % (p1, piece)},
+    nthr = min(threads, len(ulen))
+    dt1, st, _ = loader.time_units_ex(fn, fmt, blob, uoff, ulen, caps, nthr, 1)
+    assert bool((st == 0).all()), "the CPU baseline reported an error status"
+    more = max(0, min(19, int(budget_s / 4 / max(dt1, 1e-3)) - 1))
+    dt = dt1 + (loader.time_units_ex(fn, fmt, blob, uoff, ulen, caps, nthr, more)[0] if more else 0.0)
+    passes, sample = 1 + more, int(ulen.sum())
+    k1 = 1 if fmt != 3 else min(64, len(ulen))         # single thread: the first file (its first 64 units for Xpress)
+    s1 = int(ulen[:k1].sum())
+    d1, st1, _ = loader.time_units_ex(fn, fmt, blob, uoff[:k1], ulen[:k1], caps[:k1], 1, 1)
+    p1 = 1 + max(0, min(9, int(min(2.0, budget_s / 4) / max(d1, 1e-3)) - 1))
+    if p1 > 1:
+        d1 += loader.time_units_ex(fn, fmt, blob, uoff[:k1], ulen[:k1], caps[:k1], 1, p1 - 1)[0]
+    return {"value": round(sample * passes / dt / 1e6, 1), "unit": "MB/s", "cores": nthr, "host_cores": host_cores, "kind": kind,
+            "single_thread": {"value": round(s1 * p1 / d1 / 1e6, 1), "unit": "MB/s", "sample": "%d pass(es) over the first %d unit(s), %d B, one thread" % (p1, k1, s1)},
             "malloc": malloc,
-            "sample": "%d passes over the first %d B of the batch, %d threads x %d B: one independent ms_compress call per thread and pass" % (passes, sample, threads, piece)}
+            "sample": "%d pass(es) over %s: %d B per pass on %d threads" % (passes, what, sample, nthr)}
 
 
 def cpu_decompress_baseline(fmt, blob, budget_s=3.0, whole=None):
@@ -436,6 +500,7 @@ def main():
     ap.add_argument("--codec", default="lznt1", choices=["lznt1", "xpress", "xpress_huff"], help="headline codec")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-extra", action="store_true", help="headline leg only")
+    ap.add_argument("--config5-only", action="store_true", help="the three codecs over BASELINE configs[4], none of the other legs")
     ap.add_argument("--oversubscribe", action="store_true", help="TEST ONLY: let the N ranks share the visible GPUs (gloo for the timing reduction); "
                     "exercises the sharded multi-rank path on a 1-GPU box, the line is marked and is not an N-GPU measurement")
     args = ap.parse_args()
@@ -477,7 +542,7 @@ def main():
     if args.oversubscribe:
         res["oversubscribed"] = "TEST RUN: %d ranks shared %d GPU(s); not an %d-GPU measurement" % (world, torch.cuda.device_count(), world)
     if rank == 0 and world == 1 and not args.no_cpu:
-        res["cpu_baseline"] = cpu_baseline(fmt, cor.blob())
+        res["cpu_baseline"] = cpu_baseline(fmt, cor)
     extra = {}
     if not args.no_extra:
         c5 = {}
@@ -486,22 +551,23 @@ def main():
                 c5[codec] = sharded_leg(m, ctx, cor, m.FORMATS[codec], rank, world, steps2, 1, sharding, rdev)
                 res["parity_checked"][codec] = c5[codec]["parity_checked"]
                 if rank == 0 and world == 1 and not args.no_cpu:
-                    c5[codec]["cpu_baseline"] = cpu_baseline(m.FORMATS[codec], cor.blob())
+                    c5[codec]["cpu_baseline"] = cpu_baseline(m.FORMATS[codec], cor)
         extra["config5"] = c5
-    if world == 1 and not args.no_extra:
+    if world == 1 and not args.no_extra and not args.config5_only:
         single = {}
-        for codec, wl in (("lznt1", "mozilla"), ("xpress", "silesia_units64k"), ("xpress_huff", "silesia_files")):
+        for key, wl in (("lznt1", "mozilla"), ("xpress", "silesia_units64k"), ("xpress_huff", "silesia_files"), ("xpress_huff_unit_mode", "silesia_units64k")):
+            codec = "xpress_huff" if key.startswith("xpress_huff") else key      # Xpress+Huffman in file mode AND in unit mode (every 64 KiB unit independent, each with EOS)
             f2 = m.FORMATS[codec]
             b2, o2, l2, d2 = single_gpu_workload(cor, wl)
             j2 = Job(m, ctx, f2, b2, o2, l2)
             n2 = args.steps if codec == "lznt1" else steps2
             t2, p2 = timed(j2, n2, 3 if codec == "lznt1" else 1, sharding)
             ob = j2.out_bytes()
-            single[codec] = {"MB_per_s": round(j2.in_bytes * n2 / t2 / 1e6, 1), "ms_per_step": round(t2 / n2 * 1e3, 4), "steps": n2,
+            single[key] = {"MB_per_s": round(j2.in_bytes * n2 / t2 / 1e6, 1), "ms_per_step": round(t2 / n2 * 1e3, 4), "steps": n2,
                              "workload": d2, "compression_ratio": round(ob / j2.in_bytes, 4), "roofline": roofline(f2, p2, j2.in_bytes, ob, n2, "single_gpu")}
             j2.close()
-            single[codec]["end_to_end"] = end_to_end_leg(m, f2, b2, o2, l2, d2)
-            assert single[codec]["end_to_end"]["out_bytes"] == ob, "the host-pointer path and the HBM-resident path disagree on the output size"
+            single[key]["end_to_end"] = end_to_end_leg(m, f2, b2, o2, l2, d2)
+            assert single[key]["end_to_end"]["out_bytes"] == ob, "the host-pointer path and the HBM-resident path disagree on the output size"
         extra["single_gpu"] = single
         # What ONE rank of an 8-GPU run of this job holds (2 of the 16 replicas, 423 877 160 B): its rate against an eighth of the
         # one-GPU rate is the strong-scaling efficiency the partition itself allows at N = 8 (no exchange step exists; what is lost is the
@@ -529,6 +595,8 @@ def main():
                                       "compression_ratio": round(j2.out_bytes() / j2.in_bytes, 4),
                                       "kernels_ms_per_step": {k: round(v[0] / steps2, 4) for k, v in p2.items()}}
             j2.close()
+            if not args.no_cpu:
+                extra["lznt1_sa_dict"]["cpu_baseline"] = cpu_baseline(m.FORMATS["lznt1"], cor, sa_dict=True)
         finally:
             ctx.lib.mscomp_amd_set_lznt1_sa_dict(0)
         dec = {}
@@ -548,6 +616,19 @@ def main():
             if not args.no_cpu:
                 decf[codec]["cpu_baseline"] = cpu_decompress_baseline(f2, b2, whole=list(zip(o2, l2)))
         extra["decompress_files"] = decf
+    # all three codecs of the metric in the part of the line the driver keeps (flat scalars under `config`): MB/s, ms per step, roofline
+    # fraction of the codec's dominant kernel and the parity gate's verdict, BASELINE configs[4] on this many GPUs
+    legs = {args.codec: head}
+    legs.update(extra.get("config5", {}))
+    for codec, leg in legs.items():
+        res["config"]["%s_MB_per_s" % codec] = leg["MB_per_s"]
+        res["config"]["%s_ms_per_step" % codec] = leg["ms_per_step"]
+        res["config"]["%s_roofline_frac" % codec] = (leg["roofline"] or {}).get("frac")
+        res["config"]["%s_hbm_read_frac" % codec] = (leg["roofline"] or {}).get("hbm_read_frac")
+        res["config"]["%s_parity_checked" % codec] = leg["parity_checked"]
+    if extra.get("one_rank_of_8"):
+        for codec, r in extra["one_rank_of_8"].items():
+            res["config"]["%s_one_rank_of_8_rate_vs_whole_job" % codec] = r["rate_vs_whole_job_on_one_gpu"]
     if extra:
         res["extra"] = extra
     if rank == 0:

@@ -61,7 +61,7 @@ size_t       xpress_huff_max_compressed_size(size_t in_len);
 /* Decompressors. Same contract as the reference: *out_len holds the capacity on entry and the number of
  * bytes produced on MSCOMP_OK; MSCOMP_BUF_ERROR when the output (or what is left of the input) does not fit,
  * MSCOMP_DATA_ERROR for a malformed stream.
- *   ms_decompress      include/mscomp.h:79,   src/mscomp.cpp:119-134               -> ms_decompress
+ *   ms_decompress      include/mscomp.h:88,   src/mscomp.cpp:119-134               -> ms_decompress
  *   lznt1_decompress   include/lznt1.h:51,    src/lznt1_decompress.cpp:293 (the inflate wrapper, internal.h:616-630) -> lznt1_decompress
  *   xpress_decompress  include/xpress.h:50,   src/xpress_decompress.cpp:405                -> xpress_decompress
  *   xpress_huff_decompress include/xpress_huff.h:49, src/xpress_huff_decompress.cpp:130      -> xpress_huff_decompress */
@@ -162,7 +162,7 @@ MSCompStatus mscomp_amd_plan_execute(mscomp_amd_plan* plan, const uint8_t* d_in,
 MSCompStatus mscomp_amd_compress_units_host(MSCompFormat format, int n_dev, const int* devices, size_t n_units,
                                             const uint8_t* const* in_ptrs, const size_t* in_lens, uint8_t* const* out_ptrs, const size_t* out_caps,
                                             size_t* out_lens, MSCompStatus* statuses);
-/* The same for the decoders: unit i is one ms_decompress call (mscomp.h:79) with *out_len = out_caps[i] on entry; statuses[i] =
+/* The same for the decoders: unit i is one ms_decompress call (mscomp.h:88) with *out_len = out_caps[i] on entry; statuses[i] =
  * MSCOMP_OK / MSCOMP_BUF_ERROR / MSCOMP_DATA_ERROR exactly as the reference's one-shot decoder returns them. */
 MSCompStatus mscomp_amd_decompress_units_host(MSCompFormat format, int n_dev, const int* devices, size_t n_units,
                                               const uint8_t* const* in_ptrs, const size_t* in_lens, uint8_t* const* out_ptrs, const size_t* out_caps,

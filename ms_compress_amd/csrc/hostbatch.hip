@@ -196,7 +196,8 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 		rs = mscomp_amd_plan_execute(b.plan, d_in, static_cast<uint8_t*>(w->d_out[slot]), d_len, d_st);
 		if (rs != MSCOMP_OK) { break; }
 		if (hipMemcpyAsync(w->h_meta[slot], d_len, n * 12, hipMemcpyDeviceToHost, w->ex) != hipSuccess || hipEventRecord(w->ev_ex[slot], w->ex) != hipSuccess) { rs = MSCOMP_ERRNO; break; }
-		if (hipStreamWaitEvent(w->dn, w->ev_ex[slot], 0) != hipSuccess) { rs = MSCOMP_ERRNO; break; }
+		// (no stream wait of `dn` on ev_ex here: finish(k) waits for that event on the HOST before it queues batch k's copies, and a wait queued now
+		//  would put batch k - 1's downloads behind batch k's kernels)
 		if (k >= 1) { rs = finish(k - 1); }
 	}
 	if (rs == MSCOMP_OK && nb) { rs = finish(nb - 1); }

@@ -380,11 +380,16 @@ MSCompStatus xpress_deflate_end(mscomp_stream* s)
 // The Xpress streaming DECOMPRESSOR (include/xpress.h:56-58, xpress_decompress.cpp:45-403) is not offloaded: one Xpress stream is a
 // serial chain of tokens and the streaming calls hand it over a few bytes at a time -- nothing for a GPU. The three symbols exist so
 // that a program naming them links against the drop-in; the init call answers MSCOMP_MEM_ERROR (the status the reference's own
-// unfinished streaming entry point uses, xpress_compress.cpp:72) and leaves the stream untouched, so a caller falls into its error
+// unfinished streaming entry point uses, xpress_compress.cpp:72), writes the reason into stream->error and otherwise leaves the stream untouched, so a caller falls into its error
 // path at once instead of decoding nothing. A caller that needs streaming Xpress decompression keeps the reference's
 // src/xpress_decompress.cpp in its link and builds this library with -DMSCOMP_AMD_NO_XPRESS_INFLATE.
 #ifndef MSCOMP_AMD_NO_XPRESS_INFLATE
-MSCompStatus xpress_inflate_init(mscomp_stream*) { return MSCOMP_MEM_ERROR; }
+MSCompStatus xpress_inflate_init(mscomp_stream* s)
+{
+	// say why in the stream's own message field (general.h:95: `char error[256]`), so that the caller's log names the cause
+	if (s) { snprintf(s->error, sizeof s->error, "libmscomp_amd: streaming Xpress decompression is not offloaded; use xpress_decompress / ms_decompress (one-shot), or link the reference's xpress_decompress.cpp and build with -DMSCOMP_AMD_NO_XPRESS_INFLATE"); }
+	return MSCOMP_MEM_ERROR;
+}
 MSCompStatus xpress_inflate(mscomp_stream*) { return MSCOMP_ARG_ERROR; }
 MSCompStatus xpress_inflate_end(mscomp_stream*) { return MSCOMP_ARG_ERROR; }
 #endif

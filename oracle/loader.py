@@ -54,6 +54,9 @@ def load_oracle():
         lib.orc_compress_units.restype = C.c_int
         lib.orc_time_units.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         lib.orc_time_units.restype = C.c_double
+        lib.orc_time_units_ex.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        lib.orc_time_units_ex.restype = C.c_double
         _oracle = lib
     return _oracle
 
@@ -152,6 +155,22 @@ def time_units(fn, fmt, units, caps, threads, passes):
     dt = lib.orc_time_units(fp, fmt, blob.ctypes.data, in_off.ctypes.data, len(units), out.ctypes.data, out_off.ctypes.data,
                             out_len.ctypes.data, status.ctypes.data, threads, passes)
     return dt, status, out_len
+
+
+def time_units_ex(fn, fmt, blob, in_off, in_len, caps, threads, passes, keep_output=False):
+    """time_units for units given as (offset, length) into ONE numpy uint8 array (units may alias: replicas of the same files cost no
+    memory on the input side), handed to the threads one at a time in the order given. Returns (seconds, statuses, lengths[, out, out_off])."""
+    import numpy as np
+    lib = load_oracle()
+    in_off = np.ascontiguousarray(in_off, dtype=np.uint64); in_len = np.ascontiguousarray(in_len, dtype=np.uint64)
+    caps = np.ascontiguousarray(caps, dtype=np.uint64)
+    out_off = np.zeros(len(caps), dtype=np.uint64); out_off[1:] = np.cumsum(caps[:-1] + np.uint64(64))
+    out = np.empty(int(out_off[-1] + caps[-1]) + 64 if len(caps) else 64, dtype=np.uint8)
+    out_len = np.zeros(len(caps), dtype=np.uint64); status = np.zeros(len(caps), dtype=np.int32)
+    fp = C.cast(fn, C.c_void_p) if fn is not None else None
+    dt = lib.orc_time_units_ex(fp, fmt, blob.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, len(caps), out.ctypes.data, out_off.ctypes.data,
+                               caps.ctypes.data, out_len.ctypes.data, status.ctypes.data, threads, passes)
+    return (dt, status, out_len, out, out_off) if keep_output else (dt, status, out_len)
 
 
 def ref_compress(fmt, data, cap=None):

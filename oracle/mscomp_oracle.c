@@ -892,6 +892,43 @@ double orc_time_units(void* fn, int format, const uint8_t* in, const uint64_t* i
 	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
+/* The same with explicit unit lengths and one unit per grab: units may alias each other in `in` (the replicas of bench.py's
+ * job are the same 12 files) and are handed out one at a time in the order given (bench.py passes whole files longest first). */
+typedef struct { int format; const uint8_t* in; const uint64_t* in_off; const uint64_t* in_len; size_t n_units; uint8_t* out; const uint64_t* out_off;
+                 const uint64_t* out_cap; uint64_t* out_len; int32_t* status; size_t next; pthread_mutex_t mu; one_shot_fn fn; } ex_job;
+static void* ex_worker(void* arg)
+{
+	ex_job* j = (ex_job*)arg;
+	for (;;) {
+		pthread_mutex_lock(&j->mu);
+		const size_t i = j->next++;
+		pthread_mutex_unlock(&j->mu);
+		if (i >= j->n_units) { return NULL; }
+		size_t ol = (size_t)j->out_cap[i];
+		const int st = j->fn(j->format, j->in + j->in_off[i], (size_t)j->in_len[i], j->out + j->out_off[i], &ol);
+		j->status[i] = st; j->out_len[i] = st == ORC_OK ? ol : 0;
+	}
+}
+double orc_time_units_ex(void* fn, int format, const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, size_t n_units,
+                         uint8_t* out, const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status, int threads, int passes)
+{
+	struct timespec t0, t1;
+	if (threads < 1) { threads = 1; }
+	if (threads > 256) { threads = 256; }
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	for (int p = 0; p < passes; ++p) {
+		ex_job f = { format, in, in_off, in_len, n_units, out, out_off, out_cap, out_len, status, 0, PTHREAD_MUTEX_INITIALIZER, fn ? (one_shot_fn)fn : (one_shot_fn)orc_compress };
+		pthread_t th[256]; pthread_attr_t at; int started = threads;
+		pthread_attr_init(&at); pthread_attr_setstacksize(&at, 8u << 20);
+		for (int t = 1; t < threads; ++t) { if (pthread_create(&th[t], &at, ex_worker, &f)) { started = t; break; } }
+		ex_worker(&f);
+		for (int t = 1; t < started; ++t) { pthread_join(th[t], NULL); }
+		pthread_attr_destroy(&at);
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
 /* research helper (chunk-parallel Xpress-Huffman decoding): where do the chunks of a stream start? Decodes the stream
  * (cap bytes of room) and records the input offset of every chunk's table; returns the number of chunks or a negative status. */
 long orc_xh_chunk_starts(const uint8_t* in, size_t n, size_t cap, uint64_t* starts, size_t max_starts)

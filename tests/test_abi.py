@@ -162,6 +162,29 @@ def test_xpress_deflate_entry_points_answer_like_the_reference():
         assert ours == answers(ref)
 
 
+def test_xpress_inflate_stub_says_why():
+    """The streaming Xpress DEcompressor is not offloaded: the init call answers MSCOMP_MEM_ERROR, names the reason in
+    stream->error and leaves the rest of the stream untouched -- directly and through ms_inflate_init. No GPU needed."""
+    import ctypes as C
+    import ms_compress_amd as m
+
+    class Stream(C.Structure):
+        _fields_ = [("format", C.c_int), ("compressing", C.c_bool), ("in_", C.c_void_p), ("in_avail", C.c_size_t), ("in_total", C.c_size_t),
+                    ("out", C.c_void_p), ("out_avail", C.c_size_t), ("out_total", C.c_size_t), ("error", C.c_char * 256),
+                    ("warning", C.c_char * 256), ("state", C.c_void_p)]
+    lib = m.load_library()
+    if not hasattr(lib, "xpress_inflate_init"):
+        pytest.skip("built with -DMSCOMP_AMD_NO_XPRESS_INFLATE")
+    lib.xpress_inflate_init.argtypes = [C.c_void_p]
+    lib.ms_inflate_init.argtypes = [C.c_int, C.c_void_p]
+    for call in (lambda s: lib.xpress_inflate_init(C.byref(s)), lambda s: lib.ms_inflate_init(3, C.byref(s))):
+        s = Stream()
+        s.in_avail, s.state = 77, 0x1000
+        assert call(s) == m.MSCOMP_MEM_ERROR
+        assert b"not offloaded" in s.error and s.in_avail == 77 and s.state == 0x1000 and s.format == 0
+    assert lib.xpress_inflate_init(None) == m.MSCOMP_MEM_ERROR
+
+
 def test_every_c_symbol_of_the_reference_is_exported():
     """A program linked against libMSCompression must link against the drop-in: every C-linkage function the compiled reference exports
     (include/mscomp.h, lznt1.h, xpress.h, xpress_huff.h) is exported by libmscomp_amd.so as well (C++-mangled internals aside)."""

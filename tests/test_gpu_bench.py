@@ -1,0 +1,64 @@
+"""bench.py end to end on the GPU box: the multi-rank path (two ranks sharing the one GPU: SURVEY.md 8e) and the parity gate on data
+that is NOT the synthetic corpus (SILESIA_DIR: the reference's encoder is run on the host, BASELINE.json north_star "full Silesia corpus")."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _bench(args, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_share_the_gpu():
+    """python bench.py --gpus 2 --oversubscribe: the sharded multi-rank path end to end (self-spawned ranks, gloo timing reduction,
+    every rank's shard through the parity gate). One line, marked as a test run."""
+    line = _bench(["--gpus", "2", "--oversubscribe", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-extra"])
+    assert line["n_gpus"] == 2 and "oversubscribed" in line and line["scaling"] == "strong"
+    assert line["parity_checked"] == {"lznt1": True}
+    assert line["config"]["bytes_per_step"] == 3391017280 and line["config"]["bytes_rank0"] * 2 == 3391017280
+    assert line["config"]["lznt1_parity_checked"] is True and line["value"] > 0
+
+
+def test_three_ranks_all_codecs():
+    """three ranks (an uneven split of the 192 / 51 824 units), all three codecs: only rank 0's shard starts at a replica, the job totals must still add up"""
+    line = _bench(["--gpus", "3", "--oversubscribe", "--steps", "1", "--warmup", "0", "--no-cpu", "--config5-only"])
+    assert line["n_gpus"] == 3
+    assert line["parity_checked"] == {"lznt1": True, "xpress": True, "xpress_huff": True}
+    for codec in ("lznt1", "xpress", "xpress_huff"):
+        assert line["config"]["%s_MB_per_s" % codec] > 0 and line["config"]["%s_roofline_frac" % codec] > 0
+
+
+def test_parity_gate_on_real_data(tmp_path):
+    """Data that is not the synthetic corpus (SILESIA_DIR holds 12 files of the Silesia sizes -- here the synthetic bytes written to disk, so
+    the test needs no download): the gate must run the reference's encoder on the host instead of returning None, for all three codecs."""
+    from ms_compress_amd import corpus
+    saved = os.environ.pop("SILESIA_DIR", None)
+    try:
+        for i, name in enumerate(corpus.NAMES):
+            corpus.file_bytes(i).tofile(str(tmp_path / name))
+    finally:
+        if saved is not None:
+            os.environ["SILESIA_DIR"] = saved
+    line = _bench(["--steps", "1", "--warmup", "0", "--no-cpu", "--config5-only"], env={"SILESIA_DIR": str(tmp_path)})
+    assert line["data"].startswith("silesia:")
+    assert line["parity_checked"] == {"lznt1": True, "xpress": True, "xpress_huff": True}
+
+
+@pytest.mark.skipif(not os.environ.get("SILESIA_DIR"), reason="SILESIA_DIR not set: the real corpus is not in this image")
+def test_parity_gate_on_the_real_silesia_corpus():
+    line = _bench(["--steps", "1", "--warmup", "0", "--no-cpu", "--config5-only"])
+    assert line["data"].startswith("silesia:")
+    assert line["parity_checked"] == {"lznt1": True, "xpress": True, "xpress_huff": True}

@@ -6,7 +6,7 @@
 #  2. rocprofv3 --kernel-trace --stats of the HEADLINE command (bench.py --no-extra: every launch of the dominant kernel is the
 #     headline workload, so its average duration is comparable with the HIP-event figure of the line) and of the full default command;
 #  3. HBM traffic: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (TCC counters do not fit one pass), per leg (tools/gpu_leg.py);
-#  4. SQ counters of the single-GPU legs in two passes of 8 (issue / wait shares, instruction mix, LDS pipe, conflicts).
+#  4. SQ counters of the configs[4] legs and the single-GPU legs in two passes of 8 (issue / wait shares, instruction mix, LDS pipe, conflicts).
 set -u
 TAG=${1:-run}
 QUICK=${2:-}
@@ -25,7 +25,7 @@ for leg in $LEGS; do
 done
 SQA="SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS"
 SQB="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS"
-SLEGS="single:lznt1 single:xpress single:xpress_huff decompress:xpress decompress:xpress_huff"
+SLEGS="config5:lznt1 config5:xpress config5:xpress_huff single:lznt1 single:xpress single:xpress_huff decompress:xpress decompress:xpress_huff"
 [ -n "$QUICK" ] && SLEGS="single:lznt1"
 for leg in $SLEGS; do
   t=${leg/:/_}

@@ -72,7 +72,13 @@ for f in sorted(glob.glob(os.path.join(src, "sqa_*_counter_collection.csv"))):
              "lds_pipe_busy_frac": round(raw.get("SQ_LDS_IDX_ACTIVE", 0) / max(1, raw.get("SQ_BUSY_CU_CYCLES", 1)), 3),
              "lds_bank_conflict_share": round(raw.get("SQ_LDS_BANK_CONFLICT", 0) / idx, 3), "lds_unaligned_stall_share": round(raw.get("SQ_LDS_UNALIGNED_STALL", 0) / idx, 4),
              "lds_cycles_per_lds_instruction": round(idx / max(1, raw.get("SQ_INSTS_LDS", 1)), 2)}
-        d["bound"] = "lds-pipe" if d["lds_pipe_busy_frac"] >= 0.4 else ("issue" if d["wave_time_issue_stalled_frac"] + d["wave_time_issuing_frac"] >= 0.6 else "latency (waves parked in s_waitcnt / barriers)")
+        # share of the CU-busy cycles in which a VALU instruction was executing (SQ_ACTIVE_INST_VALU is summed over the 4 SIMDs of a CU the way
+        # SQ_BUSY_CU_CYCLES is summed over CUs: ~1.0 = the vector pipes never idle)
+        d["valu_busy_frac"] = round(raw.get("SQ_ACTIVE_INST_VALU", 0) / max(1, raw.get("SQ_BUSY_CU_CYCLES", 1)), 3)
+        d["bound"] = ("valu-issue (vector pipes busy)" if d["valu_busy_frac"] >= 0.8 else
+                      "lds-pipe" if d["lds_pipe_busy_frac"] >= 0.6 else
+                      "issue" if d["wave_time_issue_stalled_frac"] + d["wave_time_issuing_frac"] >= 0.6 else
+                      "latency (waves parked in s_waitcnt / barriers)")
         sq.setdefault(WL[kind], {})[k] = {"codec": codec, "derived": d, "per_launch": raw}
 json.dump({"how": "rocprofv3 --kernel-trace --pmc <8 SQ counters> -- python tools/gpu_leg.py single:<codec> 3, two passes (A: SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY "
                   "SQ_ACTIVE_INST_ANY/_VALU/_SCA/_LDS; B: SQ_INSTS_VALU/_SALU/_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS). "
