@@ -452,12 +452,10 @@ def end_to_end_leg(m, fmt, blob, in_off, in_len, desc, reps=3):
     the outputs capacity after capacity in another, through mscomp_amd_compress_units_host on this GPU (uploads, kernels and downloads
     of 512 MiB batches overlapped; one upload per run of adjacent units). One untimed call first (contexts, scratch, staging), then the
     median of `reps`. Never `value` (that is HBM-resident)."""
-    ins = [blob[int(o):int(o) + int(l)] for o, l in zip(in_off, in_len)]
-    caps = [m.max_compressed_size(fmt, int(l)) + 2 for l in in_len]
-    out = np.zeros(sum(caps) + 64, dtype=np.uint8)
-    outs, pos = [], 0
-    for c in caps:
-        outs.append(out[pos:pos + c]); pos += c
+    caps = np.array([m.max_compressed_size(fmt, int(l)) + 2 for l in in_len], np.uint64)
+    out = np.zeros(int(caps.sum()) + 64, dtype=np.uint8)
+    ooff = np.zeros(len(caps), np.uint64); ooff[1:] = np.cumsum(caps)[:-1]
+    ins, outs = m.HostViews(blob, in_off, in_len), m.HostViews(out, ooff, caps)       # (pointer tables built by numpy: what a C caller hands over)
     ts = []
     for r in range(reps + 1):
         t0 = time.perf_counter()

@@ -7,5 +7,5 @@ reference interface; ``corpus.py`` the synthetic Silesia-shaped bench input; ``s
 """
 from .api import (MSCOMP_NONE, MSCOMP_LZNT1, MSCOMP_XPRESS, MSCOMP_XPRESS_HUFF, MSCOMP_OK, MSCOMP_ERRNO,  # noqa: F401
                   MSCOMP_ARG_ERROR, MSCOMP_DATA_ERROR, MSCOMP_MEM_ERROR, MSCOMP_BUF_ERROR, FORMATS, CHUNK,
-                  MSCompError, load_library, max_compressed_size, compress, compress_units, compress_units_host, decompress_units_host, pack_offsets, decompress, decompress_units, compact_batch,
+                  MSCompError, load_library, max_compressed_size, compress, compress_units, compress_units_host, decompress_units_host, HostViews, pack_offsets, decompress, decompress_units, compact_batch,
                   Context, Plan)

@@ -324,20 +324,45 @@ def decompress_units_host(fmt, in_arrays, out_arrays, devices=(0,)):
     return compress_units_host(fmt, in_arrays, out_arrays, devices=devices, decompress=True)
 
 
+class HostViews:
+    """n units as views of ONE numpy uint8 array: unit i = base[off[i] : off[i] + length[i]]. The pointer table of a call is then built
+    by numpy (base address + offsets) instead of one Python attribute access per unit (milliseconds for thousands of units)."""
+
+    def __init__(self, base, off, length):
+        self.base = base
+        self.off = np.ascontiguousarray(off, dtype=np.uint64)
+        self.length = np.ascontiguousarray(length, dtype=np.uint64)
+        assert len(self.off) == len(self.length) and (len(self.off) == 0 or int((self.off + self.length).max()) <= base.size)
+
+    def __len__(self):
+        return len(self.off)
+
+    def tables(self):
+        return (self.off + np.uint64(self.base.ctypes.data)), self.length
+
+
+def _host_tables(arrays):
+    if isinstance(arrays, HostViews):
+        return arrays.tables()
+    n = len(arrays)
+    return (np.array([a.ctypes.data for a in arrays], dtype=np.uint64) if n else np.zeros(0, np.uint64),
+            np.array([a.size for a in arrays], dtype=np.uint64) if n else np.zeros(0, np.uint64))
+
+
 def compress_units_host(fmt, in_arrays, out_arrays, devices=(0,), decompress=False):
-    """mscomp_amd_compress_units_host: units given as numpy uint8 arrays (host memory, any layout), outputs written into the numpy uint8
-    arrays of out_arrays (capacity = their length), on the GPUs `devices` (a range per entry; an ordinal may repeat). Returns
-    (status of the call, out_lens uint64 array, statuses int32 array). Nothing is copied on the Python side."""
+    """mscomp_amd_compress_units_host: units given as numpy uint8 arrays (host memory, any layout) or as HostViews of one array, outputs
+    written into the numpy uint8 arrays / HostViews of out_arrays (capacity = their length), on the GPUs `devices` (a range per entry; an
+    ordinal may repeat). Returns (status of the call, out_lens uint64 array, statuses int32 array). Nothing is copied on the Python side."""
     lib = load_library()
     n = len(in_arrays)
     assert len(out_arrays) == n
-    ip = (C.c_void_p * max(1, n))(*[a.ctypes.data for a in in_arrays])
-    il = (C.c_size_t * max(1, n))(*[a.size for a in in_arrays])
-    op = (C.c_void_p * max(1, n))(*[a.ctypes.data for a in out_arrays])
-    oc = (C.c_size_t * max(1, n))(*[a.size for a in out_arrays])
+    ip, il = _host_tables(in_arrays)
+    op, oc = _host_tables(out_arrays)
+    pad = np.zeros(1, np.uint64)
+    ip, il, op, oc = [(x if n else pad) for x in (ip, il, op, oc)]
     ol = np.zeros(max(1, n), dtype=np.uint64)
     st = np.full(max(1, n), -9, dtype=np.int32)
     dv = (C.c_int * len(devices))(*[int(d) for d in devices])
     fn = lib.mscomp_amd_decompress_units_host if decompress else lib.mscomp_amd_compress_units_host
-    rc = fn(int(fmt), len(devices), dv, n, ip, il, op, oc, ol.ctypes.data, st.ctypes.data)
+    rc = fn(int(fmt), len(devices), dv, n, ip.ctypes.data, il.ctypes.data, op.ctypes.data, oc.ctypes.data, ol.ctypes.data, st.ctypes.data)
     return rc, ol[:n], st[:n]

@@ -65,6 +65,9 @@ struct mscomp_amd_ctx {
 	DevBuf xps_buf;                                    // large Xpress streams by segments: segment records | mode per stream | done per unit
 	DevBuf cp_tab;                                     // compaction: out_off (u64) | tile_prefix (u32) of the batch being packed
 	DevBuf one_in, one_out, one_meta;                  // staging of the host-pointer one-shot path
+	void* h_tab = nullptr; size_t h_tab_cap = 0;       // pinned staging of a plan's tables: they go up stream-ordered, plan_create does not wait for the stream
+	hipEvent_t h_tab_ev = nullptr; bool h_tab_busy = false;   // (a stream that shares a hardware queue with a busy one would make that wait as long as the other's kernels)
+	std::vector<DevBuf> table_pool;                    // table buffers of destroyed plans, reused by the next plan (hipFree waits for the whole device: it would stall pipelines that create a plan per batch)
 	uint64_t epoch = 1;                                // bumped when one of the buffers above moves (captured graphs are stale then)
 	bool profiling = false;
 	std::vector<ProfRec> recs;
@@ -217,6 +220,9 @@ void mscomp_amd_ctx_destroy(mscomp_amd_ctx* c)
 	for (auto& r : c->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
 	for (auto e : c->free_events) { (void)hipEventDestroy(e); }
 	for (DevBuf* b : c->bufs()) { b->release(); }
+	for (DevBuf& b : c->table_pool) { b.release(); }
+	if (c->h_tab) { (void)hipHostFree(c->h_tab); }
+	if (c->h_tab_ev) { (void)hipEventDestroy(c->h_tab_ev); }
 	delete c;
 }
 
@@ -254,8 +260,21 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 	if (!p) { return MSCOMP_MEM_ERROR; }
 	p->ctx = c; p->format = format; p->decompress = decompress; p->n_units = (uint32_t)n_units;
 
-	std::vector<uint64_t> host(n_units * 4 + (n_units + 2) / 2 + 1);
-	uint64_t* h = host.data();
+	const size_t host_words = n_units * 4 + (n_units + 2) / 2 + 1;
+	std::vector<uint64_t> host;
+	uint64_t* h = nullptr;
+	if (!decompress) {                                   // compress plans: pinned staging, no stream wait (the decompress plans below upload more tables and wait as before)
+		if (c->h_tab_busy) { (void)hipEventSynchronize(c->h_tab_ev); c->h_tab_busy = false; }   // (the previous plan's copy: long done)
+		if (c->h_tab_cap < host_words * 8) {
+			if (c->h_tab) { (void)hipHostFree(c->h_tab); c->h_tab = nullptr; c->h_tab_cap = 0; }
+			const size_t want = host_words * 8 + host_words + 4096;
+			if (hipHostMalloc(&c->h_tab, want, hipHostMallocDefault) == hipSuccess) { c->h_tab_cap = want; } else { c->h_tab = nullptr; (void)hipGetLastError(); }
+		}
+		if (c->h_tab && !c->h_tab_ev && hipEventCreateWithFlags(&c->h_tab_ev, hipEventDisableTiming) != hipSuccess) { c->h_tab_ev = nullptr; (void)hipGetLastError(); }
+		if (c->h_tab && c->h_tab_ev) { h = static_cast<uint64_t*>(c->h_tab); }
+	}
+	const bool pinned = h != nullptr;
+	if (!pinned) { host.resize(host_words); h = host.data(); }
 	uint32_t* h_cp = reinterpret_cast<uint32_t*>(h + 4 * n_units);
 	uint64_t chunks = 0, total = 0;
 	for (size_t i = 0; i < n_units; ++i) {
@@ -270,10 +289,16 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 	h_cp[n_units] = (uint32_t)chunks;
 	p->n_chunks = (uint32_t)chunks;
 	p->total_in = total;
-	const size_t bytes = host.size() * sizeof(uint64_t);
+	const size_t bytes = host_words * sizeof(uint64_t);
+	{	// the smallest pooled buffer that is large enough, else a new one
+		size_t best = c->table_pool.size();
+		for (size_t i = 0; i < c->table_pool.size(); ++i) { if (c->table_pool[i].cap >= bytes && (best == c->table_pool.size() || c->table_pool[i].cap < c->table_pool[best].cap)) { best = i; } }
+		if (best < c->table_pool.size()) { p->tables = c->table_pool[best]; c->table_pool.erase(c->table_pool.begin() + (long)best); }
+	}
 	if (!p->tables.reserve(bytes)) { delete p; return MSCOMP_MEM_ERROR; }
-	if (hipMemcpyAsync(p->tables.p, host.data(), bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-	    hipStreamSynchronize(c->stream) != hipSuccess) { p->tables.release(); delete p; return MSCOMP_ERRNO; }
+	if (hipMemcpyAsync(p->tables.p, h, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { p->tables.release(); delete p; return MSCOMP_ERRNO; }
+	if (pinned) { if (hipEventRecord(c->h_tab_ev, c->stream) != hipSuccess) { p->tables.release(); delete p; return MSCOMP_ERRNO; } c->h_tab_busy = true; }
+	else if (hipStreamSynchronize(c->stream) != hipSuccess) { p->tables.release(); delete p; return MSCOMP_ERRNO; }
 	uint64_t* d = static_cast<uint64_t*>(p->tables.p);
 	p->bt.in_off = d; p->bt.in_len = d + n_units; p->bt.out_off = d + 2 * n_units; p->bt.out_cap = d + 3 * n_units;
 	p->bt.chunk_prefix = reinterpret_cast<const uint32_t*>(d + 4 * n_units);
@@ -440,6 +465,7 @@ void mscomp_amd_plan_destroy(mscomp_amd_plan* p)
 	DeviceGuard g(p->ctx->device);
 	(void)hipStreamSynchronize(p->ctx->stream);
 	if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); }
+	if (p->tables.p && p->ctx->table_pool.size() < 8) { p->ctx->table_pool.push_back(p->tables); p->tables.p = nullptr; p->tables.cap = 0; }
 	p->tables.release(); p->tokpre.release(); p->lzg_tab.release(); p->xps_tab.release();
 	delete p;
 }

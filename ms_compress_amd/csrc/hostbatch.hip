@@ -8,41 +8,42 @@
 //
 //   * the units are cut into n_dev contiguous ranges with near-equal input bytes (the rule of ms_compress_amd/sharding.py shard_ranges;
 //     chunks and files are independent, so there is no exchange step and no collective);
-//   * one host thread per range: its own context (kept in a per-device pool between calls: the scratch stays allocated), three streams
-//     (uploads / kernels / downloads) and two sets of device buffers, so that batch k + 1 goes up and batch k - 1 comes down while batch
-//     k is in the kernels;
-//   * a batch is a run of units of at most MSCOMP_AMD_HOST_BATCH_MB (default 512) MiB of input; runs of units that lie back to back in
+//   * one host thread per range; the range runs as sub-batches of at most MSCOMP_AMD_HOST_BATCH_MB (default 32) MiB of input, up to 8 in flight,
+//     each in its own slot (context + stream + device buffers, kept in a per-device pool between calls): an uploader thread, the range's
+//     thread (plans and launches) and a downloader thread move them along, so uploads, the kernels of several sub-batches and downloads
+//     overlap (run_range below);
+//   * runs of units that lie back to back in
 //     the caller's memory travel as ONE copy each way (a file cut into 64 KiB units is one upload; outputs laid out capacity after capacity
 //     come back as one download of the range that holds streams), other units one copy each.
 #include "../../include/mscomp_amd.h"
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
 #include <mutex>
 #include <thread>
 #include <vector>
 
 namespace {
 
-struct Worker {                                           // everything one device range needs, kept between calls
-	int device = -1;
+#define HB_SLOTS 8                                        // sub-batches in flight per device range
+
+// One sub-batch in flight: its own context (stream `ex`, scratch), device buffers and pinned result words. Kept between calls.
+struct Slot {
 	mscomp_amd_ctx* ctx = nullptr;
-	hipStream_t up = nullptr, ex = nullptr, dn = nullptr;
-	hipEvent_t ev_up[2] = { nullptr, nullptr }, ev_ex[2] = { nullptr, nullptr }, ev_dn[2] = { nullptr, nullptr };
-	void* d_in[2] = { nullptr, nullptr }; void* d_out[2] = { nullptr, nullptr }; void* d_meta[2] = { nullptr, nullptr };
-	size_t in_cap[2] = { 0, 0 }, out_cap[2] = { 0, 0 }, meta_cap[2] = { 0, 0 };
-	uint64_t* h_meta[2] = { nullptr, nullptr }; size_t h_cap[2] = { 0, 0 };      // pinned: out_len (u64) x n | status (i32) x n
+	hipStream_t ex = nullptr;
+	hipEvent_t ev_ex = nullptr;
+	void* d_in = nullptr; void* d_out = nullptr; void* d_meta = nullptr;
+	size_t in_cap = 0, out_cap = 0, meta_cap = 0;
+	uint64_t* h_meta = nullptr; size_t h_cap = 0;          // pinned: out_len (u64) x n | status (i32) x n
 	bool init(int dev)
 	{
-		device = dev;
-		if (hipSetDevice(dev) != hipSuccess) { return false; }
-		if (hipStreamCreateWithFlags(&up, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ex, hipStreamNonBlocking) != hipSuccess ||
-		    hipStreamCreateWithFlags(&dn, hipStreamNonBlocking) != hipSuccess) { return false; }
-		for (int i = 0; i < 2; ++i) {
-			if (hipEventCreateWithFlags(&ev_up[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_ex[i], hipEventDisableTiming) != hipSuccess ||
-			    hipEventCreateWithFlags(&ev_dn[i], hipEventDisableTiming) != hipSuccess) { return false; }
-		}
+		if (hipStreamCreateWithFlags(&ex, hipStreamNonBlocking) != hipSuccess) { return false; }
+		if (hipEventCreateWithFlags(&ev_ex, hipEventDisableTiming) != hipSuccess) { return false; }
 		return mscomp_amd_ctx_create(dev, ex, &ctx) == MSCOMP_OK;
 	}
 	static bool grow(void** p, size_t* cap, size_t need)
@@ -53,27 +54,46 @@ struct Worker {                                           // everything one devi
 		if (hipMalloc(p, want) != hipSuccess) { *p = nullptr; (void)hipGetLastError(); return false; }
 		*cap = want; return true;
 	}
-	bool reserve(int slot, size_t in_b, size_t out_b, size_t n)
+	bool reserve(size_t in_b, size_t out_b, size_t n)
 	{
-		if (!grow(&d_in[slot], &in_cap[slot], in_b + 64) || !grow(&d_out[slot], &out_cap[slot], out_b + 64) || !grow(&d_meta[slot], &meta_cap[slot], n * 16 + 64)) { return false; }
-		if (h_cap[slot] < n) {
-			if (h_meta[slot]) { (void)hipHostFree(h_meta[slot]); h_meta[slot] = nullptr; h_cap[slot] = 0; }
+		if (!grow(&d_in, &in_cap, in_b + 64) || !grow(&d_out, &out_cap, out_b + 64) || !grow(&d_meta, &meta_cap, n * 16 + 64)) { return false; }
+		if (h_cap < n) {
+			if (h_meta) { (void)hipHostFree(h_meta); h_meta = nullptr; h_cap = 0; }
 			void* q = nullptr;
 			if (hipHostMalloc(&q, (n + n / 4 + 64) * 16, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
-			h_meta[slot] = static_cast<uint64_t*>(q); h_cap[slot] = n + n / 4 + 64;
+			h_meta = static_cast<uint64_t*>(q); h_cap = n + n / 4 + 64;
 		}
 		return true;
 	}
 	void destroy()
 	{
-		if (device >= 0) { (void)hipSetDevice(device); }
 		if (ctx) { mscomp_amd_ctx_destroy(ctx); ctx = nullptr; }
-		for (int i = 0; i < 2; ++i) {
-			if (d_in[i]) { (void)hipFree(d_in[i]); } if (d_out[i]) { (void)hipFree(d_out[i]); } if (d_meta[i]) { (void)hipFree(d_meta[i]); }
-			if (h_meta[i]) { (void)hipHostFree(h_meta[i]); }
-			if (ev_up[i]) { (void)hipEventDestroy(ev_up[i]); } if (ev_ex[i]) { (void)hipEventDestroy(ev_ex[i]); } if (ev_dn[i]) { (void)hipEventDestroy(ev_dn[i]); }
-		}
-		if (up) { (void)hipStreamDestroy(up); } if (ex) { (void)hipStreamDestroy(ex); } if (dn) { (void)hipStreamDestroy(dn); }
+		if (d_in) { (void)hipFree(d_in); } if (d_out) { (void)hipFree(d_out); } if (d_meta) { (void)hipFree(d_meta); }
+		if (h_meta) { (void)hipHostFree(h_meta); }
+		if (ev_ex) { (void)hipEventDestroy(ev_ex); }
+		if (ex) { (void)hipStreamDestroy(ex); }
+	}
+};
+
+struct Worker {                                           // everything one device range needs, kept between calls
+	int device = -1;
+	hipStream_t up = nullptr, dn = nullptr;                  // all uploads / all downloads of the range (one thread each issues them in order)
+	Slot slot[HB_SLOTS]; bool have[HB_SLOTS] = {};
+	bool init(int dev)
+	{
+		device = dev;
+		return hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&up, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&dn, hipStreamNonBlocking) == hipSuccess;
+	}
+	Slot* get(int s)                                         // slots come to life when a job is large enough to reach them
+	{
+		if (!have[s]) { if (!slot[s].init(device)) { slot[s].destroy(); slot[s] = Slot(); return nullptr; } have[s] = true; }
+		return &slot[s];
+	}
+	void destroy()
+	{
+		if (device >= 0) { (void)hipSetDevice(device); }
+		for (int s = 0; s < HB_SLOTS; ++s) { if (have[s]) { slot[s].destroy(); have[s] = false; } }
+		if (up) { (void)hipStreamDestroy(up); up = nullptr; } if (dn) { (void)hipStreamDestroy(dn); dn = nullptr; }
 	}
 };
 
@@ -100,17 +120,25 @@ struct Batch { size_t b0, b1; std::vector<uint64_t> in_off, in_len, out_off, out
 
 size_t batch_bytes()
 {
-	static const size_t v = [] { const char* e = getenv("MSCOMP_AMD_HOST_BATCH_MB"); const long x = e ? atol(e) : 512; return (size_t)(x >= 1 && x <= 65536 ? x : 512) << 20; }();
+	static const size_t v = [] { const char* e = getenv("MSCOMP_AMD_HOST_BATCH_MB"); const long x = e ? atol(e) : 32; return (size_t)(x >= 1 && x <= 65536 ? x : 32) << 20; }();
 	return v;
 }
 
-// units [u0, u1) on worker w: MSCOMP_OK, or the first error that stopped the range (HIP failure / out of memory / bad argument)
+// units [u0, u1) on worker w: MSCOMP_OK, or the first error that stopped the range (HIP failure / out of memory / bad argument).
+//
+// The range is cut into sub-batches of about MSCOMP_AMD_HOST_BATCH_MB (default 32) MiB of input, up to HB_SLOTS of them in flight, each in
+// its own slot (context + stream + buffers), and three host threads move them along:
+//   uploader   : sub-batch i's inputs host -> device (copies from pageable memory hold the calling thread, so they get their own);
+//   launcher   : this thread -- plan + kernels of sub-batch i as soon as its input is up, on the slot's stream: the kernels of the sub-batches
+//                in flight overlap on the GPU (the serial stages of a small batch are latency-bound: one wave per unit / chunk);
+//   downloader : results + streams of sub-batch i device -> host when its kernels are through, then the slot is free again.
+// A sub-batch's download therefore runs under the kernels of the ones behind it and its upload under those in front of it.
 MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 {
 	if (hipSetDevice(w->device) != hipSuccess) { return MSCOMP_ERRNO; }
 	const size_t limit = batch_bytes();
 	std::vector<Batch> batches;
-	for (size_t i = u0; i < u1;) {                               // batches: runs of units up to `limit` input bytes (a larger unit is a batch of its own)
+	for (size_t i = u0; i < u1;) {                               // sub-batches: runs of units up to `limit` input bytes (a larger unit is one of its own)
 		Batch b; b.b0 = i; b.in_total = 0; b.out_total = 0; b.plan = nullptr; b.out_mirror = true;
 		uint64_t in_pos = 0;
 		while (i < u1 && (i == b.b0 || (in_pos + j.in_lens[i] <= limit && i - b.b0 < (1u << 22)))) {
@@ -133,79 +161,133 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 		b.out_total = out_pos;
 		batches.push_back(std::move(b));
 	}
-	MSCompStatus rs = MSCOMP_OK;
 	const size_t nb = batches.size();
-	auto finish = [&](size_t k) -> MSCompStatus {                // batch k is through the kernels: results to the caller, outputs on their way down
-		Batch& b = batches[k];
-		const int slot = (int)(k & 1u);
-		if (hipEventSynchronize(w->ev_ex[slot]) != hipSuccess) { return MSCOMP_ERRNO; }
-		const size_t n = b.b1 - b.b0;
-		const uint64_t* h_len = w->h_meta[slot]; const int32_t* h_st = reinterpret_cast<const int32_t*>(h_len + n);
-		const uint8_t* d_out = static_cast<const uint8_t*>(w->d_out[slot]);
-		MSCompStatus r = MSCOMP_OK;
-		size_t last_ok = n;                                        // mirror layout: one copy up to the end of the last stream
-		for (size_t i = 0; i < n; ++i) {
-			const size_t u = b.b0 + i;
-			j.statuses[u] = (MSCompStatus)h_st[i];
-			j.out_lens[u] = h_st[i] == MSCOMP_OK ? (size_t)h_len[i] : 0;
-			if (h_st[i] == MSCOMP_OK) { last_ok = i; }
-		}
-		auto span = [&](size_t i) -> size_t {                      // bytes of unit i to bring home: the stream, and for LZNT1 the two uncounted 00 00 behind it
-			size_t len = (size_t)h_len[i];
-			if (!j.decompress && j.format == MSCOMP_LZNT1 && j.out_caps[b.b0 + i] - len >= 2) { len += 2; }
-			return len;
-		};
-		if (b.out_mirror && last_ok != n) {
-			const size_t bytes = (size_t)b.out_off[last_ok] + span(last_ok);
-			if (bytes && hipMemcpyAsync(j.out_ptrs[b.b0], d_out, bytes, hipMemcpyDeviceToHost, w->dn) != hipSuccess) { r = MSCOMP_ERRNO; }
-		} else if (!b.out_mirror) {
-			for (size_t i = 0; i < n && r == MSCOMP_OK; ++i) {
-				if (h_st[i] != MSCOMP_OK) { continue; }
-				const size_t bytes = span(i);
-				if (bytes && hipMemcpyAsync(j.out_ptrs[b.b0 + i], d_out + b.out_off[i], bytes, hipMemcpyDeviceToHost, w->dn) != hipSuccess) { r = MSCOMP_ERRNO; }
-			}
-		}
-		if (hipEventRecord(w->ev_dn[slot], w->dn) != hipSuccess) { r = MSCOMP_ERRNO; }
-		mscomp_amd_plan_destroy(b.plan); b.plan = nullptr;
-		return r;
-	};
-	bool used[2] = { false, false };
-	for (size_t k = 0; k < nb && rs == MSCOMP_OK; ++k) {
-		Batch& b = batches[k];
-		const int slot = (int)(k & 1u);
-		const size_t n = b.b1 - b.b0;
-		if (used[slot] && hipEventSynchronize(w->ev_dn[slot]) != hipSuccess) { rs = MSCOMP_ERRNO; break; }     // the slot's buffers are free again
-		if (!w->reserve(slot, (size_t)b.in_total, (size_t)b.out_total, n)) { rs = MSCOMP_MEM_ERROR; break; }
-		used[slot] = true;
-		uint8_t* d_in = static_cast<uint8_t*>(w->d_in[slot]);
-		for (size_t i = 0; i < n && rs == MSCOMP_OK;) {             // uploads: units that lie back to back in the caller's memory AND on the device go as one copy
-			size_t e = i + 1;
-			uint64_t bytes = b.in_len[i];
-			while (e < n && (b.in_len[e - 1] & 15u) == 0 && j.in_ptrs[b.b0 + e] == j.in_ptrs[b.b0 + e - 1] + b.in_len[e - 1]) { bytes += b.in_len[e]; ++e; }
-			if (bytes && hipMemcpyAsync(d_in + b.in_off[i], j.in_ptrs[b.b0 + i], (size_t)bytes, hipMemcpyHostToDevice, w->up) != hipSuccess) { rs = MSCOMP_ERRNO; }
-			i = e;
-		}
-		if (rs == MSCOMP_OK && hipEventRecord(w->ev_up[slot], w->up) != hipSuccess) { rs = MSCOMP_ERRNO; }
-		if (rs != MSCOMP_OK) { break; }
-		// (the plan's tables go up on the kernel stream and wait for it: batch k - 1 is in the kernels meanwhile, batch k on its way up)
-		rs = j.decompress ? mscomp_amd_plan_create_decompress(w->ctx, j.format, n, b.in_off.data(), b.in_len.data(), b.out_off.data(), b.out_cap.data(), &b.plan)
-		                  : mscomp_amd_plan_create(w->ctx, j.format, n, b.in_off.data(), b.in_len.data(), b.out_off.data(), b.out_cap.data(), &b.plan);
-		if (rs != MSCOMP_OK) { break; }
-		uint64_t* d_len = static_cast<uint64_t*>(w->d_meta[slot]); int32_t* d_st = reinterpret_cast<int32_t*>(d_len + n);
-		if (hipStreamWaitEvent(w->ex, w->ev_up[slot], 0) != hipSuccess) { rs = MSCOMP_ERRNO; break; }
-		rs = mscomp_amd_plan_execute(b.plan, d_in, static_cast<uint8_t*>(w->d_out[slot]), d_len, d_st);
-		if (rs != MSCOMP_OK) { break; }
-		if (hipMemcpyAsync(w->h_meta[slot], d_len, n * 12, hipMemcpyDeviceToHost, w->ex) != hipSuccess || hipEventRecord(w->ev_ex[slot], w->ex) != hipSuccess) { rs = MSCOMP_ERRNO; break; }
-		// (no stream wait of `dn` on ev_ex here: finish(k) waits for that event on the HOST before it queues batch k's copies, and a wait queued now
-		//  would put batch k - 1's downloads behind batch k's kernels)
-		if (k >= 1) { rs = finish(k - 1); }
+	if (nb == 0) { return MSCOMP_OK; }
+	// the sub-batch with the largest UNIT first: the kernels of a large file (Xpress+Huffman: its chunks form one chain of serial stages) are the
+	// critical path of the range, everything else runs beside them (stable: equal sub-batches keep the caller's order)
+	if (!(getenv("MSCOMP_AMD_HOST_ORDER") && *getenv("MSCOMP_AMD_HOST_ORDER") == '0')) {
+		std::vector<uint64_t> big(nb, 0);
+		for (size_t k = 0; k < nb; ++k) { for (uint64_t l : batches[k].in_len) { if (l > big[k]) { big[k] = l; } } }
+		std::vector<size_t> ord(nb);
+		for (size_t k = 0; k < nb; ++k) { ord[k] = k; }
+		std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return big[a] > big[b]; });
+		std::vector<Batch> sorted; sorted.reserve(nb);
+		for (size_t k = 0; k < nb; ++k) { sorted.push_back(std::move(batches[ord[k]])); }
+		batches.swap(sorted);
 	}
-	if (rs == MSCOMP_OK && nb) { rs = finish(nb - 1); }
-	(void)hipStreamSynchronize(w->up); (void)hipStreamSynchronize(w->ex);
-	if (hipStreamSynchronize(w->dn) != hipSuccess && rs == MSCOMP_OK) { rs = MSCOMP_ERRNO; }
+	static const size_t nslots = [] { const char* e = getenv("MSCOMP_AMD_HOST_SLOTS"); const long x = e ? atol(e) : HB_SLOTS; return (size_t)(x >= 1 && x <= HB_SLOTS ? x : HB_SLOTS); }();   // sub-batches in flight (212 MB corpus, 32 MiB sub-batches: 2 / 4 / 8 slots -> Xpress 11.7 / 9.3 / 8.5 ms, Xpress+Huffman 23.9 / 16.4 / 14.2 ms)
+
+	std::mutex mu; std::condition_variable cv;
+	std::vector<char> uploaded(nb, 0), launched(nb, 0);
+	static const bool trace = getenv("MSCOMP_AMD_HOST_TRACE") != nullptr;   // dev: a time line of the sub-batches on stderr
+	const auto t_zero = std::chrono::steady_clock::now();
+	auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_zero).count(); };
+	std::vector<double> tl(trace ? nb * 6 : 0, 0.0);                      // upload begin / end, launch begin / end, kernels done, download end
+	bool busy[HB_SLOTS] = {};
+	MSCompStatus failed = MSCOMP_OK;                             // first error (under mu); every loop stops when it is set
+	auto fail = [&](MSCompStatus r) { std::lock_guard<std::mutex> lk(mu); if (failed == MSCOMP_OK) { failed = r; } cv.notify_all(); };
+	auto is_failed = [&]() { std::lock_guard<std::mutex> lk(mu); return failed != MSCOMP_OK; };
+
+	std::thread uploader([&] {
+		if (hipSetDevice(w->device) != hipSuccess) { fail(MSCOMP_ERRNO); return; }
+		for (size_t k = 0; k < nb; ++k) {
+			const int s = (int)(k % nslots);
+			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !busy[s] || failed != MSCOMP_OK; }); if (failed != MSCOMP_OK) { return; } busy[s] = true; }
+			Batch& b = batches[k];
+			const size_t n = b.b1 - b.b0;
+			if (trace) { tl[k * 6] = now_ms(); }
+			Slot* sl = w->get(s);
+			if (!sl) { fail(MSCOMP_ERRNO); return; }
+			if (!sl->reserve((size_t)b.in_total, (size_t)b.out_total, n)) { fail(MSCOMP_MEM_ERROR); return; }
+			uint8_t* d_in = static_cast<uint8_t*>(sl->d_in);
+			for (size_t i = 0; i < n;) {                               // units that lie back to back in the caller's memory AND on the device go as one copy
+				size_t e = i + 1;
+				uint64_t bytes = b.in_len[i];
+				while (e < n && (b.in_len[e - 1] & 15u) == 0 && j.in_ptrs[b.b0 + e] == j.in_ptrs[b.b0 + e - 1] + b.in_len[e - 1]) { bytes += b.in_len[e]; ++e; }
+				if (bytes && hipMemcpyAsync(d_in + b.in_off[i], j.in_ptrs[b.b0 + i], (size_t)bytes, hipMemcpyHostToDevice, w->up) != hipSuccess) { fail(MSCOMP_ERRNO); return; }
+				i = e;
+			}
+			if (hipStreamSynchronize(w->up) != hipSuccess) { fail(MSCOMP_ERRNO); return; }
+			if (trace) { tl[k * 6 + 1] = now_ms(); }
+			{ std::lock_guard<std::mutex> lk(mu); uploaded[k] = 1; }
+			cv.notify_all();
+		}
+	});
+
+	std::thread downloader([&] {
+		if (hipSetDevice(w->device) != hipSuccess) { fail(MSCOMP_ERRNO); return; }
+		for (size_t k = 0; k < nb; ++k) {
+			const int s = (int)(k % nslots);
+			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return launched[k] || failed != MSCOMP_OK; }); if (!launched[k]) { return; } }
+			Batch& b = batches[k];
+			Slot* sl = &w->slot[s];
+			if (hipEventSynchronize(sl->ev_ex) != hipSuccess) { fail(MSCOMP_ERRNO); return; }
+			if (trace) { tl[k * 6 + 4] = now_ms(); }
+			const size_t n = b.b1 - b.b0;
+			const uint64_t* h_len = sl->h_meta; const int32_t* h_st = reinterpret_cast<const int32_t*>(h_len + n);
+			const uint8_t* d_out = static_cast<const uint8_t*>(sl->d_out);
+			size_t last_ok = n;                                        // mirror layout: one copy up to the end of the last stream
+			for (size_t i = 0; i < n; ++i) { if (h_st[i] == MSCOMP_OK) { last_ok = i; } }
+			auto span = [&](size_t i) -> size_t {                      // bytes of unit i to bring home: the stream, and for LZNT1 the two uncounted 00 00 behind it
+				size_t len = (size_t)h_len[i];
+				if (!j.decompress && j.format == MSCOMP_LZNT1 && j.out_caps[b.b0 + i] - len >= 2) { len += 2; }
+				return len;
+			};
+			bool ok = true;
+			if (b.out_mirror && last_ok != n) {
+				const size_t bytes = (size_t)b.out_off[last_ok] + span(last_ok);
+				if (bytes && hipMemcpyAsync(j.out_ptrs[b.b0], d_out, bytes, hipMemcpyDeviceToHost, w->dn) != hipSuccess) { ok = false; }
+			} else if (!b.out_mirror) {
+				for (size_t i = 0; i < n && ok; ++i) {
+					if (h_st[i] != MSCOMP_OK) { continue; }
+					const size_t bytes = span(i);
+					if (bytes && hipMemcpyAsync(j.out_ptrs[b.b0 + i], d_out + b.out_off[i], bytes, hipMemcpyDeviceToHost, w->dn) != hipSuccess) { ok = false; }
+				}
+			}
+			if (!ok || hipStreamSynchronize(w->dn) != hipSuccess) { fail(MSCOMP_ERRNO); return; }
+			if (trace) { tl[k * 6 + 5] = now_ms(); }
+			for (size_t i = 0; i < n; ++i) {                           // results to the caller once the bytes are home
+				const size_t u = b.b0 + i;
+				j.statuses[u] = (MSCompStatus)h_st[i];
+				j.out_lens[u] = h_st[i] == MSCOMP_OK ? (size_t)h_len[i] : 0;
+			}
+			mscomp_amd_plan_destroy(b.plan); b.plan = nullptr;         // (its tables go back to the slot's context: no hipFree on this path)
+			{ std::lock_guard<std::mutex> lk(mu); busy[s] = false; }
+			cv.notify_all();
+		}
+	});
+
+	for (size_t k = 0; k < nb; ++k) {                            // launcher
+		const int s = (int)(k % nslots);
+		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return uploaded[k] || failed != MSCOMP_OK; }); if (!uploaded[k]) { break; } }
+		Batch& b = batches[k];
+		Slot* sl = &w->slot[s];
+		const size_t n = b.b1 - b.b0;
+		if (trace) { tl[k * 6 + 2] = now_ms(); }
+		MSCompStatus rs = j.decompress ? mscomp_amd_plan_create_decompress(sl->ctx, j.format, n, b.in_off.data(), b.in_len.data(), b.out_off.data(), b.out_cap.data(), &b.plan)
+		                               : mscomp_amd_plan_create(sl->ctx, j.format, n, b.in_off.data(), b.in_len.data(), b.out_off.data(), b.out_cap.data(), &b.plan);
+		uint64_t* d_len = static_cast<uint64_t*>(sl->d_meta); int32_t* d_st = reinterpret_cast<int32_t*>(d_len + n);
+		if (rs == MSCOMP_OK) { rs = mscomp_amd_plan_execute(b.plan, static_cast<uint8_t*>(sl->d_in), static_cast<uint8_t*>(sl->d_out), d_len, d_st); }
+		if (rs == MSCOMP_OK && (hipMemcpyAsync(sl->h_meta, d_len, n * 12, hipMemcpyDeviceToHost, sl->ex) != hipSuccess || hipEventRecord(sl->ev_ex, sl->ex) != hipSuccess)) { rs = MSCOMP_ERRNO; }
+		if (rs != MSCOMP_OK) { fail(rs); break; }
+		if (trace) { tl[k * 6 + 3] = now_ms(); }
+		{ std::lock_guard<std::mutex> lk(mu); launched[k] = 1; }
+		cv.notify_all();
+	}
+	uploader.join(); downloader.join();
+	(void)hipStreamSynchronize(w->up); (void)hipStreamSynchronize(w->dn);
+	for (int s = 0; s < HB_SLOTS; ++s) { if (w->have[s]) { (void)hipStreamSynchronize(w->slot[s].ex); } }
 	for (auto& b : batches) { if (b.plan) { mscomp_amd_plan_destroy(b.plan); b.plan = nullptr; } }
 	(void)hipGetLastError();
-	return rs;
+	(void)is_failed;
+	if (trace) {
+		for (size_t k = 0; k < nb; ++k) {
+			fprintf(stderr, "hostbatch %2zu: %8.0f KB in | up %7.3f-%7.3f | launch %7.3f-%7.3f | kernels done %7.3f | down %7.3f\n", k, (double)batches[k].in_total / 1024.0,
+			        tl[k * 6], tl[k * 6 + 1], tl[k * 6 + 2], tl[k * 6 + 3], tl[k * 6 + 4], tl[k * 6 + 5]);
+		}
+		fprintf(stderr, "hostbatch total %.3f ms\n", now_ms());
+	}
+	return failed;
 }
 
 } // namespace
@@ -247,7 +329,7 @@ static MSCompStatus units_host(MSCompFormat format, bool decompress, int n_dev, 
 		Worker* w = take_worker(dev[r]);
 		if (!w) { res[r] = MSCOMP_ERRNO; return; }
 		res[r] = run_range(w, job, cuts[r], cuts[r + 1]);
-		give_worker(w);
+		if (res[r] == MSCOMP_OK) { give_worker(w); } else { w->destroy(); delete w; }   // (a range that failed may leave a sticky HIP error or half-grown buffers behind: its worker is not reused)
 	};
 	for (int r = 1; r < n_dev; ++r) { threads.emplace_back(body, r); }
 	body(0);                                                         // range 0 on the calling thread
