@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmscomp_amd.so")
+LIB_PATH = os.environ.get("MSCOMP_AMD_LIB") or os.path.join(HERE, "libmscomp_amd.so")   # (MSCOMP_AMD_LIB: a development build of the same library, e.g. with a *_PROFILE macro)
 
 # enum values identical to /root/reference/include/mscomp/general.h:65-85
 MSCOMP_NONE, MSCOMP_RESERVED, MSCOMP_LZNT1, MSCOMP_XPRESS, MSCOMP_XPRESS_HUFF = 0, 1, 2, 3, 4

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <thread>
 #include <condition_variable>
 #include <hip/hip_runtime.h>
 #include <new>
@@ -875,32 +876,66 @@ struct OneShotTls {
 // is shared (counted), an overlapping but different range waits until the other call has released its own, and a range that cannot be registered
 // at all (locked-memory limits) is simply not pinned -- the copies then go through the runtime's staging buffers.
 struct HostPins {
-	struct Ent { const uint8_t* b; size_t n; int refs; };
+	struct Ent { const uint8_t* b; size_t n; int refs; std::vector<std::thread::id> owners; };
 	std::mutex mu; std::condition_variable cv; std::vector<Ent> ents;
 	bool pin(const void* ptr, size_t n)                       // true: the range is page-locked (and mapped) until unpin
 	{
 		if (!ptr || !n) { return false; }
 		const uint8_t* b = static_cast<const uint8_t*>(ptr);
+		const std::thread::id me = std::this_thread::get_id();
 		std::unique_lock<std::mutex> lk(mu);
 		for (;;) {
 			bool overlap = false;
 			for (auto& e : ents) {
-				if (e.b == b && e.n == n) { ++e.refs; return true; }
-				if (b < e.b + e.n && e.b < b + n) { overlap = true; }
+				if (e.b == b && e.n == n) { ++e.refs; e.owners.push_back(me); return true; }
+				if (b < e.b + e.n && e.b < b + n) {
+					// a different range that overlaps one THIS thread holds (a call whose in and out overlap): waiting would wait for ourselves --
+					// the range is simply not pinned and its copies go through the runtime's staging buffers
+					for (auto& o : e.owners) { if (o == me) { return false; } }
+					overlap = true;
+				}
 			}
 			if (!overlap) { break; }
 			cv.wait(lk);
 		}
+		// (hipHostRegister of tens of megabytes takes milliseconds and runs under the table's lock: large one-shot calls of different threads
+		// register one after the other; their copies and kernels still overlap)
 		if (hipHostRegister(const_cast<uint8_t*>(b), n, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return false; }
-		ents.push_back(Ent{ b, n, 1 });
+		ents.push_back(Ent{ b, n, 1, { me } });
 		return true;
+	}
+	// A call that does NOT pin its input (the staged paths) but reads a range another thread's call has registered: the runtime then copies
+	// from it as from pinned memory (asynchronously), so the registration must outlive that copy. hold() takes a reference on every entry that
+	// overlaps the range (the entries are returned and given back with release() once the copy is done).
+	std::vector<std::pair<const uint8_t*, size_t>> hold(const void* ptr, size_t n)
+	{
+		std::vector<std::pair<const uint8_t*, size_t>> held;
+		if (!ptr || !n) { return held; }
+		const uint8_t* b = static_cast<const uint8_t*>(ptr);
+		std::unique_lock<std::mutex> lk(mu);
+		for (auto& e : ents) { if (b < e.b + e.n && e.b < b + n) { ++e.refs; held.push_back({ e.b, e.n }); } }
+		return held;
+	}
+	void release(const std::vector<std::pair<const uint8_t*, size_t>>& held)
+	{
+		std::unique_lock<std::mutex> lk(mu);
+		for (auto& h : held) {
+			for (size_t i = 0; i < ents.size(); ++i) {
+				if (ents[i].b == h.first && ents[i].n == h.second) {
+					if (--ents[i].refs == 0) { (void)hipHostUnregister(const_cast<uint8_t*>(ents[i].b)); ents.erase(ents.begin() + (long)i); cv.notify_all(); }
+					break;
+				}
+			}
+		}
 	}
 	void unpin(const void* ptr, size_t n)
 	{
 		const uint8_t* b = static_cast<const uint8_t*>(ptr);
+		const std::thread::id me = std::this_thread::get_id();
 		std::unique_lock<std::mutex> lk(mu);
 		for (size_t i = 0; i < ents.size(); ++i) {
 			if (ents[i].b == b && ents[i].n == n) {
+				for (size_t k = 0; k < ents[i].owners.size(); ++k) { if (ents[i].owners[k] == me) { ents[i].owners.erase(ents[i].owners.begin() + (long)k); break; } }
 				if (--ents[i].refs == 0) { (void)hipHostUnregister(const_cast<uint8_t*>(b)); ents.erase(ents.begin() + (long)i); cv.notify_all(); }
 				return;
 			}
@@ -1042,6 +1077,8 @@ static MSCompStatus one_shot(MSCompFormat format, bool decompress, const uint8_t
 	if (!c->one_in.reserve(in_len + 64) || !c->one_meta.reserve(64)) { return MSCOMP_MEM_ERROR; }
 	uint8_t* d_in = static_cast<uint8_t*>(c->one_in.p);
 	uint64_t* d_len = static_cast<uint64_t*>(c->one_meta.p); int32_t* d_st = reinterpret_cast<int32_t*>(d_len + 1);
+	// (another thread's large LZNT1 call may have page-locked this very input: keep its registration alive until our copy is through)
+	struct Held { std::vector<std::pair<const uint8_t*, size_t>> v; ~Held() { if (!v.empty()) { g_pins.release(v); } } } held{ g_pins.hold(in, in_len) };
 	if (in_len && hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, c->stream) != hipSuccess) { return MSCOMP_ERRNO; }
 	struct { uint64_t len; int32_t st; int32_t pad; } meta;
 	for (;;) {

@@ -54,9 +54,17 @@ struct Slot {
 		if (hipMalloc(p, want) != hipSuccess) { *p = nullptr; (void)hipGetLastError(); return false; }
 		*cap = want; return true;
 	}
+	// The mirror-layout download copies the slack between the streams of a batch to the caller too: the output buffer of a slot is all zeros
+	// wherever no stream of the current batch lies (cleared when it is allocated and again, off the critical path, when a batch has left it).
+	bool reserve_out(size_t need)
+	{
+		if (need <= out_cap) { return true; }
+		if (!grow(&d_out, &out_cap, need)) { return false; }
+		return hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_out), 0, out_cap / 4, ex) == hipSuccess;
+	}
 	bool reserve(size_t in_b, size_t out_b, size_t n)
 	{
-		if (!grow(&d_in, &in_cap, in_b + 64) || !grow(&d_out, &out_cap, out_b + 64) || !grow(&d_meta, &meta_cap, n * 16 + 64)) { return false; }
+		if (!grow(&d_in, &in_cap, in_b + 64) || !reserve_out(out_b + 64) || !grow(&d_meta, &meta_cap, n * 16 + 64)) { return false; }
 		if (h_cap < n) {
 			if (h_meta) { (void)hipHostFree(h_meta); h_meta = nullptr; h_cap = 0; }
 			void* q = nullptr;
@@ -154,7 +162,12 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 		std::vector<uint64_t> dcap(b.b1 - b.b0);
 		for (size_t k = b.b0; k < b.b1; ++k) {
 			uint64_t c = j.out_caps[k];
-			if (!j.decompress) { const uint64_t most = (uint64_t)ms_max_compressed_size(j.format, j.in_lens[k]) + 2u; if (most < c) { c = most; b.out_mirror = false; } }
+			uint64_t most;
+			if (!j.decompress) { most = (uint64_t)ms_max_compressed_size(j.format, j.in_lens[k]) + 2u; }
+			else if (j.format == MSCOMP_LZNT1) { most = ((uint64_t)j.in_lens[k] / 3u + 1u) * 4096u; }            // a chunk takes at least 3 bytes and gives at most 4096
+			else { most = (uint64_t)j.in_lens[k] * 16u + (1u << 20); }     // Xpress formats have no bound (a 10-byte token can stand for 4 GiB): 16 x the input first; a unit that
+			                                                              // answers MSCOMP_BUF_ERROR below the caller's capacity is decoded again, alone, with room (after the pipeline)
+			if (most < c) { c = most; b.out_mirror = false; }
 			dcap[k - b.b0] = c;
 		}
 		for (size_t k = b.b0; k < b.b1; ++k) { const uint64_t c = dcap[k - b.b0]; b.out_off.push_back(out_pos); b.out_cap.push_back(c); out_pos += b.out_mirror ? c : ((c + 15u) & ~(uint64_t)15u); }
@@ -185,6 +198,7 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 	std::vector<double> tl(trace ? nb * 6 : 0, 0.0);                      // upload begin / end, launch begin / end, kernels done, download end
 	bool busy[HB_SLOTS] = {};
 	MSCompStatus failed = MSCOMP_OK;                             // first error (under mu); every loop stops when it is set
+	std::vector<size_t> again;                                   // decompression: units whose DEVICE capacity (not the caller's) was too small (downloader thread only)
 	auto fail = [&](MSCompStatus r) { std::lock_guard<std::mutex> lk(mu); if (failed == MSCOMP_OK) { failed = r; } cv.notify_all(); };
 	auto is_failed = [&]() { std::lock_guard<std::mutex> lk(mu); return failed != MSCOMP_OK; };
 
@@ -250,8 +264,11 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 				const size_t u = b.b0 + i;
 				j.statuses[u] = (MSCompStatus)h_st[i];
 				j.out_lens[u] = h_st[i] == MSCOMP_OK ? (size_t)h_len[i] : 0;
+				if (j.decompress && h_st[i] == MSCOMP_BUF_ERROR && b.out_cap[i] < j.out_caps[u]) { again.push_back(u); }
 			}
 			mscomp_amd_plan_destroy(b.plan); b.plan = nullptr;         // (its tables go back to the slot's context: no hipFree on this path)
+			// zeros again where this batch's streams were (stream-ordered in front of the slot's next kernels, under the other slots' work)
+			if (b.out_total && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sl->d_out), 0, ((size_t)b.out_total + 3) / 4, sl->ex) != hipSuccess) { fail(MSCOMP_ERRNO); return; }
 			{ std::lock_guard<std::mutex> lk(mu); busy[s] = false; }
 			cv.notify_all();
 		}
@@ -280,6 +297,13 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 	for (auto& b : batches) { if (b.plan) { mscomp_amd_plan_destroy(b.plan); b.plan = nullptr; } }
 	(void)hipGetLastError();
 	(void)is_failed;
+	if (failed == MSCOMP_OK) {                                   // the few units that need more room than 16 x their input: the one-shot decoder (it grows its staging: api.hip one_shot)
+		for (size_t u : again) {
+			size_t len = j.out_caps[u];
+			const MSCompStatus r = ms_decompress(j.format, j.in_ptrs[u], j.in_lens[u], j.out_ptrs[u], &len);
+			j.statuses[u] = r; j.out_lens[u] = r == MSCOMP_OK ? len : 0;
+		}
+	}
 	if (trace) {
 		for (size_t k = 0; k < nb; ++k) {
 			fprintf(stderr, "hostbatch %2zu: %8.0f KB in | up %7.3f-%7.3f | launch %7.3f-%7.3f | kernels done %7.3f | down %7.3f\n", k, (double)batches[k].in_total / 1024.0,

@@ -135,6 +135,11 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 			done = done || (take && lk == maxlen);
 		}
 	}
+#if defined(LZ_PROBE) && LZ_PROBE == 1      /* dev probe: 40 more VALU instructions per window */
+	{ uint32_t y_ = key; _Pragma("unroll") for (int q_ = 0; q_ < 40; ++q_) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(y_) : "v"(o0)); } asm volatile("" :: "v"(y_)); }
+#elif defined(LZ_PROBE) && LZ_PROBE == 2    /* dev probe: four more 16-byte LDS reads per window */
+	{ _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) { const uint4 y_ = lds_ld128(s_data, (p * 7u + 64u * q_) & 4095u); asm volatile("" :: "v"(y_.x), "v"(y_.y), "v"(y_.z), "v"(y_.w)); } }
+#endif
 	bool unres = !done && q[LZ_SELF] < p;                    // a 9th older candidate exists and max_len was not reached
 	// 2. greedy walk; positions with rem != 0 are finished by the whole wave when (and only when) the walk lands on them
 	u64 un = __ballot(unres);                                // unresolved positions
@@ -194,6 +199,11 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 				const uint32_t qq = s_bucket[idx & 4095u];         // unconditional load, masked below
 				const bool valid = idx < eL && qq < pL;            // !valid: this lane is at or beyond pL's own entry
 				const uint32_t l2 = lz_lcp(s_data, qq, valid, pL, maxL, a0, a1, a2, a3);
+#if defined(LZ_PROBE) && LZ_PROBE == 3      /* dev probe: 20 more VALU instructions per finishing step */
+				{ uint32_t y_ = l2; _Pragma("unroll") for (int q_ = 0; q_ < 20; ++q_) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(y_) : "v"(qq)); } asm volatile("" :: "v"(y_)); }
+#elif defined(LZ_PROBE) && LZ_PROBE == 4    /* dev probe: one more 16-byte LDS read per finishing step */
+				{ const uint4 y_ = lds_ld128(s_data, (qq * 7u + 64u) & 4095u); asm volatile("" :: "v"(y_.x), "v"(y_.y), "v"(y_.z), "v"(y_.w)); }
+#endif
 				const uint32_t k2 = l2 ? ((l2 << 12) | (4095u - qq)) : 0u;
 				const bool past = !valid;
 				const uint32_t m = wave_max_u32(k2);

@@ -294,6 +294,13 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 				uint32_t x = (LINKW == WINDOW) ? (uint32_t)s_links[(uint32_t)xr - lrel] : (uint32_t)lkw[(uint32_t)xr];
 				// 16 bytes per step against my own 48 bytes held in registers (lengths are capped at 48 here)
 				uint4 c = ld128(s_data, (uint32_t)xr);
+#if defined(XF_PROBE) && XF_PROBE == 1        /* dev probe: one more divergent global gather per step */
+				{ const uint32_t y = lkw[((uint32_t)xr * 7u + 13u) & 0xFFFFu]; asm volatile("" :: "v"(y)); }
+#elif defined(XF_PROBE) && XF_PROBE == 2      /* dev probe: ten more VALU instructions per step */
+				{ uint32_t y = dist; _Pragma("unroll") for (int q_ = 0; q_ < 10; ++q_) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(y) : "v"(c.x)); } asm volatile("" :: "v"(y)); }
+#elif defined(XF_PROBE) && XF_PROBE == 3      /* dev probe: five more LDS dword reads per step */
+				{ const uint4 y = ld128(s_data, ((uint32_t)xr * 5u + 77u) & 0xFFFFu); asm volatile("" :: "v"(y.x), "v"(y.y), "v"(y.z), "v"(y.w)); }
+#endif
 				uint32_t l = first_diff16(make_uint4(c.x ^ oa.x, c.y ^ oa.y, c.z ^ oa.z, c.w ^ oa.w));
 				if (l == 16u && cap > 16u) {
 					c = ld128(s_data, (uint32_t)xr + 16u);

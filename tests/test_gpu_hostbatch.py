@@ -143,6 +143,29 @@ def test_generous_capacities_do_not_become_allocations(oracle, gpu_ctx):
         assert st[0] == 0 and ol[0] == len(exp) and bytes(out[: len(exp)]) == exp
 
 
+def test_generous_decompress_capacities(oracle, gpu_ctx):
+    """the decoders' side of the same rule: capacities of a terabyte (the C entry is called with them; the arrays hold what the streams decode
+    to) must not become device allocations -- LZNT1 is bounded by 4096 bytes per 3 of input, the Xpress formats start at 16 x the input and a
+    unit that needs more (5 MB of zeros behind a 100-byte stream) is decoded again with room, the others in its batch undisturbed"""
+    import ctypes as C
+    import ms_compress_amd as m
+    lib = m.load_library()
+    plain = [bytes(5_000_000), cases.mixed_buffer()[:120000], b"abc" * 70000, bytes(range(256)) * 40]
+    for fmt in (2, 3, 4):
+        streams = [oracle.oracle_compress(fmt, u)[1] for u in plain]
+        n = len(plain)
+        ins = [np.frombuffer(s_, dtype=np.uint8) for s_ in streams]
+        outs = [np.full(len(u) + 64, GUARD, dtype=np.uint8) for u in plain]
+        ip = (C.c_void_p * n)(*[a.ctypes.data for a in ins]); il = (C.c_size_t * n)(*[a.size for a in ins])
+        op = (C.c_void_p * n)(*[a.ctypes.data for a in outs]); oc = (C.c_size_t * n)(*([1 << 40] * n))
+        ol = (C.c_size_t * n)(); st = (C.c_int * n)(*([-9] * n))
+        dv = (C.c_int * 1)(0)
+        assert lib.mscomp_amd_decompress_units_host(fmt, 1, dv, n, ip, il, op, oc, ol, st) == 0
+        for i, u in enumerate(plain):
+            assert st[i] == 0 and ol[i] == len(u) and bytes(outs[i][: len(u)]) == u, (fmt, i)
+            assert bool((outs[i][len(u):] == GUARD).all())
+
+
 def test_argument_errors(gpu_ctx):
     import ms_compress_amd as m
     a = np.zeros(100, dtype=np.uint8); o = np.zeros(200, dtype=np.uint8)
