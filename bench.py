@@ -282,11 +282,14 @@ def secondary_bound(fmt, timer_name, workload_key):
     sym = SYMBOLS.get((fmt, timer_name))
     if not doc or not sym:
         return None
+    probes, ptag = _profile_doc("additive_probes")
     for wl in (workload_key, "single_gpu"):          # this workload's own counters when they were collected, else the single-GPU leg's (shares carry over, totals do not)
         rec = doc.get("workloads", {}).get(wl, {}).get(sym)
         if rec and rec.get("codec") == CODEC_OF[fmt]:
             out = dict(rec["derived"])
             out["from"] = "profiles/%s_sq_counters.json, workload %s%s" % (tag, wl, "" if wl == workload_key else " (NOT this workload: shares of wave time carry over, totals do not)")
+            if probes and sym in probes:                 # what the kernel's time is made of, measured by adding instructions to its hot loop (more direct than busy counters)
+                out["additive_probes"] = {"from": "profiles/%s_additive_probes.json" % ptag, "reading": probes[sym]["reading"]}
             return out
     return None
 
