@@ -22,6 +22,7 @@
 //                     (XpressDictionary.h:88-93) is the limit n-p-1.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 namespace msc {
 
@@ -359,7 +360,8 @@ void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, 
 	static PerDeviceOnce attr;
 	constexpr uint32_t TXP = 4096u, TXH = XH_TILE_SEL;
 	const uint32_t lds_xp = 0x2000u + TXP + 64u + (0x2000u + TXP) * 2u;           // data + all links of the window in LDS
-	const uint32_t lds_xh = 0x10000u + TXH + 64u;                                // data only (2 blocks/CU); links come from L2
+	static const uint32_t xh_pad = [] { const char* e = getenv("MSCOMP_AMD_XF_LDS_PAD_KB"); return e ? (uint32_t)atoi(e) * 1024u : 0u; }();   // dev: more LDS per block = fewer blocks per CU (occupancy probe)
+	const uint32_t lds_xh = 0x10000u + TXH + 64u + xh_pad;                        // data only (2 blocks/CU); links come from L2
 	if (attr.needed()) {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x2000u, 0x2000u, 512u, TXP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xp);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_find_kernel<0x10000u, 0u, 1024u, TXH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xh);
