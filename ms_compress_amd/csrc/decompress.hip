@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(64) void xhd_parse_kernel(const uint8_t* __restrict
 		_Pragma("unroll") for (int i_ = 0; i_ < (int)(XHD_INB / 1024u); ++i_) { const u64 q_ = (u64)loaded * XHD_INB + ((uint32_t)i_ * 64u + lane) * 16u; \
 			*reinterpret_cast<uint4*>(b_ + ((uint32_t)i_ * 64u + lane) * 16u) = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } \
 		++loaded; __syncthreads(); }
-	// loaded * 2048 never lies behind the walk, so the distance to it is a plain 32-bit difference (units end below 4 GiB - 4096)
+	// loaded * XHD_INB never lies behind the walk, so the distance to it is a plain 32-bit difference (units end below 4 GiB - 4096)
 	#define XHD_NEED(q, margin) while (loaded * XHD_INB - (q) < (margin) && loaded * XHD_INB < endq) { XHD_BLOCK() }
 	XHD_BLOCK() XHD_BLOCK()
 	auto rb = [&](uint32_t q) -> uint32_t { return S.in[q & (2u * XHD_INB - 1u)]; };
@@ -1319,7 +1319,7 @@ __global__ __launch_bounds__(64) void xhc_parse_kernel(const uint8_t* __restrict
 		_Pragma("unroll") for (int i_ = 0; i_ < (int)(XHD_INB / 1024u); ++i_) { const u64 q_ = (u64)loaded * XHD_INB + ((uint32_t)i_ * 64u + lane) * 16u; \
 			*reinterpret_cast<uint4*>(b_ + ((uint32_t)i_ * 64u + lane) * 16u) = q_ < endq ? *reinterpret_cast<const uint4*>(ab + q_) : make_uint4(0, 0, 0, 0); } \
 		++loaded; __syncthreads(); }
-	// loaded * 2048 never lies behind the walk, so the distance to it is a plain 32-bit difference (units end below 4 GiB - 4096)
+	// loaded * XHD_INB never lies behind the walk, so the distance to it is a plain 32-bit difference (units end below 4 GiB - 4096)
 	#define XHD_NEED(q, margin) while (loaded * XHD_INB - (q) < (margin) && loaded * XHD_INB < endq) { XHD_BLOCK() }
 	loaded = (a0 + at) / XHD_INB;
 	XHD_BLOCK() XHD_BLOCK()
