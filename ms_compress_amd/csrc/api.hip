@@ -943,6 +943,25 @@ struct HostPins {
 	}
 };
 static HostPins g_pins;
+} // extern "C" (the two functions below are C++: they belong to the library's other translation units)
+namespace msc {
+// for the other host paths of the library (hostbatch.hip): keep every registration that overlaps [ptr, ptr + n) alive until the returned
+// token is given back (nullptr: nothing overlapped)
+void* host_pins_hold(const void* ptr, size_t n)
+{
+	auto v = g_pins.hold(ptr, n);
+	if (v.empty()) { return nullptr; }
+	return new (std::nothrow) std::vector<std::pair<const uint8_t*, size_t>>(std::move(v));
+}
+void host_pins_release(void* token)
+{
+	if (!token) { return; }
+	auto* v = static_cast<std::vector<std::pair<const uint8_t*, size_t>>*>(token);
+	g_pins.release(*v);
+	delete v;
+}
+}
+extern "C" {
 
 // one large host buffer through the GPU with the link busy in both directions while the kernels run. LZNT1 chunks
 // are independent and the output is their concatenation (lznt1_compress.cpp:262), so the buffer is cut into slices of 1024 chunks:

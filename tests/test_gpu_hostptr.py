@@ -124,6 +124,33 @@ def test_two_threads_compress_the_same_input_at_once(gpu_ctx, mozilla):
         assert not bad, (sliced, bad)
 
 
+def test_host_batch_beside_a_large_one_shot_call_on_the_same_input(gpu_ctx, mozilla):
+    """one thread compresses mozilla with the large host-pointer LZNT1 call (which page-locks its input for the duration), another reads the
+    SAME input through the host-batch entry at the same time (legal: inputs may be shared): the batch entry's staged copies keep the other
+    call's registration alive (csrc/api.hip host_pins_hold); every result against the reference's digests"""
+    import ms_compress_amd as m
+    lib = m.load_library()
+    g2, g4 = GOLD["mozilla"]["lznt1"], GOLD["mozilla"]["xpress_huff"]
+    bad = []
+
+    def one_shot():
+        cap = lib.ms_max_compressed_size(2, len(mozilla)) + 2
+        for _ in range(4):
+            st, ol, out = _call(lib, 2, mozilla, cap, 0)
+            if not (st == 0 and ol == g2["len"] and sha(out[:ol]) == g2["sha256"]):
+                bad.append(("one_shot", st, ol))
+
+    def batch():
+        for fmt, g in ((4, g4), (2, g2), (4, g4)):
+            out = np.zeros(m.max_compressed_size(fmt, len(mozilla)) + 2, dtype=np.uint8)
+            rc, lens, st = m.compress_units_host(fmt, [mozilla], [out], devices=(0,))
+            if not (rc == 0 and st[0] == 0 and int(lens[0]) == g["len"] and sha(out[: int(lens[0])]) == g["sha256"]):
+                bad.append(("batch", fmt, rc, int(st[0]), int(lens[0])))
+    ts = [threading.Thread(target=one_shot), threading.Thread(target=batch)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("fmt,key", [(3, "xpress"), (4, "xpress_huff")])
 def test_whole_file_host_pointer_xpress_formats(gpu_ctx, fmt, key):
     """one 21 MB buffer through ms_compress with host pointers: bytes of the reference, exact capacity, one short -> MSCOMP_BUF_ERROR"""
