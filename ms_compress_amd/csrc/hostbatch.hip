@@ -131,10 +131,14 @@ struct Job {
 };
 struct Batch { size_t b0, b1; std::vector<uint64_t> in_off, in_len, out_off, out_cap; uint64_t in_total, out_total; bool out_mirror; mscomp_amd_plan* plan; };
 
-size_t batch_bytes()
+// input bytes per sub-batch: MSCOMP_AMD_HOST_BATCH_MB, else 32 MiB -- 96 MiB for Xpress+Huffman compression, whose one-wave-per-chunk stages
+// (parse, Huffman, encode) are latency-bound in small batches: many small batches side by side cost 13 ms of GPU time for the 212 MB corpus
+// where one batch costs 8.6
+size_t batch_bytes(MSCompFormat format, bool decompress)
 {
-	static const size_t v = [] { const char* e = getenv("MSCOMP_AMD_HOST_BATCH_MB"); const long x = e ? atol(e) : 32; return (size_t)(x >= 1 && x <= 65536 ? x : 32) << 20; }();
-	return v;
+	static const long env = [] { const char* e = getenv("MSCOMP_AMD_HOST_BATCH_MB"); const long x = e ? atol(e) : 0; return (x >= 1 && x <= 65536) ? x : 0L; }();
+	if (env) { return (size_t)env << 20; }
+	return (size_t)((format == MSCOMP_XPRESS_HUFF && !decompress) ? 96 : 32) << 20;
 }
 
 // units [u0, u1) on worker w: MSCOMP_OK, or the first error that stopped the range (HIP failure / out of memory / bad argument).
@@ -149,7 +153,7 @@ size_t batch_bytes()
 MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 {
 	if (hipSetDevice(w->device) != hipSuccess) { return MSCOMP_ERRNO; }
-	const size_t limit = batch_bytes();
+	const size_t limit = batch_bytes(j.format, j.decompress);
 	std::vector<Batch> batches;
 	for (size_t i = u0; i < u1;) {                               // sub-batches: runs of units up to `limit` input bytes (a larger unit is one of its own)
 		Batch b; b.b0 = i; b.in_total = 0; b.out_total = 0; b.plan = nullptr; b.out_mirror = true;
@@ -257,10 +261,18 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 				return len;
 			};
 			bool ok = true;
-			if (b.out_mirror && last_ok != n) {
+			// a few large units whose streams are much shorter than their capacities (whole files): one copy per stream moves fewer bytes
+			// than the one copy of the capacity span
+			bool mirror = b.out_mirror;
+			if (mirror && last_ok != n && n <= 64) {
+				size_t streams = 0;
+				for (size_t i = 0; i < n; ++i) { if (h_st[i] == MSCOMP_OK) { streams += span(i); } }
+				if (streams + streams / 4 < (size_t)b.out_off[last_ok] + span(last_ok)) { mirror = false; }
+			}
+			if (mirror && last_ok != n) {
 				const size_t bytes = (size_t)b.out_off[last_ok] + span(last_ok);
 				if (bytes && hipMemcpyAsync(j.out_ptrs[b.b0], d_out, bytes, hipMemcpyDeviceToHost, w->dn) != hipSuccess) { ok = false; }
-			} else if (!b.out_mirror) {
+			} else if (!mirror) {
 				for (size_t i = 0; i < n && ok; ++i) {
 					if (h_st[i] != MSCOMP_OK) { continue; }
 					const size_t bytes = span(i);
