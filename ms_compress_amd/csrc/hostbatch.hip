@@ -153,6 +153,14 @@ size_t batch_bytes(MSCompFormat format, bool decompress)
 MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 {
 	if (hipSetDevice(w->device) != hipSuccess) { return MSCOMP_ERRNO; }
+	// ONE large LZNT1 unit: the one-shot call has the better path for it (the caller's buffers mapped, one launch reading and writing them over
+	// PCIe: 2.1 ms for 51 MB against 3.0 ms through a staged sub-batch)
+	if (u1 - u0 == 1 && !j.decompress && j.format == MSCOMP_LZNT1 && j.in_lens[u0] >= ((size_t)36 << 20)) {
+		size_t len = j.out_caps[u0];
+		const MSCompStatus r = ms_compress(j.format, j.in_ptrs[u0], j.in_lens[u0], j.out_ptrs[u0], &len);
+		j.statuses[u0] = r; j.out_lens[u0] = r == MSCOMP_OK ? len : 0;
+		return (r == MSCOMP_OK || r == MSCOMP_BUF_ERROR) ? MSCOMP_OK : r;
+	}
 	const size_t limit = batch_bytes(j.format, j.decompress);
 	std::vector<Batch> batches;
 	for (size_t i = u0; i < u1;) {                               // sub-batches: runs of units up to `limit` input bytes (a larger unit is one of its own)
