@@ -32,6 +32,21 @@ def test_two_ranks_share_the_gpu():
     assert line["config"]["lznt1_parity_checked"] is True and line["value"] > 0
 
 
+def test_two_ranks_launched_the_drivers_way():
+    """the launch line the driver uses for N > 1 (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...): bench.py is then one of the ranks and must not spawn again; rank 0 prints the one line"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-extra"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["parity_checked"] == {"lznt1": True} and line["value"] > 0
+
+
 def test_three_ranks_all_codecs():
     """three ranks (an uneven split of the 192 / 51 824 units), all three codecs: only rank 0's shard starts at a replica, the job totals must still add up"""
     line = _bench(["--gpus", "3", "--oversubscribe", "--steps", "1", "--warmup", "0", "--no-cpu", "--config5-only"])
