@@ -219,7 +219,7 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 	auto fail = [&](MSCompStatus r) { std::lock_guard<std::mutex> lk(mu); if (failed == MSCOMP_OK) { failed = r; } cv.notify_all(); };
 	auto is_failed = [&]() { std::lock_guard<std::mutex> lk(mu); return failed != MSCOMP_OK; };
 
-	std::thread uploader([&] {
+	auto up_fn = [&] {
 		if (hipSetDevice(w->device) != hipSuccess) { fail(MSCOMP_ERRNO); return; }
 		for (size_t k = 0; k < nb; ++k) {
 			const int s = (int)(k % nslots);
@@ -247,9 +247,9 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 			{ std::lock_guard<std::mutex> lk(mu); uploaded[k] = 1; }
 			cv.notify_all();
 		}
-	});
+	};
 
-	std::thread downloader([&] {
+	auto dn_fn = [&] {
 		if (hipSetDevice(w->device) != hipSuccess) { fail(MSCOMP_ERRNO); return; }
 		for (size_t k = 0; k < nb; ++k) {
 			const int s = (int)(k % nslots);
@@ -301,8 +301,12 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 			{ std::lock_guard<std::mutex> lk(mu); busy[s] = false; }
 			cv.notify_all();
 		}
-	});
+	};
 
+	// one sub-batch: the three stages one after the other on this thread (nothing to overlap, no threads to start)
+	const bool inline_stages = nb == 1;
+	std::thread uploader, downloader;
+	if (inline_stages) { up_fn(); } else { uploader = std::thread(up_fn); downloader = std::thread(dn_fn); }
 	for (size_t k = 0; k < nb; ++k) {                            // launcher
 		const int s = (int)(k % nslots);
 		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return uploaded[k] || failed != MSCOMP_OK; }); if (!uploaded[k]) { break; } }
@@ -320,7 +324,7 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 		{ std::lock_guard<std::mutex> lk(mu); launched[k] = 1; }
 		cv.notify_all();
 	}
-	uploader.join(); downloader.join();
+	if (inline_stages) { dn_fn(); } else { uploader.join(); downloader.join(); }
 	(void)hipStreamSynchronize(w->up); (void)hipStreamSynchronize(w->dn);
 	for (int s = 0; s < HB_SLOTS; ++s) { if (w->have[s]) { (void)hipStreamSynchronize(w->slot[s].ex); } }
 	for (auto& b : batches) { if (b.plan) { mscomp_amd_plan_destroy(b.plan); b.plan = nullptr; } }
