@@ -246,6 +246,9 @@ uint32_t     mscomp_amd_debug_lzd_walked(mscomp_amd_ctx* ctx);
  * lanes x {add, exchange}, keys drawn from nkeys <= 2048 values) that were served out of order: 0 on gfx950;
  * 0xFFFFFFFF if the check could not run. */
 uint32_t     mscomp_amd_debug_lds_lane_order(mscomp_amd_ctx* ctx, uint32_t seed, uint32_t blocks, uint32_t rounds, uint32_t nkeys);
+/* A device that serves them in another order is not refused: the two kernels then issue that atomic one lane at a time (the same bytes, a
+ * slower sort; csrc/kernels.h). Test hook: 1 = run that order-independent form on every device, 0 = back to the default. Process-wide. */
+void         mscomp_amd_debug_set_serial_atomics(int on);
 /* Version / build string of the library (includes the gfx target it was compiled for). */
 const char*  mscomp_amd_version(void);
 

@@ -176,8 +176,9 @@ size_t ms_max_compressed_size(MSCompFormat f, size_t n)
 
 // The LZNT1 bucket sort and the Xpress chain links are only bit-exact when the returning same-address LDS atomics of one
 // wave instruction are served in lane order (util.hip: lds_lane_order_kernel). That is how gfx950 behaves, but it is not an
-// architectural promise, so the library checks the device it is about to use -- once per device and process -- and refuses
-// (MSCOMP_ERRNO) to create a context on a device that fails: wrong bytes must never leave silently.
+// architectural promise, so the library checks the device it is about to use, once per device and process. A device that serves them in
+// another order gets the order-independent form of the two kernels (one lane at a time: kernels.h set_serial_atomics -- the same bytes,
+// a slower sort); a device on which the check cannot RUN is refused (MSCOMP_ERRNO): wrong bytes must never leave silently.
 static int lane_order_verdict(int device, hipStream_t st)
 {
 	static std::mutex mu;
@@ -192,7 +193,8 @@ static int lane_order_verdict(int device, hipStream_t st)
 			if (bad == 0) { bad = run_lds_lane_order_check(st, 0xC0FFEEu, 64, 64, 2048, d_bad); }
 			(void)hipFree(d_bad);
 		}
-		verdict[device] = bad == 0 ? 1 : -1;
+		verdict[device] = bad == 0 ? 1 : (bad == 0xFFFFFFFFu ? -1 : 2);             // 2 = runs, out of order: the serial form
+		if (verdict[device] == 2) { set_serial_atomics(device, 1); }
 	}
 	return verdict[device];
 }
@@ -205,7 +207,7 @@ MSCompStatus mscomp_amd_ctx_create(int device, void* hip_stream, mscomp_amd_ctx*
 	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { return MSCOMP_ERRNO; }
 	DeviceGuard g(device);
 	if (!g.ok) { return MSCOMP_ERRNO; }
-	if (lane_order_verdict(device, (hipStream_t)hip_stream) != 1) { return MSCOMP_ERRNO; }
+	if (lane_order_verdict(device, (hipStream_t)hip_stream) < 1) { return MSCOMP_ERRNO; }
 	mscomp_amd_ctx* c = new (std::nothrow) mscomp_amd_ctx();
 	if (!c) { return MSCOMP_MEM_ERROR; }
 	c->device = device; c->stream = (hipStream_t)hip_stream;
@@ -795,6 +797,9 @@ void mscomp_amd_debug_set_xpress_decoder(int mode) { g_xpd_mode.store(mode, std:
 void mscomp_amd_debug_set_finder(int mode) { g_finder_mode.store(mode, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 void mscomp_amd_debug_set_one_shot(int mode) { g_one_zero_copy.store(mode == 1 ? 0 : 1, std::memory_order_relaxed); }
 void mscomp_amd_debug_set_lznt1(int mode) { set_lznt1_mode(mode); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
+// Test hook: 1 = the order-independent form of the LZNT1 bucket sort and the Xpress chain links on every device (what a device that fails the
+// lane-order self-check gets), 0 = back to one atomic per 64 positions
+void mscomp_amd_debug_set_serial_atomics(int on) { set_serial_atomics(-1, on); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 
 // Hardware self-check (see util.hip): lanes whose returning LDS atomic was NOT served in lane order, summed over
 // blocks x rounds x 64 lanes x {add, exchange}; 0 on gfx950. 0xFFFFFFFF = the check could not run.

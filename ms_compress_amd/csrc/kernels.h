@@ -14,6 +14,14 @@ struct PerDeviceOnce {
 	void done() { int d = 0; (void)hipGetDevice(&d); seen[(d >> 6) & 3].fetch_or(1ull << (d & 63), std::memory_order_release); }
 };
 
+// ---- lane order of same-address LDS atomics (util.hip) ----
+// The LZNT1 bucket sort and the Xpress chain links hand out slots / links with ONE returning LDS atomic per 64 positions and need the
+// same-address atomics of that instruction served in lane order -- what gfx950 does, checked once per device (api.hip lane_order_verdict). On
+// a device that fails the check (or when the test hook says so) the same kernels issue the atomic one lane at a time, in a 64-step loop: DS
+// operations of a wave execute in program order, which IS architectural. Same bytes, slower sort.
+bool serial_atomics_on_current_device();
+void set_serial_atomics(int device, int on);           // on: 1 = one lane at a time, 0 = one instruction per 64 lanes; device < 0: every device
+
 // ---- LZNT1 (lznt1.hip) ----
 #define LZNT1_SLOT 4352u     // scratch bytes per 4 KiB chunk image (2 B header + <=4096 B payload + emit slack)
 void set_lznt1_mode(int mode);

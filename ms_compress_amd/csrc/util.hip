@@ -5,6 +5,7 @@
 // "sizes -> exclusive scan -> copy/encode at the final offset".
 #include "common.h"
 #include "kernels.h"
+#include <atomic>
 
 namespace msc {
 
@@ -186,6 +187,18 @@ __global__ __launch_bounds__(64) void lds_lane_order_kernel(uint32_t seed, uint3
 		__syncthreads();
 	}
 	if (nbad) { atomicAdd(bad, nbad); }
+}
+
+static std::atomic<int> g_serial_atomics[64];
+bool serial_atomics_on_current_device()
+{
+	int d = 0;
+	if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return false; }
+	return g_serial_atomics[d < 64 ? d : 63].load(std::memory_order_relaxed) != 0;
+}
+void set_serial_atomics(int device, int on)
+{
+	for (int d = 0; d < 64; ++d) { if (device < 0 || d == (device < 64 ? device : 63)) { g_serial_atomics[d].store(on ? 1 : 0, std::memory_order_relaxed); } }
 }
 
 uint32_t run_lds_lane_order_check(hipStream_t st, uint32_t seed, uint32_t blocks, uint32_t rounds, uint32_t nkeys, uint32_t* d_bad)

@@ -76,6 +76,7 @@ __device__ __forceinline__ uint32_t first_diff16(const uint4 x) { return first_n
 // lane order (gfx950 behaviour, tools/dev/lds_order_test.hip; every parity test depends on it), so each position
 // receives exactly the most recent earlier position with its hash: the chain link of XpressDictionary.h:120-135.
 // No conflict detection, no head gather/scatter pairs: 8 exchanges in flight, links leave as coalesced u16 stores.
+template <bool serial>    // serial: the exchange one lane at a time (kernels.h set_serial_atomics); a template so that the default kernel is the code it was
 __global__ __launch_bounds__(1024) void xp_links_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                       uint16_t* __restrict__ links, uint16_t* __restrict__ lasthead, uint32_t chunk_base)
 {
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(1024) void xp_links_kernel(const uint8_t* __restric
 			const uint32_t pbase = tbase - 4096u;
 			const uint32_t tn = (ins - pbase < 4096u) ? ins - pbase : 4096u;
 			const uint16_t* const hs = s_hash + ((t - 1u) & 1u) * 4096u;
-			if (XL_NC == 1u && tn == 4096u) {
+			if (XL_NC == 1u && tn == 4096u && !serial) {
 				// full tile, single consumer: nothing to mask -- per batch one hash read, one exchange, one link store
 				for (uint32_t b0 = 0; b0 < 64u; b0 += XL_FLIGHT) {
 					uint32_t h[XL_FLIGHT], old[XL_FLIGHT];
@@ -149,7 +150,14 @@ __global__ __launch_bounds__(1024) void xp_links_kernel(const uint8_t* __restric
 				for (int j = 0; j < 8; ++j) {
 					const uint32_t r = (b0 + j) * 64u + lane;
 					old[j] = 0xFFFFu;
-					if (r < tn && (h[j] & (XL_NC - 1u)) == wv) { old[j] = __hip_atomic_exchange(&s_head[h[j]], pbase + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+					const bool act = r < tn && (h[j] & (XL_NC - 1u)) == wv;
+					if (!serial) { if (act) { old[j] = __hip_atomic_exchange(&s_head[h[j]], pbase + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); } }
+					else {    // one lane at a time, in lane order (kernels.h): DS operations of a wave execute in program order
+						for (uint32_t l = 0; l < 64u; ++l) {
+							if (lane == l && act) { old[j] = __hip_atomic_exchange(&s_head[h[j]], pbase + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+							__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+						}
+					}
 				}
 				#pragma unroll
 				for (int j = 0; j < 8; ++j) {
@@ -343,8 +351,13 @@ void launch_xp_links_range(hipStream_t st, const uint8_t* d_in, const BatchTable
 	if (chunk_count == 0) { return; }
 	const uint32_t lds = XL_LDS_BYTES;
 	static PerDeviceOnce attr;
-	if (attr.needed()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_links_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr.done(); }
-	hipLaunchKernelGGL(xp_links_kernel, dim3(chunk_count), dim3(1024), lds, st, d_in, bt, links, lasthead, chunk_base);
+	if (attr.needed()) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_links_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(xp_links_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		attr.done();
+	}
+	if (serial_atomics_on_current_device()) { hipLaunchKernelGGL(xp_links_kernel<true>, dim3(chunk_count), dim3(1024), lds, st, d_in, bt, links, lasthead, chunk_base); }
+	else { hipLaunchKernelGGL(xp_links_kernel<false>, dim3(chunk_count), dim3(1024), lds, st, d_in, bt, links, lasthead, chunk_base); }
 }
 void launch_xp_links(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead)
 {

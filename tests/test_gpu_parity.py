@@ -479,3 +479,25 @@ def test_one_shot_with_a_terabyte_of_capacity(oracle, gpu_ctx, fmt):
         # (the reference refuses its own compression of the empty buffer, FF FF FF FF, as Xpress input: xpress_decompress.cpp:414-417)
         assert st == est and (st != 0 or (n.value == len(data) and back.raw[: n.value] == data)), (fmt, len(data), st, est)
         assert st == 0 or (fmt == 3 and len(data) == 0)
+
+
+def test_order_independent_form_of_the_sort_and_the_links(oracle, gpu_ctx):
+    """what a device gets that does NOT serve same-address LDS atomics of one instruction in lane order: the LZNT1 bucket
+    sort (both chunk kernels) and the Xpress chain links issue their returning atomic one lane at a time. Forced through the test hook: the same
+    bytes as the checker's on the edge families and on a corpus slice with long units (several link chunks, previous-chunk chains)."""
+    import ms_compress_amd as m
+    from ms_compress_amd import corpus
+    lib = m.load_library()
+    units = cases.edge_cases()[::3] + [cases.mixed_buffer(), corpus.by_name("samba", 400_000).tobytes(), corpus.by_name("nci", 300_000).tobytes()]
+    lib.mscomp_amd_debug_set_serial_atomics(1)
+    try:
+        for fmt in (2, 3, 4):
+            for lz in ((1, 2) if fmt == 2 else (0,)):
+                lib.mscomp_amd_debug_set_lznt1(lz)
+                got, st = m.compress_units(fmt, units)
+                for i, (u, g, s_) in enumerate(zip(units, got, st)):
+                    es, exp = oracle.oracle_compress(fmt, u)
+                    assert s_ == 0 and es == 0 and g == exp, (fmt, lz, i, len(u))
+    finally:
+        lib.mscomp_amd_debug_set_lznt1(0)
+        lib.mscomp_amd_debug_set_serial_atomics(0)
