@@ -44,7 +44,7 @@ PROFILE_TAG = "r04"              # the committed profiles the PMC / SQ figures a
 # the kernel SYMBOL behind the library's timer name of each codec's dominant kernel (template instance included, so that the
 # PMC figures of the Xpress and the Xpress+Huffman match finder are never mixed up)
 SYMBOLS = {
-    (2, "lznt1_chunk_kernel"): "msc::lznt1_chunk4_kernel",
+    (2, "lznt1_chunk_kernel"): "msc::lznt1_chunk4_kernel<false>",
     (3, "xp_find_kernel"): "msc::xp_find_kernel<8192u, 8192u, 512u, 4096u>",
     (4, "xp_find_kernel"): "msc::xp_find_kernel<65536u, 0u, 1024u, 8192u>",
     (3, "xp_lazy2_kernel"): "msc::xp_lazy2_kernel<16384u, 32u, 4u>",

@@ -235,7 +235,8 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 
 // One returning LDS atomic for the 64 positions of a batch; `serial`: the same, one lane at a time in lane order (kernels.h: a device whose
 // same-address atomics are not served in lane order -- DS operations of a wave execute in program order)
-__device__ __forceinline__ uint32_t lz_ordered_add(uint32_t* addr, uint32_t v, bool active, int serial, uint32_t lane)
+template <bool serial>
+__device__ __forceinline__ uint32_t lz_ordered_add(uint32_t* addr, uint32_t v, bool active, uint32_t lane)
 {
 	uint32_t old = 0;
 	if (!serial) { if (active) { old = __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); } }
@@ -243,8 +244,9 @@ __device__ __forceinline__ uint32_t lz_ordered_add(uint32_t* addr, uint32_t v, b
 	return old;
 }
 
+template <bool serial>    // (a template, not an argument: the default kernels are the code they were)
 __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
-                                                        uint8_t* __restrict__ slots, uint32_t* __restrict__ slot_size, int serial)
+                                                        uint8_t* __restrict__ slots, uint32_t* __restrict__ slot_size)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t  s_data[4096 + 32];
 	__shared__ __attribute__((aligned(16))) uint16_t s_cnt[LZ_TBL];       // counts -> bucket ends
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 			{
 				const bool act = p + 2u < n;
 				const uint32_t h = lz_hash(ld32(s_data + (act ? p : 0u)) & 0xFFFFFFu);
-				const uint32_t old = lz_ordered_add(reinterpret_cast<uint32_t*>(s_cnt) + (h >> 1), (h & 1u) ? 0x10000u : 1u, act, serial, lane);
+				const uint32_t old = lz_ordered_add<serial>(reinterpret_cast<uint32_t*>(s_cnt) + (h >> 1), (h & 1u) ? 0x10000u : 1u, act, lane);
 				r = act ? ((h & 1u) ? old >> 16 : old & 0xFFFFu) : 0u;
 			}
 		}
@@ -432,8 +434,9 @@ __device__ __forceinline__ uint32_t lz4_seg_start(uint32_t j) { return j == 0 ? 
 __device__ unsigned long long g_lz4_prof[8];
 extern "C" void mscomp_amd_debug_lz4_prof(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lz4_prof), 64); unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lz4_prof), z, 64); }
 #endif
+template <bool serial>
 __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
-                                                          uint8_t* __restrict__ slots, uint32_t* __restrict__ slot_size, int serial)
+                                                          uint8_t* __restrict__ slots, uint32_t* __restrict__ slot_size)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t  s_data[4096 + 32];
 	__shared__ __attribute__((aligned(16))) uint16_t s_cnt[LZ_TBL];       // counts -> bucket ends; after the parse: prefixes and flags (below)
@@ -521,7 +524,7 @@ __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __rest
 			for (int j = 0; j < 8; ++j) { h[j] = lz_hash(lds_ld32(s_data, ((b0 + j) * 64u + lane) & 4095u) & 0xFFFFFFu); }
 			#pragma unroll
 			for (int j = 0; j < 8; ++j) {
-				old[j] = lz_ordered_add(reinterpret_cast<uint32_t*>(s_cnt) + (h[j] >> 1), (h[j] & 1u) ? 0x10000u : 1u, (b0 + j) * 64u + lane + 2u < n, serial, lane);
+				old[j] = lz_ordered_add<serial>(reinterpret_cast<uint32_t*>(s_cnt) + (h[j] >> 1), (h[j] & 1u) ? 0x10000u : 1u, (b0 + j) * 64u + lane + 2u < n, lane);
 			}
 			#pragma unroll
 			for (int j = 0; j < 8; ++j) {
@@ -664,9 +667,14 @@ void launch_lznt1_chunks(hipStream_t st, const uint8_t* d_in, const BatchTables&
 {
 	if (bt.n_chunks == 0) { return; }
 	const int mode = g_lznt1_mode ? g_lznt1_mode : 2;                 // four waves per chunk: 1.43 vs 1.74 ms on the headline workload
-	const int serial = serial_atomics_on_current_device() ? 1 : 0;
-	if (mode == 1) { hipLaunchKernelGGL(lznt1_chunk_kernel, dim3(bt.n_chunks), dim3(64), 0, st, d_in, bt, slots, slot_size, serial); }
-	else { hipLaunchKernelGGL(lznt1_chunk4_kernel, dim3(bt.n_chunks), dim3(256), 0, st, d_in, bt, slots, slot_size, serial); }
+	const bool serial = serial_atomics_on_current_device();
+	if (mode == 1) {
+		if (serial) { hipLaunchKernelGGL(lznt1_chunk_kernel<true>, dim3(bt.n_chunks), dim3(64), 0, st, d_in, bt, slots, slot_size); }
+		else { hipLaunchKernelGGL(lznt1_chunk_kernel<false>, dim3(bt.n_chunks), dim3(64), 0, st, d_in, bt, slots, slot_size); }
+	} else {
+		if (serial) { hipLaunchKernelGGL(lznt1_chunk4_kernel<true>, dim3(bt.n_chunks), dim3(256), 0, st, d_in, bt, slots, slot_size); }
+		else { hipLaunchKernelGGL(lznt1_chunk4_kernel<false>, dim3(bt.n_chunks), dim3(256), 0, st, d_in, bt, slots, slot_size); }
+	}
 }
 
 } // namespace msc
