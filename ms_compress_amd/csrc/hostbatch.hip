@@ -157,7 +157,7 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 	// PCIe: 2.1 ms for 51 MB against 3.0 ms through a staged sub-batch)
 	if (u1 - u0 == 1 && !j.decompress && j.format == MSCOMP_LZNT1 && j.in_lens[u0] >= ((size_t)36 << 20)) {
 		size_t len = j.out_caps[u0];
-		const MSCompStatus r = ms_compress(j.format, j.in_ptrs[u0], j.in_lens[u0], j.out_ptrs[u0], &len);
+		const MSCompStatus r = lznt1_compress(j.in_ptrs[u0], j.in_lens[u0], j.out_ptrs[u0], &len);   // (the codec's own entry: exists in every build flavour of the library)
 		j.statuses[u0] = r; j.out_lens[u0] = r == MSCOMP_OK ? len : 0;
 		return (r == MSCOMP_OK || r == MSCOMP_BUF_ERROR) ? MSCOMP_OK : r;
 	}
@@ -333,7 +333,9 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 	if (failed == MSCOMP_OK) {                                   // the few units that need more room than 16 x their input: the one-shot decoder (it grows its staging: api.hip one_shot)
 		for (size_t u : again) {
 			size_t len = j.out_caps[u];
-			const MSCompStatus r = ms_decompress(j.format, j.in_ptrs[u], j.in_lens[u], j.out_ptrs[u], &len);
+			const MSCompStatus r = j.format == MSCOMP_LZNT1 ? lznt1_decompress(j.in_ptrs[u], j.in_lens[u], j.out_ptrs[u], &len)
+			                     : j.format == MSCOMP_XPRESS ? xpress_decompress(j.in_ptrs[u], j.in_lens[u], j.out_ptrs[u], &len)
+			                                                 : xpress_huff_decompress(j.in_ptrs[u], j.in_lens[u], j.out_ptrs[u], &len);
 			j.statuses[u] = r; j.out_lens[u] = r == MSCOMP_OK ? len : 0;
 		}
 	}
