@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 REPLICAS = 16                # BASELINE.json configs[4]
-PROFILE_TAG = "r04"              # the committed profiles the PMC / SQ figures are looked up in; a missing file falls back to r03 and says so
+PROFILE_TAG = "r05"              # the committed profiles the PMC / SQ figures are looked up in; a missing file falls back to the round before and says so
 # the kernel SYMBOL behind the library's timer name of each codec's dominant kernel (template instance included, so that the
 # PMC figures of the Xpress and the Xpress+Huffman match finder are never mixed up)
 SYMBOLS = {
@@ -254,7 +254,7 @@ def timed(job, steps, warmup, sharding):
 # ---------------------------------------------------------------- roofline ----------------------------------------------------------------
 def _profile_doc(name):
     """(document, tag it came from): the current round's committed profile, else the round before's (and the line says which)"""
-    for tag in (PROFILE_TAG, "r03"):
+    for tag in (PROFILE_TAG, "r04"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, name)))), tag
         except Exception:
@@ -282,14 +282,15 @@ def secondary_bound(fmt, timer_name, workload_key):
     sym = SYMBOLS.get((fmt, timer_name))
     if not doc or not sym:
         return None
-    probes, ptag = _profile_doc("additive_probes")
+    probes, ptag = _profile_doc("probes")
     for wl in (workload_key, "single_gpu"):          # this workload's own counters when they were collected, else the single-GPU leg's (shares carry over, totals do not)
         rec = doc.get("workloads", {}).get(wl, {}).get(sym)
         if rec and rec.get("codec") == CODEC_OF[fmt]:
             out = dict(rec["derived"])
-            out["from"] = "profiles/%s_sq_counters.json, workload %s%s" % (tag, wl, "" if wl == workload_key else " (NOT this workload: shares of wave time carry over, totals do not)")
-            if probes and sym in probes:                 # what the kernel's time is made of, measured by adding instructions to its hot loop (more direct than busy counters)
-                out["additive_probes"] = {"from": "profiles/%s_additive_probes.json" % ptag, "reading": probes[sym]["reading"]}
+            out["from"] = "profiles/%s_sq_counters.json" % tag
+            out["workload"] = wl
+            if probes and sym in probes:                 # what the kernel's time is made of, measured by changing its hot loop: the table is in that file, not here
+                out["probes"] = "profiles/%s_probes.json" % ptag
             return out
     return None
 
@@ -308,7 +309,7 @@ def roofline(fmt, prof, in_bytes, out_bytes, steps, workload_key):
     traffic, traffic_tag = pmc_traffic(fmt, dom, workload_key)
     return {"bound": "hbm", "kernel": SYMBOLS.get((fmt, dom), dom), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "traffic_from": ("profiles/%s_pmc_traffic.json (rocprofv3 --pmc passes of this command, committed; not re-measured in this run)" % traffic_tag) if traffic else None,
+            "traffic_from": ("profiles/%s_pmc_traffic.json" % traffic_tag) if traffic else None,
             "hbm_read_frac": round(in_bytes / launches_per_step / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "kernel_ms_per_launch": round(per_launch_ms, 4), "launches_per_step": launches_per_step,
             "kernel_share_of_gpu_time": round(ms / tot_ms, 3) if tot_ms else None,
@@ -375,10 +376,18 @@ def cpu_baseline(fmt, cor, budget_s=10.0, sa_dict=False):
     fn = ref.ms_compress if ref is not None else None
     nthr = min(threads, len(ulen))
     dt1, st, _ = loader.time_units_ex(fn, fmt, blob, uoff, ulen, caps, nthr, 1)
+    busy = loader.load_oracle().orc_last_busy_seconds()
     assert bool((st == 0).all()), "the CPU baseline reported an error status"
     more = max(0, min(19, int(budget_s / 4 / max(dt1, 1e-3)) - 1))
-    dt = dt1 + (loader.time_units_ex(fn, fmt, blob, uoff, ulen, caps, nthr, more)[0] if more else 0.0)
+    dt = dt1
+    if more:
+        dt += loader.time_units_ex(fn, fmt, blob, uoff, ulen, caps, nthr, more)[0]
+        busy += loader.load_oracle().orc_last_busy_seconds()
     passes, sample = 1 + more, int(ulen.sum())
+    # the load-balanced figure: bytes x threads / thread-seconds spent inside ms_compress -- what these cores give when every thread always has
+    # a unit to take (a queue of many files); `value` is the SAME UNIT LIST as the GPU leg in one pass, whose whole-file legs last as long as
+    # the largest file on one core. Both are printed; a speed-up should be read against the balanced one.
+    balanced = sample * passes * nthr / max(busy, 1e-9) / 1e6
     k1 = 1 if fmt != 3 else min(64, len(ulen))         # single thread: the first file (its first 64 units for Xpress)
     s1 = int(ulen[:k1].sum())
     d1, st1, _ = loader.time_units_ex(fn, fmt, blob, uoff[:k1], ulen[:k1], caps[:k1], 1, 1)
@@ -386,6 +395,7 @@ def cpu_baseline(fmt, cor, budget_s=10.0, sa_dict=False):
     if p1 > 1:
         d1 += loader.time_units_ex(fn, fmt, blob, uoff[:k1], ulen[:k1], caps[:k1], 1, p1 - 1)[0]
     return {"value": round(sample * passes / dt / 1e6, 1), "unit": "MB/s", "cores": nthr, "host_cores": host_cores, "kind": kind,
+            "balanced_value": round(balanced, 1),
             "single_thread": {"value": round(s1 * p1 / d1 / 1e6, 1), "unit": "MB/s", "sample": "%d pass(es) over the first %d unit(s), %d B, one thread" % (p1, k1, s1)},
             "malloc": malloc,
             "sample": "%d pass(es) over %s: %d B per pass on %d threads" % (passes, what, sample, nthr)}
@@ -502,6 +512,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-extra", action="store_true", help="headline leg only")
     ap.add_argument("--config5-only", action="store_true", help="the three codecs over BASELINE configs[4], none of the other legs")
+    ap.add_argument("--full", action="store_true", help="print the whole document (every leg, every kernel) instead of the short line; it is written to bench_extra.json either way")
     ap.add_argument("--oversubscribe", action="store_true", help="TEST ONLY: let the N ranks share the visible GPUs (gloo for the timing reduction); "
                     "exercises the sharded multi-rank path on a 1-GPU box, the line is marked and is not an N-GPU measurement")
     args = ap.parse_args()
@@ -532,10 +543,10 @@ def main():
         "value": head["MB_per_s"], "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic" if corpus.source() == "synthetic" else corpus.source(),
-        "config": {"workload": "BASELINE configs[4], %s leg: %s; one %s block per chunk" % (args.codec, head["workload"], {2: "4 KiB", 3: "64 KiB", 4: "64 KiB"}[fmt]),
+        "config": {"workload": "BASELINE configs[4], %s: %s" % (args.codec, head["workload"]),
                    "bytes_per_step": cor.total * REPLICAS, "units": head["units"],
                    "bytes_rank0": head["bytes_rank0"], "compression_ratio": head["compression_ratio"],
-                   "parallelism": "shard-per-gpu x%d (sharding.shard_ranges: contiguous unit ranges balanced by bytes, no collective on the data path)" % world,
+                   "parallelism": "shard-per-gpu x%d, no data-path collective" % world,
                    "MiB_per_s": head["MiB_per_s"]},
         "roofline": head["roofline"],
         "parity_checked": {args.codec: head["parity_checked"]},
@@ -617,23 +628,45 @@ def main():
             if not args.no_cpu:
                 decf[codec]["cpu_baseline"] = cpu_decompress_baseline(f2, b2, whole=list(zip(o2, l2)))
         extra["decompress_files"] = decf
-    # all three codecs of the metric in the part of the line the driver keeps (flat scalars under `config`): MB/s, ms per step, roofline
-    # fraction of the codec's dominant kernel and the parity gate's verdict, BASELINE configs[4] on this many GPUs
+    # The line the driver parses: SHORT (< 4 KB), scalars only, no sentences. Everything else -- the other legs, every kernel's time,
+    # the secondary-bound counters -- goes to bench_extra.json beside this script (and gpurun_out/ when that exists, so that it travels back).
     legs = {args.codec: head}
     legs.update(extra.get("config5", {}))
     for codec, leg in legs.items():
         res["config"]["%s_MB_per_s" % codec] = leg["MB_per_s"]
         res["config"]["%s_ms_per_step" % codec] = leg["ms_per_step"]
         res["config"]["%s_roofline_frac" % codec] = (leg["roofline"] or {}).get("frac")
-        res["config"]["%s_hbm_read_frac" % codec] = (leg["roofline"] or {}).get("hbm_read_frac")
         res["config"]["%s_parity_checked" % codec] = leg["parity_checked"]
+        cb = res.get("cpu_baseline") if codec == args.codec else leg.get("cpu_baseline")
+        if cb:
+            res["config"]["%s_cpu_MB_per_s" % codec] = cb["value"]
+            res["config"]["%s_cpu_balanced_MB_per_s" % codec] = cb["balanced_value"]
     if extra.get("one_rank_of_8"):
         for codec, r in extra["one_rank_of_8"].items():
             res["config"]["%s_one_rank_of_8_rate_vs_whole_job" % codec] = r["rate_vs_whole_job_on_one_gpu"]
+    full = dict(res)
     if extra:
-        res["extra"] = extra
+        full["extra"] = extra
+    line = dict(res)
+    if res.get("roofline"):
+        line["roofline"] = {k: res["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_per_launch",
+                                                               "launches_per_step", "algorithmic_bytes_per_launch")}
+    if res.get("cpu_baseline"):
+        cb = res["cpu_baseline"]
+        line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "balanced_value": cb["balanced_value"],
+                                "single_thread_value": cb["single_thread"]["value"], "sample": cb["sample"][:160]}
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+            if os.path.isdir(d):
+                try:
+                    json.dump(full, open(os.path.join(d, "bench_extra.json"), "w"), indent=1)
+                except OSError:
+                    pass
+        if args.full:
+            line = full
+        text = json.dumps(line, separators=(",", ":"))
+        assert args.full or len(text) < 4096, "bench.py: the line grew to %d bytes; the driver needs it short" % len(text)
+        print(text, flush=True)
     ctx.close()
     if world > 1:
         torch.distributed.destroy_process_group()

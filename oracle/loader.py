@@ -57,6 +57,7 @@ def load_oracle():
         lib.orc_time_units_ex.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         lib.orc_time_units_ex.restype = C.c_double
+        lib.orc_last_busy_seconds.restype = C.c_double
         _oracle = lib
     return _oracle
 

@@ -896,6 +896,10 @@ double orc_time_units(void* fn, int format, const uint8_t* in, const uint64_t* i
  * job are the same 12 files) and are handed out one at a time in the order given (bench.py passes whole files longest first). */
 typedef struct { int format; const uint8_t* in; const uint64_t* in_off; const uint64_t* in_len; size_t n_units; uint8_t* out; const uint64_t* out_off;
                  const uint64_t* out_cap; uint64_t* out_len; int32_t* status; size_t next; pthread_mutex_t mu; one_shot_fn fn; } ex_job;
+/* seconds spent INSIDE fn, summed over the threads, by the last orc_time_units_ex call (all its passes): bytes x threads / this = the
+ * rate the same cores would give on a queue long enough to keep every thread busy (bench.py's load-balanced CPU figure) */
+static double orc_busy_seconds;
+double orc_last_busy_seconds(void) { return orc_busy_seconds; }
 static void* ex_worker(void* arg)
 {
 	ex_job* j = (ex_job*)arg;
@@ -905,8 +909,14 @@ static void* ex_worker(void* arg)
 		pthread_mutex_unlock(&j->mu);
 		if (i >= j->n_units) { return NULL; }
 		size_t ol = (size_t)j->out_cap[i];
+		struct timespec a, b;
+		clock_gettime(CLOCK_MONOTONIC, &a);
 		const int st = j->fn(j->format, j->in + j->in_off[i], (size_t)j->in_len[i], j->out + j->out_off[i], &ol);
+		clock_gettime(CLOCK_MONOTONIC, &b);
 		j->status[i] = st; j->out_len[i] = st == ORC_OK ? ol : 0;
+		pthread_mutex_lock(&j->mu);
+		orc_busy_seconds += (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+		pthread_mutex_unlock(&j->mu);
 	}
 }
 double orc_time_units_ex(void* fn, int format, const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, size_t n_units,
@@ -915,6 +925,7 @@ double orc_time_units_ex(void* fn, int format, const uint8_t* in, const uint64_t
 	struct timespec t0, t1;
 	if (threads < 1) { threads = 1; }
 	if (threads > 256) { threads = 256; }
+	orc_busy_seconds = 0.0;
 	clock_gettime(CLOCK_MONOTONIC, &t0);
 	for (int p = 0; p < passes; ++p) {
 		ex_job f = { format, in, in_off, in_len, n_units, out, out_off, out_cap, out_len, status, 0, PTHREAD_MUTEX_INITIALIZER, fn ? (one_shot_fn)fn : (one_shot_fn)orc_compress };

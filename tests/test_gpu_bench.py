@@ -22,6 +22,36 @@ def _bench(args, env=None, timeout=900):
     return json.loads(lines[0])
 
 
+def test_the_drivers_own_command_prints_one_short_parseable_line():
+    """EXACTLY what the driver runs at N = 1 (all legs, CPU baselines included; only K and W smaller): the last stdout line must parse, stay
+    under 4 KiB (the driver's record keeps the last 8 KB of stdout: round 4's 20 KB line was lost to it) and carry the headline objects;
+    the long document goes to bench_extra.json."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1"], cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout.rstrip("\n").splitlines()
+    assert len(r.stdout) < 8192 and len(out[-1]) < 4096, (len(r.stdout), len(out[-1]))
+    line = json.loads(out[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0 and line["unit"] == "MB/s"
+    assert "configs[4]" in line["config"]["workload"] and line["config"]["bytes_per_step"] == 3391017280
+    assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["bound"] == "hbm" and line["roofline"]["kernel_ms_per_launch"] > 0
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["balanced_value"] >= line["cpu_baseline"]["value"] * 0.5 and line["cpu_baseline"]["cores"] >= 1
+    assert line["parity_checked"] == {"lznt1": True, "xpress": True, "xpress_huff": True}
+    for codec in ("lznt1", "xpress", "xpress_huff"):
+        assert line["config"]["%s_MB_per_s" % codec] > 0 and 0 < line["config"]["%s_roofline_frac" % codec] < 1
+
+    def no_prose(x, where="line"):
+        if isinstance(x, dict):
+            for k, v in x.items():
+                no_prose(v, where + "." + k)
+        elif isinstance(x, str):
+            assert len(x) <= 200, (where, len(x))
+    no_prose(line)
+    full = json.load(open(os.path.join(ROOT, "bench_extra.json")))
+    assert full["value"] == line["value"] and "single_gpu" in full["extra"] and "decompress" in full["extra"]
+
+
 def test_two_ranks_share_the_gpu():
     """python bench.py --gpus 2 --oversubscribe: the sharded multi-rank path end to end (self-spawned ranks, gloo timing reduction,
     every rank's shard through the parity gate). One line, marked as a test run."""
