@@ -15,8 +15,13 @@
 //   * runs of units that lie back to back in
 //     the caller's memory travel as ONE copy each way (a file cut into 64 KiB units is one upload; outputs laid out capacity after capacity
 //     come back as one download of the range that holds streams), other units one copy each.
+//
+// This file is compiled WITH C++ exceptions (csrc/Makefile; the rest of the library is -fno-exceptions): it builds std::vector tables and
+// starts std::threads inside extern "C" entries, and an allocation or thread-creation failure there must come back as MSCOMP_MEM_ERROR,
+// not end the caller's process. Every thread body and both entries catch; threads that did start are always joined.
 #include "../../include/mscomp_amd.h"
 #include <hip/hip_runtime.h>
+#include <new>
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -55,7 +60,7 @@ struct Slot {
 	{
 		if (need <= *cap) { return true; }
 		if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
-		const size_t want = need + need / 8 + 256;
+		const size_t want = (need + need / 8 + 256 + 3) & ~(size_t)3;          // (a multiple of 4: the word-wise clears cover the whole buffer)
 		if (hipMalloc(p, want) != hipSuccess) { *p = nullptr; (void)hipGetLastError(); return false; }
 		*cap = want; return true;
 	}
@@ -150,12 +155,15 @@ size_t batch_bytes(MSCompFormat format, bool decompress)
 //                in flight overlap on the GPU (the serial stages of a small batch are latency-bound: one wave per unit / chunk);
 //   downloader : results + streams of sub-batch i device -> host when its kernels are through, then the slot is free again.
 // A sub-batch's download therefore runs under the kernels of the ones behind it and its upload under those in front of it.
-MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
+MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1, bool on_calling_thread)
 {
 	if (hipSetDevice(w->device) != hipSuccess) { return MSCOMP_ERRNO; }
 	// ONE large LZNT1 unit: the one-shot call has the better path for it (the caller's buffers mapped, one launch reading and writing them over
 	// PCIe: 2.1 ms for 51 MB against 3.0 ms through a staged sub-batch)
-	if (u1 - u0 == 1 && !j.decompress && j.format == MSCOMP_LZNT1 && j.in_lens[u0] >= ((size_t)36 << 20)) {
+	// Only on the CALLING thread (range 0): the one-shot call keeps its context, streams and staging in thread-local storage, which a
+	// range thread started for this call would build and tear down again (ms-scale, with device-wide waits that stall the other ranges).
+	// MSCOMP_AMD_HOST_BATCH_MB / MSCOMP_AMD_HOST_SLOTS do not apply on this path.
+	if (on_calling_thread && u1 - u0 == 1 && !j.decompress && j.format == MSCOMP_LZNT1 && j.in_lens[u0] >= ((size_t)36 << 20)) {
 		size_t len = j.out_caps[u0];
 		const MSCompStatus r = lznt1_compress(j.in_ptrs[u0], j.in_lens[u0], j.out_ptrs[u0], &len);   // (the codec's own entry: exists in every build flavour of the library)
 		j.statuses[u0] = r; j.out_lens[u0] = r == MSCOMP_OK ? len : 0;
@@ -219,7 +227,7 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 	auto fail = [&](MSCompStatus r) { std::lock_guard<std::mutex> lk(mu); if (failed == MSCOMP_OK) { failed = r; } cv.notify_all(); };
 	auto is_failed = [&]() { std::lock_guard<std::mutex> lk(mu); return failed != MSCOMP_OK; };
 
-	auto up_fn = [&] {
+	auto up_body = [&] {
 		if (hipSetDevice(w->device) != hipSuccess) { fail(MSCOMP_ERRNO); return; }
 		for (size_t k = 0; k < nb; ++k) {
 			const int s = (int)(k % nslots);
@@ -249,7 +257,7 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 		}
 	};
 
-	auto dn_fn = [&] {
+	auto dn_body = [&] {
 		if (hipSetDevice(w->device) != hipSuccess) { fail(MSCOMP_ERRNO); return; }
 		for (size_t k = 0; k < nb; ++k) {
 			const int s = (int)(k % nslots);
@@ -297,16 +305,27 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 			}
 			mscomp_amd_plan_destroy(b.plan); b.plan = nullptr;         // (its tables go back to the slot's context: no hipFree on this path)
 			// zeros again where this batch's streams were (stream-ordered in front of the slot's next kernels, under the other slots' work)
-			if (b.out_total && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sl->d_out), 0, ((size_t)b.out_total + 3) / 4, sl->ex) != hipSuccess) { fail(MSCOMP_ERRNO); return; }
+			// (the kernels may write into the 64 bytes of slack behind the last stream: they are cleared too, so that a later, larger batch in this slot
+			// never carries another call's bytes into the caller's inter-stream slack)
+			const size_t clr = std::min(sl->out_cap, (size_t)b.out_total + 64u);
+			if (clr && hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sl->d_out), 0, (clr + 3) / 4, sl->ex) != hipSuccess) { fail(MSCOMP_ERRNO); return; }
 			{ std::lock_guard<std::mutex> lk(mu); busy[s] = false; }
 			cv.notify_all();
 		}
 	};
 
+	// (a thread body must not let an exception out: std::bad_alloc from a table that grows becomes the range's MSCOMP_MEM_ERROR)
+	auto up_fn = [&] { try { up_body(); } catch (const std::bad_alloc&) { fail(MSCOMP_MEM_ERROR); } catch (...) { fail(MSCOMP_ERRNO); } };
+	auto dn_fn = [&] { try { dn_body(); } catch (const std::bad_alloc&) { fail(MSCOMP_MEM_ERROR); } catch (...) { fail(MSCOMP_ERRNO); } };
 	// one sub-batch: the three stages one after the other on this thread (nothing to overlap, no threads to start)
 	const bool inline_stages = nb == 1;
 	std::thread uploader, downloader;
-	if (inline_stages) { up_fn(); } else { uploader = std::thread(up_fn); downloader = std::thread(dn_fn); }
+	if (inline_stages) { up_fn(); }
+	else {
+		try { uploader = std::thread(up_fn); downloader = std::thread(dn_fn); }
+		catch (...) { fail(MSCOMP_MEM_ERROR); }                     // the system refused a thread: whichever started sees `failed` and returns; both are joined below
+	}
+	try {
 	for (size_t k = 0; k < nb; ++k) {                            // launcher
 		const int s = (int)(k % nslots);
 		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return uploaded[k] || failed != MSCOMP_OK; }); if (!uploaded[k]) { break; } }
@@ -324,7 +343,8 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1)
 		{ std::lock_guard<std::mutex> lk(mu); launched[k] = 1; }
 		cv.notify_all();
 	}
-	if (inline_stages) { dn_fn(); } else { uploader.join(); downloader.join(); }
+	} catch (const std::bad_alloc&) { fail(MSCOMP_MEM_ERROR); } catch (...) { fail(MSCOMP_ERRNO); }
+	if (inline_stages) { dn_fn(); } else { if (uploader.joinable()) { uploader.join(); } if (downloader.joinable()) { downloader.join(); } }
 	(void)hipStreamSynchronize(w->up); (void)hipStreamSynchronize(w->dn);
 	for (int s = 0; s < HB_SLOTS; ++s) { if (w->have[s]) { (void)hipStreamSynchronize(w->slot[s].ex); } }
 	for (auto& b : batches) { if (b.plan) { mscomp_amd_plan_destroy(b.plan); b.plan = nullptr; } }
@@ -362,6 +382,7 @@ static MSCompStatus units_host(MSCompFormat format, bool decompress, int n_dev, 
 	for (size_t i = 0; i < n_units; ++i) { if ((in_lens[i] && !in_ptrs[i]) || (out_caps[i] && !out_ptrs[i])) { return MSCOMP_ARG_ERROR; } statuses[i] = MSCOMP_ERRNO; out_lens[i] = 0; }
 	int prev = 0;
 	if (hipGetDevice(&prev) != hipSuccess) { return MSCOMP_ERRNO; }             // no GPU / no HIP runtime: fail loudly, there is no CPU encoder here
+	try {
 	int ndev_sys = 0;
 	if (hipGetDeviceCount(&ndev_sys) != hipSuccess) { return MSCOMP_ERRNO; }
 	std::vector<int> dev(n_dev);
@@ -383,19 +404,28 @@ static MSCompStatus units_host(MSCompFormat format, bool decompress, int n_dev, 
 	const Job job = { format, decompress, n_units, in_ptrs, in_lens, out_ptrs, out_caps, out_lens, statuses };
 	std::vector<MSCompStatus> res(n_dev, MSCOMP_OK);
 	std::vector<std::thread> threads;
+	threads.reserve((size_t)n_dev);
+	struct JoinAll { std::vector<std::thread>& t; ~JoinAll() { for (auto& x : t) { if (x.joinable()) { x.join(); } } } } join_all{threads};   // also when an exception unwinds this frame
 	auto body = [&](int r) {
-		if (cuts[r] == cuts[r + 1]) { return; }
-		Worker* w = take_worker(dev[r]);
-		if (!w) { res[r] = MSCOMP_ERRNO; return; }
-		res[r] = run_range(w, job, cuts[r], cuts[r + 1]);
-		if (res[r] == MSCOMP_OK) { give_worker(w); } else { w->destroy(); delete w; }   // (a range that failed may leave a sticky HIP error or half-grown buffers behind: its worker is not reused)
+		try {
+			if (cuts[r] == cuts[r + 1]) { return; }
+			Worker* w = take_worker(dev[r]);
+			if (!w) { res[r] = MSCOMP_ERRNO; return; }
+			try { res[r] = run_range(w, job, cuts[r], cuts[r + 1], r == 0); }
+			catch (const std::bad_alloc&) { res[r] = MSCOMP_MEM_ERROR; } catch (...) { res[r] = MSCOMP_ERRNO; }
+			if (res[r] == MSCOMP_OK) { give_worker(w); } else { w->destroy(); delete w; }   // (a range that failed may leave a sticky HIP error or half-grown buffers behind: its worker is not reused)
+		} catch (const std::bad_alloc&) { res[r] = MSCOMP_MEM_ERROR; } catch (...) { res[r] = MSCOMP_ERRNO; }
 	};
-	for (int r = 1; r < n_dev; ++r) { threads.emplace_back(body, r); }
+	int started = 1;
+	try { for (int r = 1; r < n_dev; ++r) { threads.emplace_back(body, r); ++started; } }
+	catch (...) { for (int r = started; r < n_dev; ++r) { res[r] = MSCOMP_MEM_ERROR; } }   // the system refused a thread: the ranges that have none report it, the others finish
 	body(0);                                                         // range 0 on the calling thread
 	for (auto& t : threads) { t.join(); }
 	(void)hipSetDevice(prev);
 	for (int r = 0; r < n_dev; ++r) { if (res[r] != MSCOMP_OK) { return res[r]; } }
 	return MSCOMP_OK;
+	} catch (const std::bad_alloc&) { (void)hipSetDevice(prev); return MSCOMP_MEM_ERROR; }
+	catch (...) { (void)hipSetDevice(prev); return MSCOMP_ERRNO; }
 }
 
 MSCompStatus mscomp_amd_compress_units_host(MSCompFormat format, int n_dev, const int* devices, size_t n_units,

@@ -20,7 +20,7 @@ struct PerDeviceOnce {
 // a device that fails the check (or when the test hook says so) the same kernels issue the atomic one lane at a time, in a 64-step loop: DS
 // operations of a wave execute in program order, which IS architectural. Same bytes, slower sort.
 bool serial_atomics_on_current_device();
-void set_serial_atomics(int device, int on);           // on: 1 = one lane at a time, 0 = one instruction per 64 lanes; device < 0: every device
+void set_serial_atomics(int device, int on);           // on: 1 = one lane at a time. device >= 0: that device's self-check verdict; device < 0: the process-wide test hook (its 0 does NOT clear a verdict)
 
 // ---- LZNT1 (lznt1.hip) ----
 #define LZNT1_SLOT 4352u     // scratch bytes per 4 KiB chunk image (2 B header + <=4096 B payload + emit slack)

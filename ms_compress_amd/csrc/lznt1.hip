@@ -119,6 +119,9 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 	for (uint32_t j = 0; j <= LZ_SELF; ++j) { q[j] = s_bucket[(s + j) & 4095u]; }
 	#pragma unroll
 	for (uint32_t j = 0; j <= LZ_SELF; ++j) { if (s + j >= e) { q[j] = 4096u; } }                          // 4096 = none (>= p)
+#if defined(LZ_PROBE) && LZ_PROBE == 5      /* dev probe (SUBTRACTIVE, not bit-exact): the eager scan of the odd windows is skipped (their positions are literals unless finished) */
+	if (!((wbase >> 6) & 1u))
+#endif
 	#pragma unroll
 	for (uint32_t j = 0; j < LZ_SELF; j += 4u) {
 		uint4 c[4];
@@ -141,6 +144,9 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 	{ _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) { const uint4 y_ = lds_ld128(s_data, (p * 7u + 64u * q_) & 4095u); asm volatile("" :: "v"(y_.x), "v"(y_.y), "v"(y_.z), "v"(y_.w)); } }
 #endif
 	bool unres = !done && q[LZ_SELF] < p;                    // a 9th older candidate exists and max_len was not reached
+#if defined(LZ_PROBE) && LZ_PROBE == 6      /* dev probe (SUBTRACTIVE, not bit-exact): no position is ever finished by the wave -- the 4 eager candidates are all there is */
+	unres = false;
+#endif
 	// 2. greedy walk; positions with rem != 0 are finished by the whole wave when (and only when) the walk lands on them
 	u64 un = __ballot(unres);                                // unresolved positions
 	u64 mm = __ballot(!unres && (key >> 12) >= 3u);          // resolved positions that have a match

@@ -189,16 +189,22 @@ __global__ __launch_bounds__(64) void lds_lane_order_kernel(uint32_t seed, uint3
 	if (nbad) { atomicAdd(bad, nbad); }
 }
 
-static std::atomic<int> g_serial_atomics[64];
+// Two sources, kept apart: the device's own self-check (per device, set once by api.hip lane_order_verdict, never cleared) and
+// the test hook (process-wide, mscomp_amd_debug_set_serial_atomics). The hook's "off" only withdraws the hook: a device that failed its
+// check keeps the order-independent kernels -- wrong bytes must never leave silently.
+static std::atomic<int> g_serial_verdict[64];
+static std::atomic<int> g_serial_forced;
 bool serial_atomics_on_current_device()
 {
+	if (g_serial_forced.load(std::memory_order_relaxed) != 0) { return true; }
 	int d = 0;
 	if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return false; }
-	return g_serial_atomics[d < 64 ? d : 63].load(std::memory_order_relaxed) != 0;
+	return g_serial_verdict[d < 64 ? d : 63].load(std::memory_order_relaxed) != 0;
 }
-void set_serial_atomics(int device, int on)
+void set_serial_atomics(int device, int on)            // device >= 0: that device's verdict; device < 0: the process-wide hook
 {
-	for (int d = 0; d < 64; ++d) { if (device < 0 || d == (device < 64 ? device : 63)) { g_serial_atomics[d].store(on ? 1 : 0, std::memory_order_relaxed); } }
+	if (device < 0) { g_serial_forced.store(on ? 1 : 0, std::memory_order_relaxed); }
+	else { g_serial_verdict[device < 64 ? device : 63].store(on ? 1 : 0, std::memory_order_relaxed); }
 }
 
 uint32_t run_lds_lane_order_check(hipStream_t st, uint32_t seed, uint32_t blocks, uint32_t rounds, uint32_t nkeys, uint32_t* d_bad)

@@ -89,6 +89,7 @@ __device__ __forceinline__ uint32_t xh_parse_window(const ChunkGeom& g, const ui
 	// the first candidate at or after its end (relative to the window; >= wn leaves the window). The scalar loop is
 	// then one v_readlane per taken match; candidates the finder capped at 48 are extended on demand.
 	const uint32_t remL = g.cn - o;                              // bytes left in the chunk (>= 3 for a candidate)
+	const uint32_t Lin = L;                                      // what the finder's word holds
 	const bool cappedL = (L == 45u) && remL > 48u;
 	{ const uint32_t lc_ = (L + 3u < remL) ? L + 3u : remL; if (inr && off != 0) { L = lc_ - 3u; } }
 	const uint32_t nx = lane + L + 3u;
@@ -146,7 +147,8 @@ __device__ __forceinline__ uint32_t xh_parse_window(const ChunkGeom& g, const ui
 	const uint32_t reach = wave_incl_scan_max(mend);
 	const bool is_tok = o >= entry && inr && (is_m || reach <= lane);
 	const u64 tokmask = __ballot(is_tok);
-	if (is_m) { mlen3c[o] = (uint16_t)L; }
+	if (is_m && L != Lin) { mlen3c[o] = (uint16_t)L; }           // only a clipped or extended length is written back (round 4 rewrote every taken match: each
+	                                                             // scattered 2-byte store dirties a line the kernel has just read -- 13 GB of write-backs per pass)
 	if (lane == 0) { tokc[wbase >> 6] = tokmask; }
 	tokmask_out = tokmask; L_out = L;
 	return wbase + mp;
@@ -322,8 +324,24 @@ struct HuffLdsFast {
 // instruction issue -- 13 single-purpose waves per CU at the time, 24 now, ~200 instructions per merge step.)
 #define HH_SENT 0xFFFFFFFFu
 #define HH_ORDER() asm volatile("" ::: "memory")
+// Round 5: the kernel is bound by its SCALAR instructions (a CU has one scalar unit for all its waves; it ran at 0.66 instructions per cycle,
+// profiles/r04_sq_counters.json), so the two operations are written to need few of them (HH_DIET; 0 = the round-4 code): the eight choices
+// of the path are followed with s_bitcmp1_b64 + s_addc_u32 (i = 2 i + bit: 2 instructions per level, the compiler's shift / and / shift / or
+// took 4), the path reads are unconditional (lanes outside 1..8 compute slot 0 or 1: no exec masking) and the two predicated stores of an
+// operation are one. HH_DIET = 2: the follow by the vector unit instead (every lane computes the same path; 23 vector instructions, no scalar one).
+#ifndef HH_DIET
+#define HH_DIET 1
+#endif
 template <class H> __device__ __forceinline__ void hh_push(H& h, uint32_t hl_new, uint2 e, uint32_t lane)     // hl_new = slot of the new entry (heap length after the push)
 {
+#if HH_DIET
+	const uint2 par = h.heap[hl_new >> (lane & 31u)];              // lane l: ancestor l (0 = the sentinel in front of the heap, weight 0; lanes 10.. read slot 0 or a real slot: unused)
+	const u64 up = __ballot(lane - 1u < 9u && e.x < par.x) >> 1;
+	const uint32_t m = (uint32_t)__builtin_ctzll(~up);             // ancestors passed (heap[0] has weight 0: never passed)
+	// lanes 1..m move their ancestor one level down, lane 0 drops the item at hl_new >> m: one store
+	if (lane <= m) { h.heap[hl_new >> (lane ? lane - 1u : m)] = lane ? par : e; }
+	HH_ORDER();
+#else
 	const uint32_t a = hl_new >> lane;                             // lane l: ancestor l (0 = the sentinel in front of the heap, weight 0)
 	uint2 par = make_uint2(0u, 0u);
 	if (lane >= 1u && lane <= 9u) { par = h.heap[a]; }
@@ -332,6 +350,15 @@ template <class H> __device__ __forceinline__ void hh_push(H& h, uint32_t hl_new
 	if (lane >= 1u && lane <= m) { h.heap[hl_new >> (lane - 1u)] = par; }
 	if (lane == 0u) { h.heap[hl_new >> m] = e; }
 	HH_ORDER();
+#endif
+}
+template <int NQ, class H> __device__ __forceinline__ void hh_masks(H& h, uint32_t lane, u64 (&mask)[4])
+{
+	uint4 ch[NQ];
+	#pragma unroll
+	for (uint32_t q = 0; q < (uint32_t)NQ; ++q) { ch[q] = *reinterpret_cast<const uint4*>(&h.heap[2u * (64u * q + lane)]); }
+	#pragma unroll
+	for (uint32_t q = 0; q < (uint32_t)NQ; ++q) { mask[q] = __ballot(ch[q].z < ch[q].x); }
 }
 template <class H> __device__ __forceinline__ uint2 hh_pop(H& h, uint32_t hl_old, uint32_t lane)               // hl_old = heap length before the pop
 {
@@ -340,12 +367,54 @@ template <class H> __device__ __forceinline__ uint2 hh_pop(H& h, uint32_t hl_old
 	if (lane == 0u) { h.heap[hl_old] = make_uint2(HH_SENT, 0u); }
 	HH_ORDER();
 	// the smaller child of every inner node: node i = 64 q + lane reads its children 2 i, 2 i + 1 (one 16-byte aligned pair)
-	u64 mask[4];
-	uint4 ch[4];
-	#pragma unroll
-	for (uint32_t q = 0; q < 4u; ++q) { ch[q] = *reinterpret_cast<const uint4*>(&h.heap[2u * (64u * q + lane)]); }
-	#pragma unroll
-	for (uint32_t q = 0; q < 4u; ++q) { mask[q] = __ballot(ch[q].z < ch[q].x); }
+	u64 mask[4] = { 0, 0, 0, 0 };
+#if HH_DIET
+	// ... of every inner node that HAS children: node i has one iff 2 i <= the heap's length, so the nodes 64 q .. 64 q + 63 are only looked at
+	// while the heap holds at least 128 q entries (it shrinks from 512 to 1: 2.5 of the 4 KiB-reads per pop on average; the LDS pipe is what
+	// the kernel waits for once its scalar instructions are fewer)
+	if (hl_old >= 384u) { hh_masks<4>(h, lane, mask); } else if (hl_old >= 256u) { hh_masks<3>(h, lane, mask); }
+	else if (hl_old >= 128u) { hh_masks<2>(h, lane, mask); } else { hh_masks<1>(h, lane, mask); }
+#else
+	hh_masks<4>(h, lane, mask);
+#endif
+#if HH_DIET == 2
+	// the follow on the VECTOR unit (every lane computes the same path; no scalar instruction at all): 32-bit halves of the masks, bit i mod 32
+	uint32_t F;                                                    // -> 256..511: the path's node on the leaf level
+	asm volatile("v_mov_b32 %0, 1" : "=v"(F));                     // (opaque: keeps the chain in vector registers)
+	{
+		const uint32_t m0l = (uint32_t)mask[0], m0h = (uint32_t)(mask[0] >> 32), m1l = (uint32_t)mask[1], m1h = (uint32_t)(mask[1] >> 32);
+		const uint32_t m2l = (uint32_t)mask[2], m2h = (uint32_t)(mask[2] >> 32), m3l = (uint32_t)mask[3], m3h = (uint32_t)(mask[3] >> 32);
+		#pragma unroll
+		for (int s = 0; s < 5; ++s) { F = (F << 1) | ((m0l >> (F & 31u)) & 1u); }           // levels 0..4: nodes 1..31
+		F = (F << 1) | ((m0h >> (F & 31u)) & 1u);                                          // level 5: nodes 32..63
+		{ const uint32_t w = (F & 32u) ? m1h : m1l; F = (F << 1) | ((w >> (F & 31u)) & 1u); }   // level 6: nodes 64..127
+		{ const uint32_t wa = (F & 32u) ? m2h : m2l, wb = (F & 32u) ? m3h : m3l; const uint32_t w = (F & 64u) ? wb : wa; F = (F << 1) | ((w >> (F & 31u)) & 1u); }   // level 7: 128..255
+	}
+#elif HH_DIET
+	uint32_t F = 1;                                                // -> 256..511: the path's node on the leaf level
+	u64 mk_;                                                       // (scratch of the asm block: the mask word of level 7)
+	asm volatile(
+		"s_bitcmp1_b64 %[m0], %[i]\n\ts_addc_u32 %[i], %[i], %[i]\n\t"      // levels 0..5: nodes 1..63 (s_bitcmp1_b64 takes bit i mod 64)
+		"s_bitcmp1_b64 %[m0], %[i]\n\ts_addc_u32 %[i], %[i], %[i]\n\t"
+		"s_bitcmp1_b64 %[m0], %[i]\n\ts_addc_u32 %[i], %[i], %[i]\n\t"
+		"s_bitcmp1_b64 %[m0], %[i]\n\ts_addc_u32 %[i], %[i], %[i]\n\t"
+		"s_bitcmp1_b64 %[m0], %[i]\n\ts_addc_u32 %[i], %[i], %[i]\n\t"
+		"s_bitcmp1_b64 %[m0], %[i]\n\ts_addc_u32 %[i], %[i], %[i]\n\t"
+		"s_bitcmp1_b64 %[m1], %[i]\n\ts_addc_u32 %[i], %[i], %[i]\n\t"      // level 6: nodes 64..127
+		"s_bitcmp1_b32 %[i], 6\n\ts_cselect_b64 %[mk], %[m3], %[m2]\n\t"    // level 7: nodes 128..191 | 192..255
+		"s_bitcmp1_b64 %[mk], %[i]\n\ts_addc_u32 %[i], %[i], %[i]"
+		: [i] "+s"(F), [mk] "=&s"(mk_)
+		: [m0] "s"(mask[0]), [m1] "s"(mask[1]), [m2] "s"(mask[2]), [m3] "s"(mask[3])
+		: "scc");
+#endif
+#if HH_DIET
+	const uint2 k = h.heap[F >> ((8u - lane) & 31u)];              // lane l (1..8): path node l; the other lanes read slot 0 or 1 (unused)
+	const u64 stop = __ballot(lane - 1u < 8u && t.x < k.x);
+	const uint32_t m = stop ? (uint32_t)__builtin_ctzll(stop) : 9u;   // t comes to rest on level m - 1
+	// lanes 1..m-1 move their node one level up, lane 0 drops t at path node m - 1: one store
+	if (lane < m) { h.heap[F >> (9u - (lane ? lane : m))] = lane ? k : t; }
+	HH_ORDER();
+#else
 	uint32_t i = 1;
 	#pragma unroll
 	for (int s = 0; s < 6; ++s) { i = 2u * i + (uint32_t)((mask[0] >> i) & 1u); }          // levels 0..5: nodes 1..63
@@ -359,6 +428,7 @@ template <class H> __device__ __forceinline__ uint2 hh_pop(H& h, uint32_t hl_old
 	if (lane >= 1u && lane < m) { h.heap[F >> (9u - lane)] = k; }
 	if (lane == 0u) { h.heap[F >> (9u - m)] = t; }
 	HH_ORDER();
+#endif
 	return top;
 }
 
@@ -684,6 +754,95 @@ __global__ __launch_bounds__(64) void xh_encode_kernel(const uint8_t* __restrict
 #define XE_BURST_STORE() { _Pragma("unroll") for (int k_ = 0; k_ < XE_GRP; ++k_) { \
 		s_in_off[k_ * 64 + lane] = (uint16_t)g_off[k_]; s_in_len[k_ * 64 + lane] = (uint16_t)g_len[k_]; s_in_byte[k_ * 64 + lane] = (uint8_t)g_byte[k_]; } \
 		if (lane < (uint32_t)XE_GRP) { s_in_tok[lane] = g_tok; } }
+#ifndef XE_COMPACT
+#define XE_COMPACT 1
+#endif
+#if XE_COMPACT
+	// Round 5: a step works on 64 TOKENS, not on the 64 positions of a window. On the bench corpus a window holds 3-24 tokens (0.04-0.38 per
+	// byte), so the scans, the bit ORs and the word stores of a step ran with a fifth of the lanes; the tokens of a group of XE_GRP windows are
+	// first compacted -- token of rank r (mbcnt over the window masks) writes its place in the group to s_tokpos[r] -- and then taken 64 at a
+	// time in rank order, which is position order: everything behind the lane -> token mapping is the code it was.
+	static_assert(XE_GRP * 64 <= 256, "s_tokpos holds a position of the group in a byte");
+	__shared__ uint8_t s_tokpos[XE_GRP * 64];
+	if (nwin) { XE_BURST_LOAD(0u) }
+	const uint32_t ngrp = (nwin + (uint32_t)XE_GRP - 1u) / (uint32_t)XE_GRP;
+	for (uint32_t gi = 0; gi <= ngrp; ++gi) {
+		uint32_t ntok;
+		if (gi < ngrp) {                                          // publish this group's inputs, start loading the next, compact its tokens
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+			XE_BURST_STORE()
+			if ((gi + 1u) * (uint32_t)XE_GRP < nwin) { XE_BURST_LOAD((gi + 1u) * (uint32_t)XE_GRP * 64u) }
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+			uint32_t base = 0;
+			#pragma unroll
+			for (uint32_t k = 0; k < (uint32_t)XE_GRP; ++k) {
+				const u64 tm = __hip_atomic_load(&s_in_tok[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				if ((tm >> lane) & (u64)1) { s_tokpos[base + popc_below(tm)] = (uint8_t)(k * 64u + lane); }
+				base += (uint32_t)__popcll(tm);
+			}
+			ntok = xh_uniform(base);
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+		} else {
+			if (!g.last) { break; }
+			ntok = 1u;                                              // the EOS token of the unit's last chunk (lane 0)
+		}
+		for (uint32_t r0 = 0; r0 < ntok; r0 += 64u) {
+		uint32_t clen = 0, code = 0, ob = 0, offlow = 0, rawn = 0, L = 0;
+		bool is_tok = false;
+		if (gi < ngrp) {
+			is_tok = r0 + lane < ntok;
+			if (is_tok) {
+				const uint32_t pos = s_tokpos[r0 + lane];
+				const uint32_t off = s_in_off[pos];
+				uint32_t sym = s_in_byte[pos];
+				if (off != 0 && !fallback) {
+					L = s_in_len[pos];
+					ob = 31u - (uint32_t)__builtin_clz(off);
+					sym = 0x100u | (ob << 4) | (L < 15u ? L : 15u);
+					offlow = off ^ (1u << ob);
+					rawn = L >= 270u ? 3u : (L >= 15u ? 1u : 0u);
+				}
+				clen = s_lens[sym]; code = s_codes[sym];
+			}
+		} else {
+			is_tok = (lane == 0);
+			if (is_tok) { clen = s_lens[0x100]; code = s_codes[0x100]; }
+		}
+		const uint32_t tb = clen + ob;
+		const uint32_t ib = xh_incl_scan_add(tb), ir = xh_incl_scan_add(rawn);
+		const uint32_t T0 = T + ib - tb, T1 = T0 + clen, T2 = T1 + ob;
+		const uint32_t R0 = R + ir - rawn;
+		if (is_tok) {
+			if (clen) { XH_ORBITS(code, clen, T0) }
+			if (ob) { XH_ORBITS(offlow, ob, T1) }
+			const uint32_t f0 = XH_F(T0), f1 = XH_F(T1), f2 = XH_F(T2);
+			if (f1 > f0) { s_slot[(f1 + 1u) & 255u] = 4u + 2u * (f1 - 1u) + R0; }
+			if (f2 > f1) { s_slot[(f2 + 1u) & 255u] = 4u + 2u * (f2 - 1u) + R0 + rawn; }
+			if (rawn) {
+				uint8_t* q = bs + 4u + 2u * f1 + R0;
+				if (rawn == 1u) { q[0] = (uint8_t)(L - 15u); }
+				else { q[0] = 0xFF; q[1] = (uint8_t)L; q[2] = (uint8_t)(L >> 8); }
+			}
+		}
+		T += (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
+		R += (uint32_t)__builtin_amdgcn_readlane((int)ir, 63);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+		// store the words that are complete now
+		const uint32_t wcomplete = T >> 4;
+		for (uint32_t base = Wdone; base < wcomplete; base += 64u) {
+			const uint32_t ww = base + lane;
+			if (ww < wcomplete) {
+				const uint32_t v = (__hip_atomic_load(&s_bits[(ww & 255u) >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> ((ww & 1u) * 16u)) & 0xFFFFu;
+				const uint32_t sp = __hip_atomic_load(&s_slot[ww & 255u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				bs[sp] = (uint8_t)v; bs[sp + 1u] = (uint8_t)(v >> 8);
+				atomicAnd(&s_bits[(ww & 255u) >> 1], ~(0xFFFFu << ((ww & 1u) * 16u)));
+			}
+		}
+		if (wcomplete > Wdone) { Wdone = wcomplete; }
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+		}
+	}
+#else
 	if (nwin) { XE_BURST_LOAD(0u) }
 	for (uint32_t w = 0; w <= nwin; ++w) {
 		// window w < nwin: the tokens starting in it; w == nwin: the EOS token of the unit's last chunk (lane 0)
@@ -750,6 +909,7 @@ __global__ __launch_bounds__(64) void xh_encode_kernel(const uint8_t* __restrict
 		if (wcomplete > Wdone) { Wdone = wcomplete; }
 		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
 	}
+#endif
 	// Finish (Bitstream.h:142-147): the current word (zero padded) and one zero word
 	const uint32_t fe = XH_F(T);
 	for (uint32_t ww = Wdone + lane; ww <= fe + 1u; ww += 64u) {

@@ -91,39 +91,40 @@ __device__ __forceinline__ void xe_emit_tokens(uint8_t* __restrict__ out, u64 ca
 #undef XE_PUT
 }
 
-__global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
+// P = the type of a position in the unit / in its output: uint32_t for units below 2 GiB (every position, the output size and the capacity that
+// matters fit 32 bits: the scalar unit, which runs the walk, does one add / compare where the 64-bit form needs two), u64 otherwise. Same code.
+template <typename P>
+__device__ __forceinline__ void xpress_emit_body(const uint8_t* __restrict__ d_in, const BatchTables& bt,
                                                         S16 mlen3, S16 moff,
-                                                        uint8_t* __restrict__ d_out, u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
+                                                        uint8_t* __restrict__ d_out, u64* __restrict__ d_out_len, int32_t* __restrict__ d_status, uint32_t u,
+                                                        uint16_t (*s_in_off)[512], uint16_t (*s_in_len)[512], uint8_t (*s_in_byte)[512])
 {
 	const uint32_t lane = threadIdx.x;
-	const uint32_t u = blockIdx.x;
-	const u64 n = bt.in_len[u];
-	const u64 cap = bt.out_cap[u];
+	const P n = (P)bt.in_len[u];
+	const P cap = bt.out_cap[u] > (u64)(P)~(P)0 ? (P)~(P)0 : (P)bt.out_cap[u];     // (a capacity beyond P's range never binds: the stream is shorter)
 	const uint8_t* __restrict__ d = d_in + bt.in_off[u];
 	uint8_t* __restrict__ out = d_out + bt.out_off[u];
 	const u64 mbase = (u64)bt.chunk_prefix[u] * 65536u;           // this unit's slice of the per-position match arrays
-	const u64 end2 = n >= 2u ? n - 2u : 0u;
+	const P end2 = n >= 2u ? n - 2u : 0u;
 
-	u64 cur = 0, F = 0, S = 0, N = 0, R = 0;                      // next token start, filled, sum sizes, tokens, long matches
-	bool pend = false; u64 pend_pos = 0; uint32_t pend_low = 0;   // length nibble byte waiting for its high half
-	uint32_t facc = 0; u64 fposc = 0;                             // flag word in progress (first token = bit 0) and its slot
+	P cur = 0, F = 0, S = 0, N = 0, R = 0;                      // next token start, filled, sum sizes, tokens, long matches
+	bool pend = false; P pend_pos = 0; uint32_t pend_low = 0;   // length nibble byte waiting for its high half
+	uint32_t facc = 0; P fposc = 0;                             // flag word in progress (first token = bit 0) and its slot
 
 	// Inputs are burst-loaded 8 windows (512 positions) at a time into a double-buffered LDS stage: one wait on global
 	// memory per 512 positions instead of one per window (loads are unconditional with a clamped index).
-	__shared__ uint16_t s_in_off[2][512];
-	__shared__ uint16_t s_in_len[2][512];
-	__shared__ uint8_t  s_in_byte[2][512];
+	// (the stage itself is declared by the kernel and handed in: two instances of this body must not each get their own)
 	uint32_t g_off[8], g_len[8], g_byte[8];
 #define XE_BURST_LOAD(gbase) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { \
-		const u64 q_ = (gbase) + (u64)k_ * 64u + lane; const u64 c_ = q_ < n ? q_ : n - 1u; \
+		const P q_ = (gbase) + (P)k_ * 64u + lane; const P c_ = q_ < n ? q_ : n - 1u; \
 		{ const uint32_t w_ = mlen3.word(mbase + c_); g_off[k_] = w_ >> 16; g_len[k_] = w_ & 0xFFFFu; } g_byte[k_] = d[c_]; } }
 #define XE_BURST_STORE(buf) { _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) { \
 		s_in_off[buf][k_ * 64 + lane] = (uint16_t)g_off[k_]; s_in_len[buf][k_ * 64 + lane] = (uint16_t)g_len[k_]; s_in_byte[buf][k_ * 64 + lane] = (uint8_t)g_byte[k_]; } }
-	if (n) { XE_BURST_LOAD((u64)0) }
+	if (n) { XE_BURST_LOAD((P)0) }
 #ifdef XE_PROFILE
 	unsigned long long xe_acc[6] = {0, 0, 0, 0, 0, 0}, xe_prev = __builtin_readcyclecounter();
 #endif
-	for (u64 wbase = 0; wbase < n; wbase += 64u) {
+	for (P wbase = 0; wbase < n; wbase += 64u) {
 		XE_T(5)
 		const uint32_t wi = (uint32_t)((wbase >> 6) & 7u), buf = (uint32_t)((wbase >> 9) & 1u);
 		if (wi == 0) {                                            // group start: publish this group's inputs, start loading the next
@@ -131,8 +132,8 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 			if (wbase + 512u < n) { XE_BURST_LOAD(wbase + 512u) }
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
 		}
-		const u64 wend = (wbase + 64u < n) ? wbase + 64u : n;
-		const u64 p = wbase + lane;
+		const P wend = (wbase + 64u < n) ? wbase + 64u : n;
+		const P p = wbase + lane;
 		const bool inr = p < n;
 		if (cur >= wend) { continue; }                            // window wholly covered by a match
 		uint32_t off = inr ? (uint32_t)s_in_off[buf][wi * 64u + lane] : 0u, L = s_in_len[buf][wi * 64u + lane];
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 		// The serial loop only decides which candidates are TAKEN (incl. the lagging-fill rule); the token mask is derived
 		// in parallel afterwards.
 		u64 matchmask = 0;
-		const u64 cur_entry = cur;
+		const P cur_entry = cur;
 		const uint32_t wn = (uint32_t)(wend - wbase);
 		// Fast path (all but ~1 window in 128): `filled` (F) lies beyond this window and no token of it can reach F, so the
 		// lazy-Fill rule cannot fire (F > position for every token start in the window) -- plain 32-bit walk.
@@ -189,9 +190,9 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 				// the finder capped this match at 48: extend it
 				matchmask |= ((u64)1) << mp;
 				capm &= ~(((u64)1) << mp);
-				const u64 pm = wbase + mp;
-				const u64 x = pm - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
-				const u64 ext = 45u + wave_extend(d, x + 48u, pm + 48u, n - pm - 1u - 48u, n, lane);
+				const P pm = wbase + mp;
+				const P x = pm - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
+				const P ext = (P)(45u + wave_extend(d, x + 48u, pm + 48u, n - pm - 1u - 48u, n, lane));
 				if (lane == mp) { L = (uint32_t)ext; }
 				if (ext > 0x10000u) { cur = pm + ext + 3u; far = true; break; }
 				const uint32_t nxs = mp + (uint32_t)ext + 3u;
@@ -208,20 +209,20 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 			const uint32_t rel = (uint32_t)(cur - wbase);
 			const u64 rest = (mm >> rel);
 			if (rest == 0) {
-				const u64 lastp = (wend - 1u < end2) ? wend - 1u : end2;              // fills done by the literal tokens up to wend
+				const P lastp = (wend - 1u < end2) ? wend - 1u : end2;              // fills done by the literal tokens up to wend
 				if (end2 && F <= lastp && lastp < end2) { F = (F + 0x2000u < end2) ? F + 0x2000u : end2; }
 				cur = wend;
 				break;
 			}
 			const uint32_t mp = rel + ctz64(rest);
-			const u64 pm = wbase + mp;
+			const P pm = wbase + mp;
 			if (F <= pm) { F = (F + 0x2000u < end2) ? F + 0x2000u : end2; }            // fill by a token in (cur, pm]
 			matchmask |= ((u64)1) << mp;
-			u64 Lm = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)mp);
+			P Lm = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)mp);
 			if (Lm == 45u) {                                      // the finder capped this match at 48: extend it
-				const u64 x = pm - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
-				const u64 lim = n - pm - 1u;                        // never count the buffer's final byte
-				Lm = 45u + wave_extend(d, x + 48u, pm + 48u, lim - 48u, n, lane);
+				const P x = pm - (uint32_t)__builtin_amdgcn_readlane((int)off, (int)mp);
+				const P lim = n - pm - 1u;                        // never count the buffer's final byte
+				Lm = (P)(45u + wave_extend(d, x + 48u, pm + 48u, lim - 48u, n, lane));
 				if (lane == mp) { L = (uint32_t)Lm; }
 			}
 			cur = pm + Lm + 3u;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 		const uint32_t sh = (uint32_t)(N & 31u);                   // tokens already in the flag word in progress
 		const uint32_t tq = sh + tb;                               // my token's index counted from that word's first token
 		// every position of this window is base + a 32-bit offset: pos(t) = 4*(t div 32 + 1) + sum size(u<t)
-		const u64 base = 4u * (N / 32u + 1u) + S;
+		const P base = 4u * (N / 32u + 1u) + S;
 		const uint32_t posrel = 4u * (tq >> 5) + (incl - sz);
 		const uint32_t kdone = (sh + nt) >> 5;                     // flag words completed by this window (0..2)
 		const bool fits = base + 4u * kdone + wsum <= cap;         // uniform: no store of this window can pass the capacity
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 			u64 sm = __ballot(is_tok && (tq & 31u) == 0);             // tokens that open a flag word: its slot is the 4 bytes before them
 			const u64 lo = (u64)facc | (M << sh);
 			const uint32_t hi = sh ? (uint32_t)(M >> (64u - sh)) : 0u;
-			u64 fp = fposc;
+			P fp = fposc;
 			uint32_t w = (uint32_t)lo;
 			if (sh == 0) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; sm &= sm - 1u; }
 			if (kdone >= 1u) {
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 		// carry
 		if (longmask) {
 			const uint32_t ll = 63u - (uint32_t)__builtin_clzll(longmask);        // last long match of the window
-			const u64 rl = R + (uint32_t)__popcll(longmask) - 1u;
+			const P rl = R + (uint32_t)__popcll(longmask) - 1u;
 			pend = !(rl & 1u);
 			if (pend) {
 				pend_pos = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)ll) + 2u;
@@ -304,11 +305,11 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 #endif
 
 	// ---- final flag word (:343-344), size, status ----------------------------------------------------------------
-	const u64 gf = N / 32u;
+	const P gf = N / 32u;
 	const uint32_t cnt = (uint32_t)(N & 31u);
-	const u64 total = 4u * (gf + 1u) + S;
+	const P total = 4u * (gf + 1u) + S;
 	if (lane == 0) {
-		uint32_t wv; u64 fp;
+		uint32_t wv; P fp;
 		if (cnt) { wv = __builtin_bitreverse32(facc) | ((1u << (32u - cnt)) - 1u); fp = fposc; }
 		else { wv = 0xFFFFFFFFu; fp = total - 4u; }
 		put8(out, cap, fp, wv); put8(out, cap, fp + 1u, wv >> 8); put8(out, cap, fp + 2u, wv >> 16); put8(out, cap, fp + 3u, wv >> 24);
@@ -316,6 +317,18 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 		d_out_len[u] = ok ? total : 0;
 		d_status[u] = ok ? 0 : -5;
 	}
+}
+
+__global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
+                                                        S16 mlen3, S16 moff,
+                                                        uint8_t* __restrict__ d_out, u64* __restrict__ d_out_len, int32_t* __restrict__ d_status)
+{
+	__shared__ uint16_t s_in_off[2][512];
+	__shared__ uint16_t s_in_len[2][512];
+	__shared__ uint8_t  s_in_byte[2][512];
+	const uint32_t u = blockIdx.x;
+	if (bt.in_len[u] < ((u64)1 << 31)) { xpress_emit_body<uint32_t>(d_in, bt, mlen3, moff, d_out, d_out_len, d_status, u, s_in_off, s_in_len, s_in_byte); }
+	else { xpress_emit_body<u64>(d_in, bt, mlen3, moff, d_out, d_out_len, d_status, u, s_in_off, s_in_len, s_in_byte); }
 }
 
 // ===================================================================================================================

@@ -276,7 +276,11 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 			const u64 lim = tail - t - 1u;                                          // n - P - 1: never count the buffer's final byte
 			const uint32_t cap = lim < 48u ? (uint32_t)lim : 48u;
 			const bool prev_last = (prev_last_hash == h);
+#if defined(XF_PROBE) && XF_PROBE == 4       /* dev probe (SUBTRACTIVE, not bit-exact): walk 6 chain candidates instead of 11 */
+			uint32_t chain = 6;
+#else
 			uint32_t chain = 11;
+#endif
 			// first candidate: my own link (an offset inside the chunk), else the previous chunk's last position with my hash
 			int32_t xr;
 			bool alive;
@@ -311,7 +315,11 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 				{ const uint4 y = ld128(s_data, ((uint32_t)xr * 5u + 77u) & 0xFFFFu); asm volatile("" :: "v"(y.x), "v"(y.y), "v"(y.z), "v"(y.w)); }
 #endif
 				uint32_t l = first_diff16(make_uint4(c.x ^ oa.x, c.y ^ oa.y, c.z ^ oa.z, c.w ^ oa.w));
+#if defined(XF_PROBE) && XF_PROBE == 5       /* dev probe (SUBTRACTIVE, not bit-exact): no compare beyond the first 16 bytes */
+				if (false) {
+#else
 				if (l == 16u && cap > 16u) {
+#endif
 					c = ld128(s_data, (uint32_t)xr + 16u);
 					l = 16u + first_diff16(make_uint4(c.x ^ ob.x, c.y ^ ob.y, c.z ^ ob.z, c.w ^ ob.w));
 					if (l == 32u && cap > 32u) {
