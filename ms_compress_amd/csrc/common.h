@@ -48,13 +48,15 @@ __device__ __forceinline__ void     st32(uint8_t* p, uint32_t v) { __builtin_mem
 
 // Index of the first non-zero byte of the 16-byte value x (little endian), 16 when x == 0. Branch-free, 10 VALU:
 // v_ffbl_b32 returns 0xFFFFFFFF for a zero dword (the builtin ctz is undefined there, so the instruction is named
-// directly), the saturating adds keep it there, and the unsigned minimum picks the first hit.
+// directly); OR-ing 32 / 64 / 96 into a bit index below 32 ADDS the dword's offset and leaves the all-ones "none" as it
+// is, and the unsigned minimum picks the first hit. (Round 5: v_or_b32 where rounds 1-4 had v_add_u32 ... clamp. A
+// 3-operand / modifier-carrying VOP3 instruction issues at HALF the rate of a VOP1 / VOP2 one on this GPU -- 1 against 2
+// wave-instructions per CU and cycle, tools/dev/issue_peak.hip -- and the clamp made the three adds VOP3.)
 __device__ __forceinline__ uint32_t ffbl_raw(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 __device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { const uint32_t t = a < b ? a : b; return t < c ? t : c; }
 __device__ __forceinline__ uint32_t first_nz_byte16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
 {
-	const uint32_t a = __builtin_elementwise_add_sat(ffbl_raw(x1), 32u), b = __builtin_elementwise_add_sat(ffbl_raw(x2), 64u);
-	const uint32_t c = __builtin_elementwise_add_sat(ffbl_raw(x3), 96u);
+	const uint32_t a = ffbl_raw(x1) | 32u, b = ffbl_raw(x2) | 64u, c = ffbl_raw(x3) | 96u;
 	return min3u(min3u(ffbl_raw(x0), a, b), c, 128u) >> 3;
 }
 

@@ -93,11 +93,12 @@ __device__ __forceinline__ void xe_emit_tokens(uint8_t* __restrict__ out, u64 ca
 
 // P = the type of a position in the unit / in its output: uint32_t for units below 2 GiB (every position, the output size and the capacity that
 // matters fit 32 bits: the scalar unit, which runs the walk, does one add / compare where the 64-bit form needs two), u64 otherwise. Same code.
+#define XE_RING 128u                                           // tokens queued between the walk and the emission (a power of two >= 2 x 64)
 template <typename P>
 __device__ __forceinline__ void xpress_emit_body(const uint8_t* __restrict__ d_in, const BatchTables& bt,
                                                         S16 mlen3, S16 moff,
                                                         uint8_t* __restrict__ d_out, u64* __restrict__ d_out_len, int32_t* __restrict__ d_status, uint32_t u,
-                                                        uint16_t (*s_in_off)[512], uint16_t (*s_in_len)[512], uint8_t (*s_in_byte)[512])
+                                                        uint16_t (*s_in_off)[512], uint16_t (*s_in_len)[512], uint8_t (*s_in_byte)[512], uint16_t* s_qa, uint32_t* s_ql)
 {
 	const uint32_t lane = threadIdx.x;
 	const P n = (P)bt.in_len[u];
@@ -124,6 +125,79 @@ __device__ __forceinline__ void xpress_emit_body(const uint8_t* __restrict__ d_i
 #ifdef XE_PROFILE
 	unsigned long long xe_acc[6] = {0, 0, 0, 0, 0, 0}, xe_prev = __builtin_readcyclecounter();
 #endif
+	// Round 5: the emission works on 64 TOKENS at a time, not on the 64 positions of a window. A window holds 4-30 tokens (0.06-0.46 per
+	// byte), so the size scan, the token stores, the flag words and the carries -- more than half of this kernel's ~150 scalar instructions per
+	// window, and the scalar unit (one per CU) is what the kernel is bound by -- ran for a quarter of their lanes. The walk queues every
+	// window's tokens in a 128-entry LDS ring in rank order (match: 0x8000 | offset and len - 3; literal: the byte); a step takes 64 of them,
+	// lane = token: what follows is the per-window code it was, with tokmask = all lanes below cnt, tb = lane, and the match bits in token
+	// order a plain ballot (no ds_permute).
+	uint32_t qh = 0, qt = 0;                                     // ring: tokens taken / queued so far
+	auto emit_step = [&](const uint32_t cnt) __attribute__((always_inline)) {
+		const bool is_tok = lane < cnt;
+		const uint32_t qa = __hip_atomic_load(&s_qa[(qh + lane) & (XE_RING - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+		const uint32_t L = is_tok ? __hip_atomic_load(&s_ql[(qh + lane) & (XE_RING - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 0u;
+		const bool is_m = is_tok && (qa & 0x8000u);
+		const uint32_t off = qa & 0x7FFFu, byte = qa & 0xFFu;
+		const uint32_t nt = cnt, tb = lane;
+		const bool lng = is_m && L >= 7u;
+		const u64 longmask = __ballot(lng);
+		const bool even = !(((uint32_t)R + popc_below(longmask)) & 1u);
+		uint32_t sz = 0;
+		if (is_tok) { sz = !is_m ? 1u : 2u + (uint32_t)(lng && even) + (uint32_t)(L >= 22u) + (L >= 277u ? (L <= 0xFFFFu ? 2u : 6u) : 0u); }
+		const uint32_t incl = wave_incl_scan_add(sz);
+		const uint32_t wsum = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		const uint32_t sh = (uint32_t)(N & 31u);                   // tokens already in the flag word in progress
+		const uint32_t tq = sh + tb;                               // my token's index counted from that word's first token
+		// every position of this step is base + a 32-bit offset: pos(t) = 4*(t div 32 + 1) + sum size(u<t)
+		const P base = 4u * (N / 32u + 1u) + S;
+		const uint32_t posrel = 4u * (tq >> 5) + (incl - sz);
+		const uint32_t kdone = (sh + nt) >> 5;                     // flag words completed by this step (0..2)
+		const bool fits = base + 4u * kdone + wsum <= cap;         // uniform: no store of this step can pass the capacity
+		// the nibble of the NEXT long match in this step (it shares my byte when my rank is even)
+		const u64 above = (longmask >> lane) >> 1;
+		const uint32_t nib = L >= 7u ? (L - 7u < 15u ? L - 7u : 15u) : 0u;
+		const uint32_t partner = above ? lane + 1u + ctz64(above) : lane;
+		const uint32_t pnib = (uint32_t)__shfl((int)nib, (int)partner, 64);
+		if (fits) { xe_emit_tokens<false>(out, cap, base, posrel, is_tok, is_m, byte, off, L, lng, even, above != 0, nib, pnib, pend, pend_pos, pend_low, longmask, lane); }
+		else      { xe_emit_tokens<true >(out, cap, base, posrel, is_tok, is_m, byte, off, L, lng, even, above != 0, nib, pnib, pend, pend_pos, pend_low, longmask, lane); }
+		// ---- flag words: the word in progress lives in scalars, first token in bit 0; a completed word is bit-reversed into its slot
+		// (the first token is the MSB, :317-324) ----------
+		{
+			const u64 M = __ballot(is_m);
+			u64 sm = __ballot(is_tok && (tq & 31u) == 0);             // tokens that open a flag word: its slot is the 4 bytes before them
+			const u64 lo = (u64)facc | (M << sh);
+			const uint32_t hi = sh ? (uint32_t)(M >> (64u - sh)) : 0u;
+			P fp = fposc;
+			uint32_t w = (uint32_t)lo;
+			if (sh == 0) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; sm &= sm - 1u; }
+			if (kdone >= 1u) {
+				if (lane == 0) { xe_store32(out, cap, fp, __builtin_bitreverse32(w), !fits); }
+				w = (uint32_t)(lo >> 32);
+				if (sm) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; sm &= sm - 1u; }
+				if (kdone >= 2u) {
+					if (lane == 0) { xe_store32(out, cap, fp, __builtin_bitreverse32(w), !fits); }
+					w = hi;
+					if (sm) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; }
+				}
+			}
+			facc = w; fposc = fp;
+		}
+		// carry
+		if (longmask) {
+			const uint32_t ll = 63u - (uint32_t)__builtin_clzll(longmask);        // last long match of the step
+			const P rl = R + (uint32_t)__popcll(longmask) - 1u;
+			pend = !(rl & 1u);
+			if (pend) {
+				pend_pos = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)ll) + 2u;
+				pend_low = (uint32_t)__builtin_amdgcn_readlane((int)nib, (int)ll);
+			}
+			R += (uint32_t)__popcll(longmask);
+		}
+		N += nt;
+		S += wsum;
+		qh += cnt;
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");     // (the ring entries just read may be written again by the next window)
+	};
 	for (P wbase = 0; wbase < n; wbase += 64u) {
 		XE_T(5)
 		const uint32_t wi = (uint32_t)((wbase >> 6) & 7u), buf = (uint32_t)((wbase >> 9) & 1u);
@@ -235,71 +309,22 @@ __device__ __forceinline__ void xpress_emit_body(const uint8_t* __restrict__ d_i
 		const bool is_tok = p >= cur_entry && inr && (is_m || reach <= lane);
 		const u64 tokmask = __ballot(is_tok);
 
-		// ---- emit ----------------------------------------------------------------------------------------------
-		const uint32_t nt = (uint32_t)__popcll(tokmask);
-		const bool lng = is_m && L >= 7u;
-		const u64 longmask = __ballot(lng);
-		const bool even = !(((uint32_t)R + popc_below(longmask)) & 1u);
-		uint32_t sz = 0;
-		if (is_tok) { sz = !is_m ? 1u : 2u + (uint32_t)(lng && even) + (uint32_t)(L >= 22u) + (L >= 277u ? (L <= 0xFFFFu ? 2u : 6u) : 0u); }
-		const uint32_t incl = wave_incl_scan_add(sz);
-		const uint32_t wsum = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-		const uint32_t tb = popc_below(tokmask);
-		const uint32_t sh = (uint32_t)(N & 31u);                   // tokens already in the flag word in progress
-		const uint32_t tq = sh + tb;                               // my token's index counted from that word's first token
-		// every position of this window is base + a 32-bit offset: pos(t) = 4*(t div 32 + 1) + sum size(u<t)
-		const P base = 4u * (N / 32u + 1u) + S;
-		const uint32_t posrel = 4u * (tq >> 5) + (incl - sz);
-		const uint32_t kdone = (sh + nt) >> 5;                     // flag words completed by this window (0..2)
-		const bool fits = base + 4u * kdone + wsum <= cap;         // uniform: no store of this window can pass the capacity
-		// the nibble of the NEXT long match in this window (it shares my byte when my rank is even)
-		const u64 above = (longmask >> lane) >> 1;
-		const uint32_t nib = L >= 7u ? (L - 7u < 15u ? L - 7u : 15u) : 0u;
-		const uint32_t partner = above ? lane + 1u + ctz64(above) : lane;
-		const uint32_t pnib = (uint32_t)__shfl((int)nib, (int)partner, 64);
-		if (fits) { xe_emit_tokens<false>(out, cap, base, posrel, is_tok, is_m, byte, off, L, lng, even, above != 0, nib, pnib, pend, pend_pos, pend_low, longmask, lane); }
-		else      { xe_emit_tokens<true >(out, cap, base, posrel, is_tok, is_m, byte, off, L, lng, even, above != 0, nib, pnib, pend, pend_pos, pend_low, longmask, lane); }
-		XE_T(2)
-		// ---- flag words: the match bits in TOKEN order are a ballot after moving every token's bit to lane = its rank
-		// (tokens to [0,nt), the other lanes behind them: a permutation). The word in progress lives in scalars, first
-		// token in bit 0; a completed word is bit-reversed into its slot (the first token is the MSB, :317-324). ----------
+		// ---- queue the window's tokens: rank order = position order (round 5; see emit_step above the loop) ----------------
 		{
-			const uint32_t dst = is_tok ? tb : nt + (lane - tb);
-			const uint32_t fm = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (is_tok && is_m) ? 1 : 0);
-			const u64 M = __ballot(fm != 0);
-			u64 sm = __ballot(is_tok && (tq & 31u) == 0);             // tokens that open a flag word: its slot is the 4 bytes before them
-			const u64 lo = (u64)facc | (M << sh);
-			const uint32_t hi = sh ? (uint32_t)(M >> (64u - sh)) : 0u;
-			P fp = fposc;
-			uint32_t w = (uint32_t)lo;
-			if (sh == 0) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; sm &= sm - 1u; }
-			if (kdone >= 1u) {
-				if (lane == 0) { xe_store32(out, cap, fp, __builtin_bitreverse32(w), !fits); }
-				w = (uint32_t)(lo >> 32);
-				if (sm) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; sm &= sm - 1u; }
-				if (kdone >= 2u) {
-					if (lane == 0) { xe_store32(out, cap, fp, __builtin_bitreverse32(w), !fits); }
-					w = hi;
-					if (sm) { const uint32_t l = ctz64(sm); fp = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)l) - 4u; }
-				}
+			const uint32_t tb = popc_below(tokmask);
+			if (is_tok) {
+				const uint32_t qi = (qt + tb) & (XE_RING - 1u);
+				__hip_atomic_store(&s_qa[qi], (uint16_t)(is_m ? (0x8000u | off) : byte), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+				__hip_atomic_store(&s_ql[qi], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 			}
-			facc = w; fposc = fp;
+			qt += (uint32_t)__popcll(tokmask);
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
 		}
-		// carry
-		if (longmask) {
-			const uint32_t ll = 63u - (uint32_t)__builtin_clzll(longmask);        // last long match of the window
-			const P rl = R + (uint32_t)__popcll(longmask) - 1u;
-			pend = !(rl & 1u);
-			if (pend) {
-				pend_pos = base + (uint32_t)__builtin_amdgcn_readlane((int)posrel, (int)ll) + 2u;
-				pend_low = (uint32_t)__builtin_amdgcn_readlane((int)nib, (int)ll);
-			}
-			R += (uint32_t)__popcll(longmask);
-		}
-		N += nt;
-		S += wsum;
+		XE_T(2)
+		while (qt - qh >= 64u) { emit_step(64u); }
 		XE_T(3)
 	}
+	if (qt != qh) { emit_step(qt - qh); }                       // the last, partial step
 #ifdef XE_PROFILE
 	if (lane == 0) { for (int i_ = 0; i_ < 6; ++i_) { atomicAdd(&g_xe_prof[i_], xe_acc[i_]); } }
 #endif
@@ -326,9 +351,11 @@ __global__ __launch_bounds__(64) void xpress_emit_kernel(const uint8_t* __restri
 	__shared__ uint16_t s_in_off[2][512];
 	__shared__ uint16_t s_in_len[2][512];
 	__shared__ uint8_t  s_in_byte[2][512];
+	__shared__ uint16_t s_qa[XE_RING];                             // the token ring: 0x8000 | offset of a match, or the literal byte ...
+	__shared__ uint32_t s_ql[XE_RING];                             // ... and len - 3
 	const uint32_t u = blockIdx.x;
-	if (bt.in_len[u] < ((u64)1 << 31)) { xpress_emit_body<uint32_t>(d_in, bt, mlen3, moff, d_out, d_out_len, d_status, u, s_in_off, s_in_len, s_in_byte); }
-	else { xpress_emit_body<u64>(d_in, bt, mlen3, moff, d_out, d_out_len, d_status, u, s_in_off, s_in_len, s_in_byte); }
+	if (bt.in_len[u] < ((u64)1 << 31)) { xpress_emit_body<uint32_t>(d_in, bt, mlen3, moff, d_out, d_out_len, d_status, u, s_in_off, s_in_len, s_in_byte, s_qa, s_ql); }
+	else { xpress_emit_body<u64>(d_in, bt, mlen3, moff, d_out, d_out_len, d_status, u, s_in_off, s_in_len, s_in_byte, s_qa, s_ql); }
 }
 
 // ===================================================================================================================

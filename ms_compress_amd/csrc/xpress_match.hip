@@ -304,7 +304,10 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 				if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(__ballot(1))) { XF_CNT(2, 64) }
 				const uint32_t dist = (uint32_t)((int32_t)pr - xr);
 				// the link of xr is fetched first (L2 latency for Xpress+Huffman) and consumed after the compare
-				uint32_t x = (LINKW == WINDOW) ? (uint32_t)s_links[(uint32_t)xr - lrel] : (uint32_t)lkw[(uint32_t)xr];
+				// (byte offset in 32 bits, zero-extended: the gather is `global_load_ushort v, v_offset, s[base]`; the 64-bit index form cost a
+				// v_lshl_add_u64 per step)
+				uint32_t x = (LINKW == WINDOW) ? (uint32_t)s_links[(uint32_t)xr - lrel]
+				                               : (uint32_t)*reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(lkw) + (u64)(uint32_t)((uint32_t)xr << 1));
 				// 16 bytes per step against my own 48 bytes held in registers (lengths are capped at 48 here)
 				uint4 c = ld128(s_data, (uint32_t)xr);
 #if defined(XF_PROBE) && XF_PROBE == 1        /* dev probe: one more divergent global gather per step */
