@@ -124,7 +124,11 @@ MSCompStatus lznt1_inflate_end(mscomp_stream* stream);
 typedef struct mscomp_amd_ctx  mscomp_amd_ctx;    /* one per (device, stream); owns scratch in HBM  */
 typedef struct mscomp_amd_plan mscomp_amd_plan;   /* unit layout of one batch, uploaded once        */
 
-/* device = HIP ordinal; hip_stream = hipStream_t to launch on (NULL = the null stream). */
+/* device = HIP ordinal; hip_stream = hipStream_t to launch on (NULL = the null stream).
+ * A context belongs to ONE host thread at a time (its scratch, its pinned table staging and its pool of table buffers are not locked): use one
+ * context per thread -- the one-shot entries of Part 1 do that themselves (a thread-local context), mscomp_amd_compress_units_host keeps one per
+ * sub-batch slot. mscomp_amd_plan_create must not run while the context's stream is being captured into a graph (it waits on an event of that
+ * stream when its table staging is still in flight); capture mscomp_amd_plan_execute instead, with the plan made beforehand. */
 MSCompStatus mscomp_amd_ctx_create(int device, void* hip_stream, mscomp_amd_ctx** ctx);
 void         mscomp_amd_ctx_destroy(mscomp_amd_ctx* ctx);
 
@@ -155,10 +159,15 @@ MSCompStatus mscomp_amd_plan_execute(mscomp_amd_plan* plan, const uint8_t* d_in,
  * when the capacity has room. Bytes of a unit's capacity behind its stream are unspecified afterwards.
  * devices = n_dev device ordinals (NULL: 0 .. n_dev - 1; the same ordinal may appear twice: two ranges share that GPU). The units are cut into
  * n_dev contiguous ranges with near-equal input bytes (no exchange step, no collective: units are independent); every range runs on its own
- * host thread with its own context, three streams and double-buffered staging, batches of MSCOMP_AMD_HOST_BATCH_MB (default 512) MiB; units
+ * host thread as a pipeline of sub-batches (MSCOMP_AMD_HOST_BATCH_MB MiB of input each, default 32 -- 96 for Xpress+Huffman --, up to
+ * MSCOMP_AMD_HOST_SLOTS = 8 in flight, each with its own context and stream; an uploader and a downloader thread beside it); units
  * that lie back to back in the caller's memory travel as one copy. Returns MSCOMP_OK when every range ran (per-unit results in statuses),
  * MSCOMP_ARG_ERROR for a bad format / device / pointer, MSCOMP_MEM_ERROR / MSCOMP_ERRNO when a range could not run (statuses of units not
- * reached stay MSCOMP_ERRNO). Contexts and staging are kept per device between calls; mscomp_amd_host_pool_release() frees them. */
+ * reached stay MSCOMP_ERRNO; a failed allocation or a thread the system refuses is MSCOMP_MEM_ERROR, never an abort: csrc/hostbatch.hip is built
+ * with exceptions and catches at this boundary). ONE LZNT1 unit of 36 MiB or more on the calling thread's range takes the one-shot call's path
+ * (caller buffers mapped into the GPU's address space; the two environment knobs do not apply to it). With outputs laid out capacity after
+ * capacity, the bytes of a capacity behind its stream -- including the capacities of units that failed -- are unspecified afterwards (they come
+ * down with the streams in one copy). Contexts and staging are kept per device between calls; mscomp_amd_host_pool_release() frees them. */
 MSCompStatus mscomp_amd_compress_units_host(MSCompFormat format, int n_dev, const int* devices, size_t n_units,
                                             const uint8_t* const* in_ptrs, const size_t* in_lens, uint8_t* const* out_ptrs, const size_t* out_caps,
                                             size_t* out_lens, MSCompStatus* statuses);

@@ -468,7 +468,17 @@ void mscomp_amd_plan_destroy(mscomp_amd_plan* p)
 	DeviceGuard g(p->ctx->device);
 	(void)hipStreamSynchronize(p->ctx->stream);
 	if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); }
-	if (p->tables.p && p->ctx->table_pool.size() < 8) { p->ctx->table_pool.push_back(p->tables); p->tables.p = nullptr; p->tables.cap = 0; }
+	if (p->tables.p) {
+		// the pool keeps the 8 LARGEST buffers it has seen: a full pool gives up its smallest one for a larger one (a pool full of
+		// small buffers made every larger plan hipFree on destroy -- a device-wide wait)
+		std::vector<DevBuf>& pool = p->ctx->table_pool;
+		if (pool.size() < 8) { pool.push_back(p->tables); p->tables.p = nullptr; p->tables.cap = 0; }
+		else {
+			size_t least = 0;
+			for (size_t i = 1; i < pool.size(); ++i) { if (pool[i].cap < pool[least].cap) { least = i; } }
+			if (pool[least].cap < p->tables.cap) { DevBuf t = pool[least]; pool[least] = p->tables; p->tables = t; }   // (the smaller one is released below)
+		}
+	}
 	p->tables.release(); p->tokpre.release(); p->lzg_tab.release(); p->xps_tab.release();
 	delete p;
 }

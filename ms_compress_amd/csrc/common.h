@@ -126,10 +126,20 @@ __device__ __forceinline__ void copy_from_aligned(uint8_t* __restrict__ dst, con
 	const uint32_t body = (n - head) >> 2;
 	const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(src);
 	uint32_t* __restrict__ d32 = reinterpret_cast<uint32_t*>(dst + head);
+	// four destination dwords per thread and step (round 5: one dword per step left ~10 dependent load -> shift -> store rounds per 2.4 KiB chunk
+	// image in flight one at a time; the destination is only dword-aligned, the 16 bytes go out as the compiler sees fit for that alignment)
+	const uint32_t body4 = body & ~3u;
+	for (uint32_t i = tid * 4u; i < body4; i += nthr * 4u) {
+		const uint32_t a0 = s32[i], a1 = s32[i + 1u], a2 = s32[i + 2u], a3 = s32[i + 3u], a4 = head ? s32[i + 4u] : 0u;   // (index <= body, like the one-dword form's s32[i + 1]: at most 3 bytes behind the image, inside the slot's slack)
+		uint32_t v[4];
+		if (head == 0) { v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3; }
+		else { v[0] = __builtin_amdgcn_alignbyte(a1, a0, head); v[1] = __builtin_amdgcn_alignbyte(a2, a1, head); v[2] = __builtin_amdgcn_alignbyte(a3, a2, head); v[3] = __builtin_amdgcn_alignbyte(a4, a3, head); }
+		__builtin_memcpy(__builtin_assume_aligned(d32 + i, 4), v, 16);
+	}
 	if (head == 0) {
-		for (uint32_t i = tid; i < body; i += nthr) { d32[i] = s32[i]; }
+		for (uint32_t i = body4 + tid; i < body; i += nthr) { d32[i] = s32[i]; }
 	} else {
-		for (uint32_t i = tid; i < body; i += nthr) { d32[i] = __builtin_amdgcn_alignbyte(s32[i + 1], s32[i], head); }
+		for (uint32_t i = body4 + tid; i < body; i += nthr) { d32[i] = __builtin_amdgcn_alignbyte(s32[i + 1], s32[i], head); }
 	}
 	for (uint32_t i = head + body * 4u + tid; i < n; i += nthr) { dst[i] = src[i]; }
 }

@@ -32,10 +32,22 @@ for leg in $SLEGS; do
   rocprofv3 --kernel-trace --pmc $SQA --output-format csv -d $D -o sqa_$t -- python tools/gpu_leg.py $leg 3 > $D/sqa_$t.out 2>&1
   rocprofv3 --kernel-trace --pmc $SQB --output-format csv -d $D -o sqb_$t -- python tools/gpu_leg.py $leg 3 > $D/sqb_$t.out 2>&1
 done
+# 5. (round 5) per codec: rocprofv3 --kernel-trace --stats of ONE configs[4] leg (profiles/<tag>_kernel_stats.txt gets one table per codec: every
+#    roofline.frac of the bench line is then reproducible from profiles/ alone), and GRBM_GUI_ACTIVE of the same leg (the clock the kernels ran at:
+#    cycles summed over the 8 XCDs / duration) -- what the issue rates of the SQ counters are divided by
+for codec in lznt1 xpress xpress_huff; do
+  [ -n "$QUICK" ] && [ $codec != lznt1 ] && continue
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D -o kt_config5_$codec -- python tools/gpu_leg.py config5:$codec 3 > $D/kt_config5_$codec.out 2>&1
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $D -o clk_config5_$codec -- python tools/gpu_leg.py config5:$codec 3 > $D/clk_config5_$codec.out 2>&1
+done
+# 6. the drop-in entry with host pointers (PCIe-inclusive; never `value`): one 51 MB buffer per call, all three codecs, both directions
+python tools/gpu_oneshot.py > $D/oneshot_host_pointers.txt 2>&1
+tools/dev/issue_peak > $D/issue_peak.txt 2>&1
 # the counter summaries go into profiles/ of THIS copy of the repository first: the bench line below attaches them (roofline.traffic / .secondary)
 python tools/update_profiles.py $D $TAG > $D/update_on_box.log 2>&1
 python bench.py 2> $D/bench.err | tail -1 > $D/bench.json
+cp bench_extra.json $D/bench_extra.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o kt_head -- python bench.py --no-extra --no-cpu --steps 5 --warmup 1 2> $D/kt_head.err | tail -1 > $D/bench_headline_under_rocprof.json
 [ -n "$QUICK" ] || rocprofv3 --kernel-trace --stats --output-format csv -d $D -o kt_full -- python bench.py --no-cpu --steps 4 --warmup 1 2> $D/kt_full.err | tail -1 > $D/bench_full_under_rocprof.json
-find $D -name "*.csv" | head -80
+find $D -name "*.db" -delete; find $D -name "*.csv" | wc -l
 du -sh $D

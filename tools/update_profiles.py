@@ -25,7 +25,12 @@ def per_kernel(path):
 
 
 if os.path.exists(os.path.join(src, "bench.json")) and os.path.getsize(os.path.join(src, "bench.json")):
-    shutil.copy(os.path.join(src, "bench.json"), P("bench.json"))
+    shutil.copy(os.path.join(src, "bench.json"), P("bench.json"))                 # the ONE short line the driver parses
+if os.path.exists(os.path.join(src, "bench_extra.json")) and os.path.getsize(os.path.join(src, "bench_extra.json")):
+    shutil.copy(os.path.join(src, "bench_extra.json"), P("bench_extra.json"))     # the whole document of the same run (every leg, every kernel)
+for f in ("oneshot_host_pointers.txt", "issue_peak.txt"):
+    if os.path.exists(os.path.join(src, f)) and os.path.getsize(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), P(f))
 for f in ("bench_headline_under_rocprof.json", "bench_full_under_rocprof.json"):
     if os.path.exists(os.path.join(src, f)) and os.path.getsize(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), P(f))
@@ -35,6 +40,10 @@ if os.path.exists(os.path.join(src, "kt_head_kernel_stats.csv")):
     if os.path.exists(os.path.join(src, "kt_full_kernel_stats.csv")):
         txt += "\n" + stats_table(os.path.join(src, "kt_full_kernel_stats.csv"),
                                   "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --steps 4 --warmup 1   (all legs, compressors and decompressors: a kernel's launches mix workloads)")
+    for codec in ("lznt1", "xpress", "xpress_huff"):
+        f = os.path.join(src, "kt_config5_%s_kernel_stats.csv" % codec)
+        if os.path.exists(f):
+            txt += "\n" + stats_table(f, "rocprofv3 --kernel-trace --stats -- python tools/gpu_leg.py config5:%s 3   (ONE codec over BASELINE configs[4], 1 warm-up + 3 timed passes: every launch is this workload)" % codec)
     open(P("kernel_stats.txt"), "w").write(txt)
 
 WL = {"config5": "config5_n1", "single": "single_gpu", "decompress": "decompress_units64k"}
@@ -57,6 +66,17 @@ json.dump({"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WR
            "workload_keys": {"config5_n1": "BASELINE configs[4] on one GPU: 16x replicated corpus, 3391017280 B", "single_gpu": "BASELINE configs[1..3]: mozilla 51220480 B (lznt1), 3239 x 64 KiB units (xpress), 12 files (xpress_huff), 211938580 B"},
            "by_codec": traffic, "workloads": {w: {k: r for c in v.values() for k, r in c.items()} for w, v in traffic.items()}}, open(P("pmc_traffic.json"), "w"), indent=1)
 
+N_XCD, N_CU = 8, 256
+PEAK = {"valu_vop12_per_cu_cycle": 2.0, "valu_vop3_per_cu_cycle": 1.0, "salu_per_cu_cycle": 1.0}      # tools/dev/issue_peak.hip, measured on this GPU (profiles/<tag>_issue_peak.txt)
+clock = {}                                     # codec -> {kernel: (GHz, avg ns)} from the GRBM_GUI_ACTIVE passes of the configs[4] legs
+for f in sorted(glob.glob(os.path.join(src, "clk_config5_*_counter_collection.csv"))):
+    codec = os.path.basename(f)[len("clk_config5_"):-len("_counter_collection.csv")]
+    cyc = per_kernel(f)
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(f.replace("_counter_collection.csv", "_kernel_trace.csv"))):
+        dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    clock[codec] = {k: (v["GRBM_GUI_ACTIVE"][0] / N_XCD / (sum(dur[k]) / len(dur[k])), sum(dur[k]) / len(dur[k])) for k, v in cyc.items() if k in dur and "GRBM_GUI_ACTIVE" in v}
+
 sq = {}
 for f in sorted(glob.glob(os.path.join(src, "sqa_*_counter_collection.csv"))):
     leg = os.path.basename(f)[len("sqa_"):-len("_counter_collection.csv")]
@@ -72,20 +92,34 @@ for f in sorted(glob.glob(os.path.join(src, "sqa_*_counter_collection.csv"))):
              "lds_pipe_busy_frac": round(raw.get("SQ_LDS_IDX_ACTIVE", 0) / max(1, raw.get("SQ_BUSY_CU_CYCLES", 1)), 3),
              "lds_bank_conflict_share": round(raw.get("SQ_LDS_BANK_CONFLICT", 0) / idx, 3), "lds_unaligned_stall_share": round(raw.get("SQ_LDS_UNALIGNED_STALL", 0) / idx, 4),
              "lds_cycles_per_lds_instruction": round(idx / max(1, raw.get("SQ_INSTS_LDS", 1)), 2)}
-        # share of the CU-busy cycles in which a VALU instruction was executing (SQ_ACTIVE_INST_VALU is summed over the 4 SIMDs of a CU the way
-        # SQ_BUSY_CU_CYCLES is summed over CUs: ~1.0 = the vector pipes never idle)
-        d["valu_busy_frac"] = round(raw.get("SQ_ACTIVE_INST_VALU", 0) / max(1, raw.get("SQ_BUSY_CU_CYCLES", 1)), 3)
-        d["bound"] = ("valu-issue (vector pipes busy)" if d["valu_busy_frac"] >= 0.8 else
+        # Issue rates against what a CU can issue (round 5; replaces round 4's `valu_busy_frac`, a ratio of two counters with different units that came
+        # out above 1): wave-instructions per CU and cycle over the CU's BUSY cycles. Measured peaks of this GPU (tools/dev/issue_peak.hip): 2.0 for
+        # VOP1 / VOP2 vector instructions, 1.0 for 3-operand / modifier VOP3 ones (v_alignbyte, v_min3, clamped adds, ..._e64 compares and selects),
+        # 1.0 scalar (ONE scalar unit per CU for all its waves). The counters do not split VOP3 from VOP2, so the vector fraction is a bracket:
+        # between insts / 2 (all VOP1/2) and insts / 1 (all VOP3), the upper end capped at 1. The scalar fraction is exact.
+        busy = max(1, raw.get("SQ_BUSY_CU_CYCLES", 1))
+        v_rate, s_rate = raw.get("SQ_INSTS_VALU", 0) / busy, raw.get("SQ_INSTS_SALU", 0) / busy
+        d["valu_insts_per_cu_cycle"] = round(v_rate, 3)
+        d["salu_insts_per_cu_cycle"] = round(s_rate, 3)
+        d["valu_issue_frac_bracket"] = [round(min(1.0, v_rate / PEAK["valu_vop12_per_cu_cycle"]), 3), round(min(1.0, v_rate / PEAK["valu_vop3_per_cu_cycle"]), 3)]
+        d["salu_issue_frac"] = round(min(1.0, s_rate / PEAK["salu_per_cu_cycle"]), 3)
+        if kind == "config5" and k in clock.get(codec, {}):
+            ghz, ns = clock[codec][k]
+            d["clock_GHz_measured"] = round(ghz, 3)
+            d["cu_busy_share_of_kernel"] = round(busy / N_CU / (ghz * ns), 3)
+        d["bound"] = ("scalar unit (one per CU)" if d["salu_issue_frac"] >= 0.6 else
                       "lds-pipe" if d["lds_pipe_busy_frac"] >= 0.6 else
-                      "issue" if d["wave_time_issue_stalled_frac"] + d["wave_time_issuing_frac"] >= 0.6 else
+                      "mixed: vector + scalar + LDS issue, none saturated; latency at the resident waves" if d["wave_time_waiting_frac"] < 0.6 else
                       "latency (waves parked in s_waitcnt / barriers)")
         sq.setdefault(WL[kind], {})[k] = {"codec": codec, "derived": d, "per_launch": raw}
-json.dump({"how": "rocprofv3 --kernel-trace --pmc <8 SQ counters> -- python tools/gpu_leg.py single:<codec> 3, two passes (A: SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY "
+json.dump({"issue_peaks_measured": PEAK, "how": "rocprofv3 --kernel-trace --pmc <8 SQ counters> -- python tools/gpu_leg.py single:<codec> 3, two passes (A: SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY "
                   "SQ_ACTIVE_INST_ANY/_VALU/_SCA/_LDS; B: SQ_INSTS_VALU/_SALU/_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS). "
                   "Averages per launch. wave-time fractions are shares of SQ_WAVE_CYCLES (WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES); lds_pipe_busy = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES.",
            "workloads": sq}, open(P("sq_counters.json"), "w"), indent=1)
 r = json.load(open(P("bench.json"))) if os.path.exists(P("bench.json")) else {"value": None, "roofline": {"frac": None, "traffic": None}}
-print(r["value"], r["roofline"]["frac"], r["roofline"]["traffic"], r["roofline"].get("secondary", {}) and r["roofline"]["secondary"].get("derived", {}).get("bound"))
+print(r["value"], r["roofline"]["frac"], r["roofline"]["traffic"])
+if os.path.exists(P("bench_extra.json")):
+    r = json.load(open(P("bench_extra.json")))                     # (the decode tables below are made from the whole document)
 
 # the decompression legs of the same bench line, kernel by kernel (HIP events), with the SQ shares of the decoder kernels
 if "extra" in r and "decompress" in r["extra"]:
