@@ -17,12 +17,13 @@ digests of the REAL reference (tests/golden/corpus_full.json) -- `parity_checked
 independent 64 KiB units) and Xpress+Huffman (one unit per file, 64 KiB chunks with the previous chunk as window) run on
 the same batch right after and are reported under extra.config5, reduced over the ranks the same way.
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel: algorithmic bytes per launch / HIP-event kernel time vs the
-8 TB/s HBM peak; `traffic` from the committed PMC passes of the same command; `secondary` = the pipe that actually limits the
-kernel, from committed SQ counters) and, at N = 1, `cpu_baseline` (the reference's own CPU encoder, oracle/_ref, on this
-host's cores; a bounded sample) for all three codecs. At N = 1 the line also carries BASELINE configs[1..3] one by one
-(extra.single_gpu: mozilla as 12 505 LZNT1 chunks = the round-1 headline, 3 239 Xpress units, Xpress+Huffman file mode)
-and the decompression leg.
+Rank 0 prints ONE SHORT JSON line (< 4 KB, scalars only; `short_line` below): the contract's keys, `config` (the workload and, per codec, MB/s,
+ms per step, roofline fraction, parity verdict, CPU figures, the one-rank-of-8 ratio as flat keys), `roofline` (dominant kernel: algorithmic bytes
+per launch / HIP-event kernel time vs the 8 TB/s HBM peak; `traffic` from the committed PMC passes of the same command) and, at N = 1, `cpu_baseline`
+(the reference's own CPU encoder, oracle/_ref, on this host's cores: the leg's unit list in one pass, the load-balanced figure, one thread). The WHOLE
+document -- BASELINE configs[1..3] one by one with their host-pointer end-to-end figures, what one rank of an 8-GPU run holds, the suffix-array
+flavour, the decompression legs, every kernel's time and the counter-derived `secondary` block of every roofline -- is written to
+bench_extra.json beside this script (and to gpurun_out/ when that exists); `--full` prints it instead of the short line.
 """
 import argparse
 import json
@@ -503,6 +504,20 @@ def sharded_leg(m, ctx, cor, fmt, rank, world, steps, warmup, sharding, dev):
     return res
 
 
+def short_line(res):
+    """What rank 0 prints: the contract's keys, scalars only -- `config` flat, `roofline` and `cpu_baseline` cut to their headline keys, no `extra`, no
+    sentence longer than a workload name. (tests/test_bench_host.py checks this on the committed document of the last profiled run.)"""
+    line = {k: v for k, v in res.items() if k != "extra"}
+    if res.get("roofline"):
+        line["roofline"] = {k: res["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_per_launch",
+                                                               "launches_per_step", "algorithmic_bytes_per_launch")}
+    if res.get("cpu_baseline"):
+        cb = res["cpu_baseline"]
+        line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "balanced_value": cb["balanced_value"],
+                                "single_thread_value": cb["single_thread"]["value"], "sample": cb["sample"][:160]}
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -647,14 +662,7 @@ def main():
     full = dict(res)
     if extra:
         full["extra"] = extra
-    line = dict(res)
-    if res.get("roofline"):
-        line["roofline"] = {k: res["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_per_launch",
-                                                               "launches_per_step", "algorithmic_bytes_per_launch")}
-    if res.get("cpu_baseline"):
-        cb = res["cpu_baseline"]
-        line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "balanced_value": cb["balanced_value"],
-                                "single_thread_value": cb["single_thread"]["value"], "sample": cb["sample"][:160]}
+    line = short_line(res)
     if rank == 0:
         for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
             if os.path.isdir(d):

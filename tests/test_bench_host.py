@@ -51,5 +51,29 @@ def test_cpu_baseline_runs_the_legs_own_units():
     for fmt, words in ((2, "whole-file units"), (3, "independent 64 KiB units"), (4, "whole-file units")):
         r = bench.cpu_baseline(fmt, cor, budget_s=0.5)
         assert r["value"] > 0 and r["single_thread"]["value"] > 0 and r["cores"] >= 1 and words in r["sample"], r
+        assert r["balanced_value"] >= r["value"] * 0.5, r          # (bytes x threads / thread-seconds inside ms_compress: never far below the one-pass figure)
     r = bench.cpu_baseline(2, cor, budget_s=0.5, sa_dict=True)
     assert r is None or (r["value"] > 0 and r["kind"] == "reference")
+
+
+def test_the_printed_line_stays_short_and_parseable():
+    """bench.short_line on the whole document of the last profiled run (profiles/r05_bench_extra.json): what rank 0 prints must stay under 4 KB
+    (the driver's record keeps the last 8 KB of stdout: round 4's 20.8 KB line went unparsed), carry the contract's keys and hold no prose."""
+    import json
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_extra.json")))
+    line = bench.short_line(full)
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < 4096 and "extra" not in line
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert set(line["roofline"]) == {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_per_launch", "launches_per_step", "algorithmic_bytes_per_launch"}
+    assert 0 < line["roofline"]["frac"] < 1 and line["cpu_baseline"]["balanced_value"] > 0
+    assert "configs[4]" in line["config"]["workload"]
+
+    def walk(x):
+        if isinstance(x, dict):
+            for v in x.values():
+                walk(v)
+        elif isinstance(x, str):
+            assert len(x) <= 200
+    walk(line)

@@ -107,7 +107,8 @@ for f in sorted(glob.glob(os.path.join(src, "sqa_*_counter_collection.csv"))):
             ghz, ns = clock[codec][k]
             d["clock_GHz_measured"] = round(ghz, 3)
             d["cu_busy_share_of_kernel"] = round(busy / N_CU / (ghz * ns), 3)
-        d["bound"] = ("scalar unit (one per CU)" if d["salu_issue_frac"] >= 0.6 else
+        d["bound"] = ("lds-pipe" if d["lds_pipe_busy_frac"] >= 0.8 else
+                      "scalar unit (one per CU)" if d["salu_issue_frac"] >= 0.6 else
                       "lds-pipe" if d["lds_pipe_busy_frac"] >= 0.6 else
                       "mixed: vector + scalar + LDS issue, none saturated; latency at the resident waves" if d["wave_time_waiting_frac"] < 0.6 else
                       "latency (waves parked in s_waitcnt / barriers)")
