@@ -38,6 +38,9 @@ void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, 
 // arrays for a superset of the true token starts; the offsets of all other positions are 0.
 void launch_xp_lazy2(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, uint16_t* mlen3, uint16_t* moff);
 
+// the lazy finder for Xpress+Huffman (xhuff_lazy.hip, round 5; a measurement mode, MSCOMP_AMD_XH_LAZY=1): the chunk's links in LDS, candidate bytes from L2
+void launch_xh_lazy(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead, uint16_t* mlen3);
+
 // ---- Xpress stream emission (xpress_emit.hip): one wavefront per unit ----
 void set_xpress_emit_mode(int mode);
 int xpress_emit_mode_for(uint32_t n_units, uint32_t n_chunks);
