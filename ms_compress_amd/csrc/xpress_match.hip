@@ -306,7 +306,12 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 				// the link of xr is fetched first (L2 latency for Xpress+Huffman) and consumed after the compare
 				// (byte offset in 32 bits, zero-extended: the gather is `global_load_ushort v, v_offset, s[base]`; the 64-bit index form cost a
 				// v_lshl_add_u64 per step)
-				uint32_t x = (LINKW == WINDOW) ? (uint32_t)s_links[(uint32_t)xr - lrel]
+				uint32_t x;
+#if defined(XF_PROBE) && XF_PROBE == 7        /* dev probe (SUBTRACTIVE, not bit-exact): the link of ANOTHER position, chosen so that the 64 lanes of a wave read consecutive links (a coalesced load instead of a divergent gather; the chain then walks other, equally real, positions) */
+				x = (uint32_t)lkw[((uint32_t)pr - 1u - chain) & 0xFFFFu];
+				if (false)
+#endif
+				x = (LINKW == WINDOW) ? (uint32_t)s_links[(uint32_t)xr - lrel]
 				                               : (uint32_t)*reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(lkw) + (u64)(uint32_t)((uint32_t)xr << 1));
 				// 16 bytes per step against my own 48 bytes held in registers (lengths are capped at 48 here)
 				uint4 c = ld128(s_data, (uint32_t)xr);
