@@ -52,6 +52,35 @@ __global__ void mixed_kernel(uint32_t* out, int iters)
 	}
 	if ((a0 ^ a1 ^ a2 ^ a3 ^ s0 ^ s1 ^ s2 ^ s3) == 0x12345u) { out[0] = 1; }
 }
+// VOP3 + scalar interleaved in one wave
+__global__ void mixed3_kernel(uint32_t* out, int iters)
+{
+	uint32_t a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3;
+	uint32_t s0 = blockIdx.x, s1 = 1, s2 = 2, s3 = 3;
+	for (int i = 0; i < iters; ++i) {
+		asm volatile(REP16("v_alignbyte_b32 %0, %0, %1, 1\n s_add_u32 %4, %4, %5\n v_alignbyte_b32 %1, %1, %2, 2\n s_add_u32 %5, %5, %6\n v_alignbyte_b32 %2, %2, %3, 3\n s_add_u32 %6, %6, %7\n v_alignbyte_b32 %3, %3, %0, 1\n s_add_u32 %7, %7, %4\n")
+		             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) :: "scc");
+	}
+	if ((a0 ^ a1 ^ a2 ^ a3 ^ s0 ^ s1 ^ s2 ^ s3) == 0x12345u) { out[0] = 1; }
+}
+// vector work and scalar work in DIFFERENT waves of a block: even waves run the vector loop, odd waves the scalar loop (can a CU issue both at their own peaks?)
+__global__ void split_kernel(uint32_t* out, int iters)
+{
+	uint32_t a0 = threadIdx.x, a1 = 1, a2 = 2, a3 = 3;
+	uint32_t s0 = blockIdx.x, s1 = 1, s2 = 2, s3 = 3;
+	if ((threadIdx.x >> 6) & 1u) {
+		for (int i = 0; i < iters; ++i) {
+			asm volatile(REP16("s_add_u32 %0, %0, %1\n s_add_u32 %1, %1, %2\n s_add_u32 %2, %2, %3\n s_add_u32 %3, %3, %0\n") : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) :: "scc");
+			asm volatile(REP16("s_xor_b32 %0, %0, %1\n s_xor_b32 %1, %1, %2\n s_xor_b32 %2, %2, %3\n s_xor_b32 %3, %3, %0\n") : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) :: "scc");
+		}
+	} else {
+		for (int i = 0; i < iters; ++i) {
+			asm volatile(REP16("v_add_u32 %0, %0, %0\n v_add_u32 %1, %1, %1\n v_add_u32 %2, %2, %2\n v_add_u32 %3, %3, %3\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+			asm volatile(REP16("v_xor_b32 %0, %0, %1\n v_xor_b32 %1, %1, %2\n v_xor_b32 %2, %2, %3\n v_xor_b32 %3, %3, %0\n") : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+		}
+	}
+	if ((a0 ^ a1 ^ a2 ^ a3 ^ s0 ^ s1 ^ s2 ^ s3) == 0x12345u) { out[0] = 1; }
+}
 template <class K> static double run(K k, int blocks, int threads, int iters, uint32_t* d)
 {
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -79,7 +108,10 @@ int main()
 		const double v = waves * iters * 128.0 / cus / (tv * 1e6), v3 = waves * iters * 128.0 / cus / (t3 * 1e6);
 		const double s = waves * iters * 128.0 / cus / (ts * 1e6);
 		const double mv = waves * iters * 64.0 / cus / (tm * 1e6);
-		printf("waves/SIMD %d | VALU (v_add/v_xor) %.3f  VOP3 (alignbyte/min3) %.3f  SALU %.3f | mixed: VALU %.3f + SALU %.3f   wave-instructions per CU per ns (divide by the clock in GHz for per cycle)\n", wps, v, v3, s, mv, mv);
+		const double tm3 = run(mixed3_kernel, blocks, 256, iters, d), tsp = run(split_kernel, blocks, 256, iters, d);
+		const double m3 = waves * iters * 64.0 / cus / (tm3 * 1e6);
+		const double sp = waves / 2 * iters * 128.0 / cus / (tsp * 1e6);    // per kind: half the waves each (both finish together only if they issue at the same rate: a lower bound for the faster kind)
+		printf("waves/SIMD %d | VALU (v_add/v_xor) %.3f  VOP3 (alignbyte/min3) %.3f  SALU %.3f | interleaved in one wave: VOP2 %.3f + SALU %.3f, VOP3 %.3f + SALU %.3f | vector and scalar in different waves (half each, until the slower half ends): %.3f + %.3f   wave-instructions per CU per ns (divide by the clock in GHz for per cycle)\n", wps, v, v3, s, mv, mv, m3, m3, sp, sp);
 	}
 	return 0;
 }
