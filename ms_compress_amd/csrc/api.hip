@@ -156,7 +156,7 @@ uint32_t chunks_of(MSCompFormat f, bool decompress, uint64_t n)
 
 extern "C" {
 
-const char* mscomp_amd_version(void) { return "mscomp_amd 0.3 (gfx950, HIP; LZNT1 / Xpress / Xpress+Huffman compressors and decompressors, LZNT1 streaming, host batches over several GPUs)"; }
+const char* mscomp_amd_version(void) { return "mscomp_amd 0.5 (gfx950, HIP; LZNT1 / Xpress / Xpress+Huffman compressors and decompressors, LZNT1 streaming, host batches over several GPUs)"; }
 
 size_t lznt1_max_compressed_size(size_t n)       { return n + 3 + 2 * ((n + 4095) / 4096); }
 size_t xpress_max_compressed_size(size_t n)      { return n + 4 + 4 * (n / 32); }
