@@ -45,12 +45,17 @@ __device__ unsigned long long g_lz_prof[16];
 #define LZ_SELF     4u       // candidates each lane scans by itself before the wave cooperates
 #endif
 
-__device__ __forceinline__ uint32_t lz_hash(uint32_t key24) { return (key24 * 0x9E3779B1u) >> (32 - LZ_TBL_BITS); }
+// (never 0: bucket 0 stays empty, so "the end of the bucket before mine" is always cnt[h - 1] -- no special case in the parse.
+// Keys that hash to 0 share bucket 1: a bucket may hold several keys anyway, the 3-byte compare sorts them out.)
+__device__ __forceinline__ uint32_t lz_hash(uint32_t key24) { const uint32_t h = (key24 * 0x9E3779B1u) >> (32 - LZ_TBL_BITS); return h ? h : 1u; }
 
 // position-dependent split of the 16-bit match token (lznt1_compress.cpp:51,66) -- pure function of pos
 __device__ __forceinline__ uint32_t lz_shift(uint32_t pos)
 {
-	return pos <= 16u ? 12u : 12u - ((32u - (uint32_t)__builtin_clz(pos - 1u)) - 4u);
+	// = pos <= 16 ? 12 : 12 - (bits(pos - 1) - 4), as one unsigned minimum: clz(pos - 1) - 16 is >= 12 for pos <= 16 and wraps to a huge
+	// value for pos <= 1 (v_ffbh_u32 gives -1 for 0)
+	uint32_t z; asm("v_ffbh_u32 %0, %1" : "=v"(z) : "v"(pos - 1u));
+	return (z - 16u) < 12u ? z - 16u : 12u;
 }
 
 // racing LDS accesses between lanes of one wave: relaxed wavefront-scope atomics (plain ds_read/ds_write in the ISA;
@@ -61,6 +66,16 @@ __device__ __forceinline__ void     wst32(uint32_t* p, uint32_t v) { __hip_atomi
 __device__ __forceinline__ uint32_t wld32(uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 __device__ __forceinline__ void     wave_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local"); }
 
+// 16 bytes at any byte offset of the chunk in LDS (common.h: lds_ld128), the offset taken modulo 4096: the AND that aligns the dword
+// address also keeps it inside the chunk, so callers need no select for candidates that do not exist (they are masked afterwards).
+__device__ __forceinline__ uint4 lz_ld128(const uint8_t* base, uint32_t off)
+{
+	const uint32_t* a = reinterpret_cast<const uint32_t*>(base + (off & 0xFFCu));
+	const uint32_t sh = off & 3u;
+	const uint32_t w0 = a[0], w1 = a[1], w2 = a[2], w3 = a[3], w4 = a[4];
+	return make_uint4(__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+	                  __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh));
+}
 // Common prefix beyond the first 16 (equal) bytes of d[q..] and d[p..]: 16 bytes per step; the result may exceed maxlen
 // (callers clamp).
 __device__ __forceinline__ uint32_t lz_lcp_tail(const uint8_t* d, uint32_t q, uint32_t p, uint32_t maxlen)
@@ -68,7 +83,7 @@ __device__ __forceinline__ uint32_t lz_lcp_tail(const uint8_t* d, uint32_t q, ui
 	uint32_t l = 16u;
 	for (;;) {
 		uint4 a, b;
-		a = lds_ld128(d, q + l); b = lds_ld128(d, p + l);
+		a = lz_ld128(d, q + l); b = lz_ld128(d, p + l);
 		const uint32_t f = first_nz_byte16(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w);
 		l += f;
 		if (f < 16u || l >= maxlen) { break; }
@@ -81,7 +96,7 @@ __device__ __forceinline__ uint32_t lz_lcp(const uint8_t* d, uint32_t q, bool va
                                            uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3)
 {
 	uint4 c;
-	c = lds_ld128(d, valid ? q : 0u);
+	c = lz_ld128(d, q);
 	const uint32_t f = first_nz_byte16(c.x ^ o0, c.y ^ o1, c.z ^ o2, c.w ^ o3);
 	uint32_t l = (valid && f >= 3u) ? f : 0u;
 	if (l == 16u && maxlen > 16u) { l = lz_lcp_tail(d, q, p, maxlen); }
@@ -96,29 +111,36 @@ struct LzWin { uint32_t key, o0, shift; u64 tokmask, matchmask; };
 __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint16_t* s_cnt, const uint16_t* s_bucket, uint32_t n, uint32_t lane,
                                               uint32_t wbase, uint32_t entry, LzWin& r)
 {
+	entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)entry); wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);   // (uniform: keeps the walk's bookkeeping on the scalar unit)
 	const uint32_t wend = (wbase + 64u < n) ? wbase + 64u : n;
 	const uint32_t p = wbase + lane;
-	const uint4 own = lds_ld128(s_data, p);                       // (aligned dword reads: a misaligned 16-byte read is replayed)
+	const uint4 own = lz_ld128(s_data, p);                       // (aligned dword reads: a misaligned 16-byte read is replayed)
 	const uint32_t o0 = own.x, o1 = own.y, o2 = own.z, o3 = own.w;
 	const uint32_t shift = lz_shift(p);
 	uint32_t maxlen = 0, s = 0, e = 0;                        // my candidates: bucket[s..e) entries that are < p (ascending)
 	if (p >= entry && p > 0 && p + 3u <= n) {
 		const uint32_t mask3 = (1u << shift) + 2u;
 		maxlen = (n - p < mask3) ? n - p : mask3;
-		const uint32_t h = lz_hash(o0 & 0xFFFFFFu);
+		const uint32_t h = lz_hash(o0 & 0xFFFFFFu);          // >= 1
 		e = s_cnt[h];                                          // bucket h = [end[h-1], end[h])
-		s = h ? (uint32_t)s_cnt[h - 1u] : 0u;
+		s = s_cnt[h - 1u];
 	}
-	// 1. the oldest LZ_SELF candidates, in order, early exit at maxlen (LZNT1Dictionary.h:124-135)
-	uint32_t key = 0;                                       // (len << 12) | (4095 - q): larger = longer, then older
-	bool done = false;
-	// All loads are UNCONDITIONAL (clamped index) so that they issue back to back and are waited for once; lanes and
-	// candidates that do not exist are masked afterwards.
+	// 1. the oldest LZ_SELF candidates (LZNT1Dictionary.h:124-135: in order, strictly longer wins, stop at max_len). With
+	// key = (len << 12) | (4095 - q) the reference's choice is simply the MAXIMUM of the candidates' keys: longest first,
+	// then oldest (the candidates come oldest first, so "strictly longer" keeps the oldest of equals), and nothing can
+	// beat a candidate that reached max_len. A key below 3 << 12 (hash collision) is "no match" to everything downstream.
+	uint32_t key = 0;
+	// All loads are UNCONDITIONAL so that they issue back to back and are waited for once: the five bucket entries from one
+	// address (entries past the bucket's end -- the next buckets', or the first words of the table behind the array -- are
+	// masked by the count), the candidates' bytes with the offset taken modulo 4096.
 	uint32_t q[LZ_SELF + 1u];
+	bool ex[LZ_SELF + 1u];                                    // candidate j exists: j < e - s and it lies before me
+	const uint32_t cnt = e - s;
 	#pragma unroll
-	for (uint32_t j = 0; j <= LZ_SELF; ++j) { q[j] = s_bucket[(s + j) & 4095u]; }
+	for (uint32_t j = 0; j <= LZ_SELF; ++j) { q[j] = s_bucket[s + j]; }
 	#pragma unroll
-	for (uint32_t j = 0; j <= LZ_SELF; ++j) { if (s + j >= e) { q[j] = 4096u; } }                          // 4096 = none (>= p)
+	for (uint32_t j = 0; j <= LZ_SELF; ++j) { ex[j] = j < cnt && q[j] < p; }
+	const bool longer = maxlen > 16u;
 #if defined(LZ_PROBE) && LZ_PROBE == 5      /* dev probe (SUBTRACTIVE, not bit-exact): the eager scan of the odd windows is skipped (their positions are literals unless finished) */
 	if (!((wbase >> 6) & 1u))
 #endif
@@ -126,16 +148,14 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 	for (uint32_t j = 0; j < LZ_SELF; j += 4u) {
 		uint4 c[4];
 		#pragma unroll
-		for (int k = 0; k < 4; ++k) { c[k] = lds_ld128(s_data, q[j + k] < p ? q[j + k] : 0u); }
+		for (int k = 0; k < 4; ++k) { c[k] = lz_ld128(s_data, q[j + k]); }
 		#pragma unroll
 		for (int k = 0; k < 4; ++k) {
-			const uint32_t f = first_nz_byte16(c[k].x ^ o0, c[k].y ^ o1, c[k].z ^ o2, c[k].w ^ o3);
-			uint32_t lk = (q[j + k] < p && f >= 3u) ? f : 0u;                  // no such candidate / hash collision
-			if (lk == 16u && maxlen > 16u) { lk = lz_lcp_tail(s_data, q[j + k], p, maxlen); }   // long match
+			uint32_t lk = first_nz_byte16(c[k].x ^ o0, c[k].y ^ o1, c[k].z ^ o2, c[k].w ^ o3);
+			if (ex[j + k] && lk == 16u && longer) { lk = lz_lcp_tail(s_data, q[j + k], p, maxlen); }   // long match
 			lk = lk < maxlen ? lk : maxlen;
-			const bool take = !done && lk > (key >> 12);
-			key = take ? ((lk << 12) | (4095u - q[j + k])) : key;
-			done = done || (take && lk == maxlen);
+			const uint32_t kk = ex[j + k] ? ((lk << 12) | (q[j + k] ^ 4095u)) : 0u;
+			key = kk > key ? kk : key;
 		}
 	}
 #if defined(LZ_PROBE) && LZ_PROBE == 1      /* dev probe: 40 more VALU instructions per window */
@@ -143,13 +163,14 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 #elif defined(LZ_PROBE) && LZ_PROBE == 2    /* dev probe: four more 16-byte LDS reads per window */
 	{ _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) { const uint4 y_ = lds_ld128(s_data, (p * 7u + 64u * q_) & 4095u); asm volatile("" :: "v"(y_.x), "v"(y_.y), "v"(y_.z), "v"(y_.w)); } }
 #endif
-	bool unres = !done && q[LZ_SELF] < p;                    // a 9th older candidate exists and max_len was not reached
+	// 2. greedy walk; unresolved positions (a fifth older candidate exists and max_len was not reached) are finished by the whole wave
+	// when (and only when) the walk lands on them. (The masks are built from ballots of single compares, combined on the scalar
+	// unit: the ballot of a combined condition costs two more vector instructions. len <= maxlen, so "not reached" is key < maxlen << 12.)
+	u64 un = __builtin_amdgcn_ballot_w64(cnt > LZ_SELF) & __builtin_amdgcn_ballot_w64(q[LZ_SELF] < p) & __builtin_amdgcn_ballot_w64(key < (maxlen << 12));
 #if defined(LZ_PROBE) && LZ_PROBE == 6      /* dev probe (SUBTRACTIVE, not bit-exact): no position is ever finished by the wave -- the 4 eager candidates are all there is */
-	unres = false;
+	un = 0;
 #endif
-	// 2. greedy walk; positions with rem != 0 are finished by the whole wave when (and only when) the walk lands on them
-	u64 un = __ballot(unres);                                // unresolved positions
-	u64 mm = __ballot(!unres && (key >> 12) >= 3u);          // resolved positions that have a match
+	u64 mm = __builtin_amdgcn_ballot_w64(key >= (3u << 12)) & ~un;              // resolved positions that have a match
 	// The serial loop only decides which candidates are TAKEN; everything else (which positions are literal tokens)
 	// is derived in parallel afterwards.
 	u64 matchmask = 0;
@@ -159,14 +180,18 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 	// v_readlane per taken match; it leaves the asm block on an unresolved position (st = 1), which is finished by
 	// the whole wave. Stops are only ever removed at the walk's own position, so the table never goes stale ahead.
 	un = sgpr64(un); mm = sgpr64(mm);
+	// (a target at or beyond wn only has to be >= wn: the walk ends there and the position after the window comes from the
+	// match ends below. So no guard for nx >= 64: the shift count wraps, and nx + anything is already >= 64 >= wn.)
 	const uint32_t nx = lane + (key >> 12);
-	const u64 restl = nx < 64u ? (un | mm) >> nx : (u64)0;
-	const uint32_t J = nx >= wn ? nx : (restl ? nx + ctz64(restl) : wn);
-	uint32_t mp;
+	const u64 restl = (un | mm) >> (nx & 63u);
+	const uint32_t zl = min3u(ffbl_raw((uint32_t)restl), ffbl_raw((uint32_t)(restl >> 32)) | 32u, 64u);   // 64 = no stop left
+	const uint32_t J = (nx + zl < wn) ? nx + zl : wn;
+	uint32_t mp, rel;                                            // rel: the next token start, relative to the window (entry < wend here: < 64)
 	{
-		const uint32_t rel = entry > wbase ? entry - wbase : 0u;   // next token start, relative to the window
-		const u64 rest = rel < 64u ? (un | mm) >> rel : (u64)0;
-		mp = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rest ? rel + ctz64(rest) : wn));
+		// first stop at or after the next token start, on the scalar unit: the asm output pins the chain there
+		asm("s_max_u32 %0, %1, %2\n\ts_sub_u32 %0, %0, %2" : "=&s"(rel) : "s"(entry), "s"(wbase) : "scc");   // (a saturating subtract would go to the vector unit)
+		u64 rest; asm("s_lshr_b64 %0, %1, %2" : "=s"(rest) : "s"(un | mm), "s"(rel) : "scc");
+		mp = rest ? rel + ctz64(rest) : wn;
 	}
 	while (mp < wn) {
 		uint32_t st;
@@ -200,21 +225,25 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 			const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)o2, (int)mp), a3 = (uint32_t)__builtin_amdgcn_readlane((int)o3, (int)mp);
 			uint32_t kbest = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)mp);
 			const uint32_t pL = wbase + mp;
+			const bool longL = maxL > 16u;
 			for (uint32_t base = sL + LZ_SELF; base < eL; base += 64u) {
-				const uint32_t idx = base + lane;
-				const uint32_t qq = s_bucket[idx & 4095u];         // unconditional load, masked below
-				const bool valid = idx < eL && qq < pL;            // !valid: this lane is at or beyond pL's own entry
-				const uint32_t l2 = lz_lcp(s_data, qq, valid, pL, maxL, a0, a1, a2, a3);
+				const uint32_t qq = s_bucket[base + lane];         // unconditional load (past the array's end it reads the table), masked below
+				const bool v1 = lane < eL - base, v2 = qq < pL;     // else: this lane is at or beyond pL's own entry
+				const bool valid = v1 && v2;
+				const u64 vmask = __builtin_amdgcn_ballot_w64(v1) & __builtin_amdgcn_ballot_w64(v2);
+				const uint4 c = lz_ld128(s_data, qq);
+				uint32_t l2 = first_nz_byte16(c.x ^ a0, c.y ^ a1, c.z ^ a2, c.w ^ a3);
+				if (valid && l2 == 16u && longL) { l2 = lz_lcp_tail(s_data, qq, pL, maxL); }
+				l2 = l2 < maxL ? l2 : maxL;
 #if defined(LZ_PROBE) && LZ_PROBE == 3      /* dev probe: 20 more VALU instructions per finishing step */
 				{ uint32_t y_ = l2; _Pragma("unroll") for (int q_ = 0; q_ < 20; ++q_) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(y_) : "v"(qq)); } asm volatile("" :: "v"(y_)); }
 #elif defined(LZ_PROBE) && LZ_PROBE == 4    /* dev probe: one more 16-byte LDS read per finishing step */
 				{ const uint4 y_ = lds_ld128(s_data, (qq * 7u + 64u) & 4095u); asm volatile("" :: "v"(y_.x), "v"(y_.y), "v"(y_.z), "v"(y_.w)); }
 #endif
-				const uint32_t k2 = l2 ? ((l2 << 12) | (4095u - qq)) : 0u;
-				const bool past = !valid;
+				uint32_t k2; asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(k2) : "v"((l2 << 12) | (qq ^ 4095u)), "s"(vmask));   // (a key below 3 << 12 is no match)
 				const uint32_t m = wave_max_u32(k2);
-				if ((m >> 12) > (kbest >> 12)) { kbest = m; }    // strictly longer only: older blocks win ties
-				if ((kbest >> 12) == maxL || __ballot(past)) { break; }   // max_len reached / all older candidates seen
+				kbest = m > kbest ? m : kbest;                   // longest, then oldest (older blocks hold the larger 4095 - q)
+				if ((kbest >> 12) == maxL || ~vmask) { break; }  // max_len reached / all older candidates seen
 			}
 			if (lane == mp) { key = kbest; }
 			un = sgpr64(un & ~(((u64)1) << mp));
@@ -227,11 +256,11 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 	}
 	// tokens of the window = positions >= entry that no taken match covers: covered <=> the furthest end of the taken
 	// matches starting at or before me lies beyond me and I am not such a start myself
-	const bool is_m = (matchmask >> lane) & (u64)1;
-	const uint32_t mend = is_m ? p + (key >> 12) : 0u;
+	matchmask = sgpr64(matchmask);
+	uint32_t mend; asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(mend) : "v"(p + (key >> 12)), "s"(matchmask));   // the mask itself selects: no per-lane bit test
 	const uint32_t reach = wave_incl_scan_max(mend);
-	const bool is_tok = p >= entry && p < wend && (is_m || reach <= p);
-	const u64 tokmask = __ballot(is_tok);
+	const u64 range = (~(u64)0 << rel) & (wn >= 64u ? ~(u64)0 : (((u64)1 << wn) - 1u));     // entry <= p < wend, on the scalar unit
+	const u64 tokmask = range & (matchmask | __builtin_amdgcn_ballot_w64(reach <= p));
 	const uint32_t wreach = (uint32_t)__builtin_amdgcn_readlane((int)reach, 63);
 	const uint32_t cur = wreach > wend ? wreach : wend;
 
@@ -254,11 +283,19 @@ template <bool serial>    // (a template, not an argument: the default kernels a
 __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                         uint8_t* __restrict__ slots, uint32_t* __restrict__ slot_size)
 {
-	__shared__ __attribute__((aligned(16))) uint8_t  s_data[4096 + 32];
-	__shared__ __attribute__((aligned(16))) uint16_t s_cnt[LZ_TBL];       // counts -> bucket ends
-	__shared__ __attribute__((aligned(16))) uint16_t s_bucket[4096];      // positions sorted by (hash, position)
-	__shared__ uint32_t s_flagacc[16];                                     // flag bits of the groups in flight
-	__shared__ uint32_t s_flagpos[16];                                     // their byte position in the image
+	// ONE LDS object, the chunk FIRST: its 16-byte reads then need no address arithmetic beyond the AND that aligns them (the DS offset
+	// fields reach 1 KiB / 64 KiB from the register address), and the bucket array is followed by the count table (lz_window reads up to
+	// four entries past a bucket's end)
+	struct __attribute__((aligned(16))) Lds {
+		uint8_t  data[4096 + 32];
+		uint16_t bucket[4096];      // positions sorted by (hash, position)
+		uint16_t cnt[LZ_TBL];       // counts -> bucket ends
+		uint32_t flagacc[16];       // flag bits of the groups in flight
+		uint32_t flagpos[16];       // their byte position in the image
+	};
+	__shared__ Lds L;
+	uint8_t* const s_data = L.data; uint16_t* const s_cnt = L.cnt; uint16_t* const s_bucket = L.bucket;
+	uint32_t* const s_flagacc = L.flagacc; uint32_t* const s_flagpos = L.flagpos;
 
 	const uint32_t lane = threadIdx.x;
 	const uint32_t c = blockIdx.x;
@@ -332,7 +369,7 @@ __global__ __launch_bounds__(64) void lznt1_chunk_kernel(const uint8_t* __restri
 			const uint32_t p = b * 64u + lane;
 			if (p + 2u < n) {
 				const uint32_t h = lz_hash(ld32(s_data + p) & 0xFFFFFFu);
-				const uint32_t start = h ? (uint32_t)s_cnt[h - 1u] : 0u;
+				const uint32_t start = s_cnt[h - 1u];                  // (h >= 1)
 				const uint32_t r = (b & 1u) ? rk[b >> 1] >> 16 : rk[b >> 1] & 0xFFFFu;
 				s_bucket[start + r] = (uint16_t)p;
 			}
@@ -444,16 +481,23 @@ template <bool serial>
 __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                           uint8_t* __restrict__ slots, uint32_t* __restrict__ slot_size)
 {
-	__shared__ __attribute__((aligned(16))) uint8_t  s_data[4096 + 32];
-	__shared__ __attribute__((aligned(16))) uint16_t s_cnt[LZ_TBL];       // counts -> bucket ends; after the parse: prefixes and flags (below)
-	__shared__ __attribute__((aligned(16))) uint16_t s_bucket[4096];
-	__shared__ u64      s_tok[64], s_mat[64];                              // per window
-	__shared__ uint16_t s_endc[64];                                        // parse position after the window
-	__shared__ uint16_t s_ptok[64][LZ4_MAXM];                              // its match tokens, in order
-	__shared__ uint32_t s_prog[LZ4_NSEG];                                         // windows finished in segment j (index + 1)
-	__shared__ uint32_t s_used[LZ4_NSEG];                                         // entry position the seam in front of segment j was repaired against
-	__shared__ uint32_t s_segctr;                                          // next segment to hand out
-	__shared__ uint32_t s_total[2];
+	struct __attribute__((aligned(16))) Lds {                              // one object, the chunk first (see the kernel above); 20 432 B -> 8 blocks per CU
+		uint8_t  data[4096 + 32];
+		uint16_t bucket[4096];
+		uint16_t cnt[LZ_TBL];                                              // counts -> bucket ends; after the parse: prefixes and flags (below)
+		u64      tok[64], mat[64];                                         // per window
+		uint16_t endc[64];                                                 // parse position after the window
+		uint16_t ptok[64][LZ4_MAXM];                                       // its match tokens, in order
+		uint32_t prog[LZ4_NSEG];                                           // windows finished in segment j (index + 1)
+		uint32_t used[LZ4_NSEG];                                           // entry position the seam in front of segment j was repaired against
+		uint32_t segctr;                                                   // next segment to hand out
+		uint32_t total[2];
+	};
+	static_assert(sizeof(Lds) <= 20480, "eight blocks per CU");
+	__shared__ Lds L;
+	uint8_t* const s_data = L.data; uint16_t* const s_cnt = L.cnt; uint16_t* const s_bucket = L.bucket;
+	u64* const s_tok = L.tok; u64* const s_mat = L.mat; uint16_t* const s_endc = L.endc; uint16_t (* const s_ptok)[LZ4_MAXM] = L.ptok;
+	uint32_t* const s_prog = L.prog; uint32_t* const s_used = L.used; uint32_t& s_segctr = L.segctr; uint32_t* const s_total = L.total;
 	uint16_t* const s_T = s_cnt;                                           // [64] tokens before window w          } after the parse
 	uint16_t* const s_S = s_cnt + 64;                                      // [64] token bytes before window w     }
 	uint16_t* const s_flagpos = s_cnt + 128;                               // [512] byte position of group g's flag byte
