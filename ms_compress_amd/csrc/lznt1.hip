@@ -144,17 +144,16 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 #if defined(LZ_PROBE) && LZ_PROBE == 5      /* dev probe (SUBTRACTIVE, not bit-exact): the eager scan of the odd windows is skipped (their positions are literals unless finished) */
 	if (!((wbase >> 6) & 1u))
 #endif
-	#pragma unroll
-	for (uint32_t j = 0; j < LZ_SELF; j += 4u) {
-		uint4 c[4];
+	{
+		uint4 c[LZ_SELF];                                     // (all loads in flight together)
 		#pragma unroll
-		for (int k = 0; k < 4; ++k) { c[k] = lz_ld128(s_data, q[j + k]); }
+		for (uint32_t k = 0; k < LZ_SELF; ++k) { c[k] = lz_ld128(s_data, q[k]); }
 		#pragma unroll
-		for (int k = 0; k < 4; ++k) {
+		for (uint32_t k = 0; k < LZ_SELF; ++k) {
 			uint32_t lk = first_nz_byte16(c[k].x ^ o0, c[k].y ^ o1, c[k].z ^ o2, c[k].w ^ o3);
-			if (ex[j + k] && lk == 16u && longer) { lk = lz_lcp_tail(s_data, q[j + k], p, maxlen); }   // long match
+			if (ex[k] && lk == 16u && longer) { lk = lz_lcp_tail(s_data, q[k], p, maxlen); }   // long match
 			lk = lk < maxlen ? lk : maxlen;
-			const uint32_t kk = ex[j + k] ? ((lk << 12) | (q[j + k] ^ 4095u)) : 0u;
+			const uint32_t kk = ex[k] ? ((lk << 12) | (q[k] ^ 4095u)) : 0u;
 			key = kk > key ? kk : key;
 		}
 	}

@@ -66,6 +66,12 @@ __device__ __forceinline__ uint4 ld128(const uint8_t* base, uint32_t off)
 }
 // index of the first differing byte of two 16-byte blocks given their XOR (16 if equal)
 __device__ __forceinline__ uint32_t first_diff16(const uint4 x) { return first_nz_byte16(x.x, x.y, x.z, x.w); }
+// the same as a BIT index (common.h: first_nz_byte16 without its final shift), limited to capbits (<= 128): the limit rides in the minimum
+__device__ __forceinline__ uint32_t first_diff_bits16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t capbits)
+{
+	const uint32_t a = ffbl_raw(x1) | 32u, b = ffbl_raw(x2) | 64u, c = ffbl_raw(x3) | 96u;
+	return min3u(min3u(ffbl_raw(x0), a, b), c, capbits);
+}
 
 // One 1024-thread block per 64 KiB link chunk (its 128 KiB head table fills the CU's LDS), software-pipelined over
 // 4096-position tiles:
@@ -250,14 +256,13 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 	// links of this chunk; the previous chunk's array directly precedes it, so a window-relative position xr is entry
 	// lkw[xr] of an array that starts where the window starts (unsigned 32-bit index: scalar base + lane offset)
 	const uint16_t* __restrict__ lkg = links + (u64)lc * 65536u;
-	const uint16_t* __restrict__ lkw = lkg - (ptrdiff_t)(cbase - wstart);
+	const uint16_t* __restrict__ lkw = lkg - (ptrdiff_t)(cbase - wstart); (void)lkw;   // (dev probes only)
 	const uint16_t* __restrict__ lh_prev = lasthead + (u64)(lc - (k ? 1u : 0u)) * 32768u;
 	const uint32_t tn = (cn - tstart < XP_TILE) ? cn - tstart : XP_TILE;
 	// 65535 as the previous chunk's head is indistinguishable from "none" (0xFFFF): decide by that position's hash
 	const uint32_t prev_last_hash = (k > 0) ? xp_hash3(ldg32_safe(d, cbase - 1u, n)) : 0xFFFFFFFFu;
 	// everything below is 32-bit and relative to the staged window (s_data[0] = unit position wstart)
 	const int32_t crel = (int32_t)(uint32_t)(cbase - wstart);                 // start of this chunk   (>= 0)
-	const int32_t prel = crel - 65536;                                        // start of the previous chunk (may be < 0)
 	const uint32_t lrel = (uint32_t)(lwstart - wstart);                       // first position whose link is in s_links
 	const uint32_t p0r = (uint32_t)(P0 - wstart);
 	const u64 tail = n - P0;                                                  // bytes from the tile start to the unit end
@@ -265,35 +270,46 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 #ifdef XF_PROFILE
 	unsigned long long xf_acc[8] = {0};
 #endif
+	// The walk in numbers relative to THIS chunk's start: rc = candidate position (< 0: in the previous chunk), o = my own; a link value is an
+	// offset inside its position's chunk, so the next candidate is x + adj with adj = 0 until the chain crosses into the previous chunk
+	// (-65536 from then on). Best so far as ONE signed key = (len << 16) - distance: the maximum is the longest and, among equals, the
+	// nearest = the first met (XpressDictionary.h:164-176 takes strictly longer only); len < 3 never beats the start value 2 << 16.
+	// The chain counter is the same in every lane still walking, so it lives on the scalar unit. (Round 5: 49 -> 34 vector instructions
+	// per candidate -- and no time gained, 65.1 -> 64.9 ms: a step of the 64 KiB-window instance is the divergent link gather, one L2
+	// request per lane -- 1.1e10 per pass of configs[4], the L1 is stalled on pending misses 60 % of the time -- DESIGN 8.)
+	const int32_t nmax = -(int32_t)max_off;
+	const uint16_t* __restrict__ lkb = lkg - 65536;                            // links by (rc + 65536): the previous chunk's array directly precedes this one
+	constexpr int32_t K48 = (47 << 16) + 1;                                    // key >= K48 <=> len == 48 (NiceLength: the walk ends)
 	for (uint32_t t = tid; t < tn; t += NT) {
 		const uint32_t o = tstart + t;                                          // offset in chunk
 		const uint32_t pr = p0r + t;                                            // window-relative position of P
-		uint32_t best = 2, boff = 0;
+		int32_t key = 2 << 16;
 		const bool can = ((u64)t + 2u < tail) && (!clip || cn - o >= 3u);
+#if defined(XF_PROBE) && XF_PROBE == 4       /* dev probe (SUBTRACTIVE, not bit-exact): walk 6 chain candidates instead of 11 */
+		uint32_t chain = 6;
+#else
+		uint32_t chain = 11;
+#endif
 		if (can) {
 			const uint4 oa = ld128(s_data, pr), ob = ld128(s_data, pr + 16u), oc = ld128(s_data, pr + 32u);
 			const uint32_t h = xp_hash3(oa.x);
 			const u64 lim = tail - t - 1u;                                          // n - P - 1: never count the buffer's final byte
 			const uint32_t cap = lim < 48u ? (uint32_t)lim : 48u;
+			const uint32_t capb = (cap < 16u ? cap : 16u) << 3;                     // the cap on the first 16 bytes, in bits
 			const bool prev_last = (prev_last_hash == h);
-#if defined(XF_PROBE) && XF_PROBE == 4       /* dev probe (SUBTRACTIVE, not bit-exact): walk 6 chain candidates instead of 11 */
-			uint32_t chain = 6;
-#else
-			uint32_t chain = 11;
-#endif
 			// first candidate: my own link (an offset inside the chunk), else the previous chunk's last position with my hash
-			int32_t xr;
+			int32_t rc, adj = 0, negd;
 			bool alive;
 			{
 				uint32_t x = (LINKW == WINDOW) ? (uint32_t)s_links[pr - lrel] : (uint32_t)lkg[o];
-				int32_t base = crel;
 				alive = true;
 				if (x == 0xFFFFu) {
 					if (k == 0) { alive = false; }
-					else { x = lh_prev[h]; base = prel; alive = (x != 0xFFFFu) || prev_last; }
+					else { x = lh_prev[h]; adj = -65536; alive = (x != 0xFFFFu) || prev_last; }
 				}
-				xr = base + (int32_t)x;
-				alive = alive && (uint32_t)((int32_t)pr - xr) <= max_off;          // (also catches xr < 0: outside the window)
+				rc = (int32_t)x + adj;
+				negd = rc - (int32_t)o;                                             // -(distance)
+				alive = alive && negd >= nmax;                                      // (also catches a candidate in front of the window)
 			}
 			XF_CNT(0, 1)
 			// One candidate per iteration, straight-line: every live lane does the 16-byte compare (in a wave some lane
@@ -302,55 +318,55 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 			while (alive) {
 				XF_CNT(1, 1)
 				if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == (uint32_t)__builtin_ctzll(__ballot(1))) { XF_CNT(2, 64) }
-				const uint32_t dist = (uint32_t)((int32_t)pr - xr);
-				// the link of xr is fetched first (L2 latency for Xpress+Huffman) and consumed after the compare
-				// (byte offset in 32 bits, zero-extended: the gather is `global_load_ushort v, v_offset, s[base]`; the 64-bit index form cost a
-				// v_lshl_add_u64 per step)
+				const uint32_t xr = (uint32_t)(rc + crel);                         // window-relative
+				// the link of the candidate is fetched first (L2 latency for Xpress+Huffman) and consumed after the compare
+				// (byte offset in 32 bits, zero-extended: the gather is `global_load_ushort v, v_offset, s[base]`)
 				uint32_t x;
 #if defined(XF_PROBE) && XF_PROBE == 7        /* dev probe (SUBTRACTIVE, not bit-exact): the link of ANOTHER position, chosen so that the 64 lanes of a wave read consecutive links (a coalesced load instead of a divergent gather; the chain then walks other, equally real, positions) */
 				x = (uint32_t)lkw[((uint32_t)pr - 1u - chain) & 0xFFFFu];
 				if (false)
 #endif
-				x = (LINKW == WINDOW) ? (uint32_t)s_links[(uint32_t)xr - lrel]
-				                               : (uint32_t)*reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(lkw) + (u64)(uint32_t)((uint32_t)xr << 1));
+				x = (LINKW == WINDOW) ? (uint32_t)s_links[xr - lrel]
+				                      : (uint32_t)*reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(lkb) + (u64)(uint32_t)((rc << 1) + 131072));
 				// 16 bytes per step against my own 48 bytes held in registers (lengths are capped at 48 here)
-				uint4 c = ld128(s_data, (uint32_t)xr);
+				uint4 c = ld128(s_data, xr);
 #if defined(XF_PROBE) && XF_PROBE == 1        /* dev probe: one more divergent global gather per step */
 				{ const uint32_t y = lkw[((uint32_t)xr * 7u + 13u) & 0xFFFFu]; asm volatile("" :: "v"(y)); }
 #elif defined(XF_PROBE) && XF_PROBE == 2      /* dev probe: ten more VALU instructions per step */
-				{ uint32_t y = dist; _Pragma("unroll") for (int q_ = 0; q_ < 10; ++q_) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(y) : "v"(c.x)); } asm volatile("" :: "v"(y)); }
+				{ uint32_t y = (uint32_t)negd; _Pragma("unroll") for (int q_ = 0; q_ < 10; ++q_) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(y) : "v"(c.x)); } asm volatile("" :: "v"(y)); }
 #elif defined(XF_PROBE) && XF_PROBE == 3      /* dev probe: five more LDS dword reads per step */
 				{ const uint4 y = ld128(s_data, ((uint32_t)xr * 5u + 77u) & 0xFFFFu); asm volatile("" :: "v"(y.x), "v"(y.y), "v"(y.z), "v"(y.w)); }
 #endif
-				uint32_t l = first_diff16(make_uint4(c.x ^ oa.x, c.y ^ oa.y, c.z ^ oa.z, c.w ^ oa.w));
+				// matched length in BITS, capped inside the minimum that finds the first difference (the low three bits are dropped below)
+				uint32_t lb = first_diff_bits16(c.x ^ oa.x, c.y ^ oa.y, c.z ^ oa.z, c.w ^ oa.w, capb);
 #if defined(XF_PROBE) && XF_PROBE == 5       /* dev probe (SUBTRACTIVE, not bit-exact): no compare beyond the first 16 bytes */
 				if (false) {
 #else
-				if (l == 16u && cap > 16u) {
+				if (lb >= 128u && cap > 16u) {
 #endif
-					c = ld128(s_data, (uint32_t)xr + 16u);
-					l = 16u + first_diff16(make_uint4(c.x ^ ob.x, c.y ^ ob.y, c.z ^ ob.z, c.w ^ ob.w));
+					c = ld128(s_data, xr + 16u);
+					uint32_t l = 16u + first_diff16(make_uint4(c.x ^ ob.x, c.y ^ ob.y, c.z ^ ob.z, c.w ^ ob.w));
 					if (l == 32u && cap > 32u) {
-						c = ld128(s_data, (uint32_t)xr + 32u);
+						c = ld128(s_data, xr + 32u);
 						l = 32u + first_diff16(make_uint4(c.x ^ oc.x, c.y ^ oc.y, c.z ^ oc.z, c.w ^ oc.w));
 					}
+					lb = (l < cap ? l : cap) << 3;
 				}
-				l = l < cap ? l : cap;
-				const bool better = l > best;                                       // strictly longer only: the nearer one wins ties
-				best = better ? l : best;
-				boff = better ? dist : boff;
-				// next candidate: x is an offset inside xr's chunk (a link is always < its position, so 0xFFFF is unambiguous)
-				const bool incur = xr >= crel;
-				int32_t base = incur ? crel : prel;
-				bool more = (best < 48u) && (--chain != 0u);
+				const int32_t kc = (int32_t)((lb & ~7u) << 13) + negd;               // (len << 16) - distance
+				key = kc > key ? kc : key;
+				// next candidate: x is an offset inside the candidate's chunk (a link is always < its position, so 0xFFFF is unambiguous)
+				if (--chain == 0u) { break; }                                          // MaxChain (uniform)
+				bool more = key < K48;
 				if (x == 0xFFFFu) {
-					if (incur && k != 0) { x = lh_prev[h]; base = prel; more = more && ((x != 0xFFFFu) || prev_last); }
+					if (rc >= 0 && k != 0) { x = lh_prev[h]; adj = -65536; more = more && ((x != 0xFFFFu) || prev_last); }
 					else { more = false; }
 				}
-				xr = base + (int32_t)x;
-				alive = more && (uint32_t)((int32_t)pr - xr) <= max_off;
+				rc = (int32_t)x + adj;
+				negd = rc - (int32_t)o;
+				alive = more && negd >= nmax;
 			}
 		}
+		const uint32_t best = (uint32_t)(key + 65535) >> 16, boff = (best << 16) - (uint32_t)key;
 		const bool m = best >= 3u;
 		const u64 gi = (u64)lc * 65536u + o;
 		*reinterpret_cast<uint32_t*>(&mlen3[gi]) = m ? (best - 3u) | (boff << 16) : 0u;      // one word: length - 3 | offset << 16 (moff is its upper half)
