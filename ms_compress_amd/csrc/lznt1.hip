@@ -137,7 +137,9 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 	bool ex[LZ_SELF + 1u];                                    // candidate j exists: j < e - s and it lies before me
 	const uint32_t cnt = e - s;
 	#pragma unroll
-	for (uint32_t j = 0; j <= LZ_SELF; ++j) { q[j] = s_bucket[s + j]; }
+	// (five 2-byte reads, kept apart by the relaxed-atomic form: merged into an 8-byte + a 2-byte read, as the compiler does with plain loads, the 8-byte
+	// one is only 2-byte aligned and is replayed -- SQ_LDS_UNALIGNED_STALL 14 % of the LDS pipe's busy cycles, 54.4 against 53.3 ms on configs[4])
+	for (uint32_t j = 0; j <= LZ_SELF; ++j) { q[j] = wld16(const_cast<uint16_t*>(s_bucket) + s + j); }
 	#pragma unroll
 	for (uint32_t j = 0; j <= LZ_SELF; ++j) { ex[j] = j < cnt && q[j] < p; }
 	const bool longer = maxlen > 16u;
