@@ -462,15 +462,15 @@ extern "C" void mscomp_amd_debug_lz_prof(unsigned long long* out, int reset)
 // a window equals the recorded one), wave 0 checks that no repair ran through a whole segment (else it cascades,
 // serially), scans tokens / bytes per window, and the four waves emit their segments at known offsets; the flag bytes
 // are OR-ed into a per-group LDS array and stored at the end.
-// Segments (in windows): 4 of shrinking length (24 / 19 / 12 / 9) -- a window costs more the later it lies in the chunk
-// (fuller buckets) and every seam costs a repair. Headline workload: 16 equal segments handed out in order 1.37 ms,
-// 8: 1.23, 4 equal: 1.20; boundaries 20/36/50: 1.17, 24/43/55: 1.13, 26/46/57: 1.10, 28/49/59: 1.23; on the other corpus
-// members the less skewed splits are 2-3 % better, hence the middle.
+// Segments (in windows): 4 of shrinking length (22 / 18 / 13 / 11) -- a window costs more the later it lies in the chunk
+// (fuller buckets) and every seam costs a repair. Round 5, after the window parse lost a quarter of its vector instructions (the
+// finishing steps, which grow along the chunk, lost less), configs[4]: boundaries 16/32/48: 56.9 ms, 18/34/49: 54.9, 20/37/51: 52.6,
+// 22/40/53: 52.5, 24/43/55 (rounds 3-4): 53.5, 26/46/57: 54.4.
 #define LZ4_NSEG 4u
 #ifndef LZ4_B1
-#define LZ4_B1 24u
-#define LZ4_B2 43u
-#define LZ4_B3 55u
+#define LZ4_B1 22u
+#define LZ4_B2 40u
+#define LZ4_B3 53u
 #endif
 __device__ __forceinline__ uint32_t lz4_seg_start(uint32_t j) { return j == 0 ? 0u : j == 1 ? LZ4_B1 : j == 2 ? LZ4_B2 : j == 3 ? LZ4_B3 : 64u; }
 #define LZ4_MAXM 22u                                             // matches that can START in one window of 64 positions
