@@ -431,7 +431,10 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 	if (ok && format == MSCOMP_LZNT1) { ok = c->slots.reserve((size_t)p->n_chunks * LZNT1_SLOT + 64); }
 	if (ok && format != MSCOMP_LZNT1) {
 		const size_t per = (size_t)p->n_chunks * 65536u * sizeof(uint16_t) + 64;
-		ok = c->links.reserve(per) && c->mlen3.reserve(2 * per) && c->lasthead.reserve(per / 2 + 64);      // (mlen3: 4 bytes per position, both halves of the match word)
+		// (mlen3: 4 bytes per position, both halves of the match word. Xpress+Huffman's sorted-span finder keeps its padded position array in `links`
+		// and its bucket starts, XS_STARTS_STRIDE words per chunk, in `lasthead`)
+		const size_t lh = format == MSCOMP_XPRESS_HUFF ? (size_t)p->n_chunks * XS_STARTS_STRIDE * sizeof(uint32_t) + 64 : per / 2 + 64;
+		ok = c->links.reserve(per + 2 * XS_FRONT_PAD) && c->mlen3.reserve(2 * per) && c->lasthead.reserve(lh);
 		if (ok && format == MSCOMP_XPRESS) {
 			const size_t nw = (size_t)p->n_chunks * 1024u + 64;
 			ok = c->wtok.reserve(nw * 8) && c->wmat.reserve(nw * 8) && c->wfar.reserve(nw * 4);
@@ -621,10 +624,16 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 		uint32_t* extra = static_cast<uint32_t*>(c->extra.p); uint8_t* lens = static_cast<uint8_t*>(c->lens.p);
 		uint16_t* codes = static_cast<uint16_t*>(c->codes.p); uint32_t* fbflag = static_cast<uint32_t*>(c->fbflag.p);
 		uint32_t* fb_count = static_cast<uint32_t*>(c->fb_list.p); uint32_t* fb_list = fb_count + 16;
-		{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
 		static const bool xh_lazy = [] { const char* e = getenv("MSCOMP_AMD_XH_LAZY"); return e && atoi(e) != 0; }();   // dev / measurement switch: the lazy finder of xhuff_lazy.hip
-		if (xh_lazy) { KernelTimer t(c, "xh_lazy_kernel"); launch_xh_lazy(st, d_in, p->bt, links, lasthead, mlen3); }
-		else { KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0xFFFFu, 1); }
+		static const int xh_sort = [] { const char* e = getenv("MSCOMP_AMD_XH_SORT"); return e ? atoi(e) : 0; }();      // the finder of xpress_sort.hip (sorted spans instead of the chain walk)
+		if (xh_sort && !xh_lazy) {
+			{ KernelTimer t(c, "xp_sort_kernel"); launch_xp_sort(st, d_in, p->bt, links + XS_FRONT_PAD, reinterpret_cast<uint32_t*>(mlen3), reinterpret_cast<uint32_t*>(lasthead)); }
+			{ KernelTimer t(c, "xp_find2_kernel"); launch_xp_find2(st, d_in, p->bt, links + XS_FRONT_PAD, reinterpret_cast<const uint32_t*>(lasthead), reinterpret_cast<uint32_t*>(mlen3), 0xFFFFu, 1); }
+		} else {
+			{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
+			if (xh_lazy) { KernelTimer t(c, "xh_lazy_kernel"); launch_xh_lazy(st, d_in, p->bt, links, lasthead, mlen3); }
+			else { KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0xFFFFu, 1); }
+		}
 		{ KernelTimer t(c, "xh_parse_kernel"); launch_xh_parse(st, d_in, p->bt, mlen3, moff, tokbits, counts, extra); }
 		{ KernelTimer t(c, "xh_huff_kernel"); launch_xh_huff(st, p->bt, counts, extra, lens, codes, slot_size, fb_list, fb_count, fbflag); }
 		{ KernelTimer t(c, "xh_fallback_kernel"); launch_xh_fallback(st, d_in, p->bt, fb_list, fb_count, XH_FB_BLOCKS, tokbits, lens, codes, slot_size); }

@@ -41,6 +41,15 @@ void launch_xp_lazy2(hipStream_t st, const uint8_t* d_in, const BatchTables& bt,
 // the lazy finder for Xpress+Huffman (xhuff_lazy.hip, round 5; a measurement mode, MSCOMP_AMD_XH_LAZY=1): the chunk's links in LDS, candidate bytes from L2
 void launch_xh_lazy(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead, uint16_t* mlen3);
 
+// the finder without the dependent chain walk (xpress_sort.hip, round 5): positions sorted by (hash, position) per 64 KiB chunk, a position's
+// candidates read as one span of that array. sorted: u16 per position behind XS_FRONT_PAD entries of padding (the caller passes the padded
+// pointer); starts: XS_STARTS_STRIDE u32 per chunk (32768 bucket starts + the total); words: u32 per position -- xp_sort_kernel leaves
+// index | rank << 16 there, xp_find2_kernel replaces it by the match word (the mlen3 / moff array of the other finders).
+#define XS_STARTS_STRIDE 32832u
+#define XS_FRONT_PAD 32u
+void launch_xp_sort(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* sorted, uint32_t* words, uint32_t* starts);
+void launch_xp_find2(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* sorted, const uint32_t* starts, uint32_t* words, uint32_t max_off, int clip);
+
 // ---- Xpress stream emission (xpress_emit.hip): one wavefront per unit ----
 void set_xpress_emit_mode(int mode);
 int xpress_emit_mode_for(uint32_t n_units, uint32_t n_chunks);

@@ -327,6 +327,10 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 				if (false)
 #endif
 				// (cache-scope variants of this gather: non-temporal 126.7 ms, sc1 / sc0 sc1 78.7, sc0 65.1, plain 64.9: the L1 serves ~60 % of the lanes)
+#if defined(XF_PROBE) && XF_PROBE == 8        /* dev probe (not bit-exact): NO link load and no dependent chain -- the next candidate lies 37 bytes further back; the compares are the product's */
+				x = (uint32_t)(rc - adj - 37) & 0xFFFFu; if (rc - adj < 37) { x = 0xFFFFu; }
+				if (false)
+#endif
 				x = (LINKW == WINDOW) ? (uint32_t)s_links[xr - lrel]
 				                      : (uint32_t)*reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(lkb) + (u64)(uint32_t)((rc << 1) + 131072));
 				// 16 bytes per step against my own 48 bytes held in registers (lengths are capped at 48 here)

@@ -33,3 +33,9 @@ def _run(env_extra):
 
 def test_lazy_xpress_huff_finder_gives_the_same_bytes():
     assert _run({"MSCOMP_AMD_XH_LAZY": "1"}) == _run({"MSCOMP_AMD_XH_LAZY": "0"})
+
+
+def test_sorted_span_xpress_huff_finder_gives_the_same_bytes():
+    """csrc/xpress_sort.hip (round 5): the chunk's positions sorted by (hash, position), a position's <= 11 candidates read as two spans of
+    that array instead of a chain walk -- a third way to the same bytes, also a measurement mode (MSCOMP_AMD_XH_SORT=1)."""
+    assert _run({"MSCOMP_AMD_XH_SORT": "1"}) == _run({"MSCOMP_AMD_XH_SORT": "0"})
