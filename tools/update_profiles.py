@@ -28,7 +28,7 @@ if os.path.exists(os.path.join(src, "bench.json")) and os.path.getsize(os.path.j
     shutil.copy(os.path.join(src, "bench.json"), P("bench.json"))                 # the ONE short line the driver parses
 if os.path.exists(os.path.join(src, "bench_extra.json")) and os.path.getsize(os.path.join(src, "bench_extra.json")):
     shutil.copy(os.path.join(src, "bench_extra.json"), P("bench_extra.json"))     # the whole document of the same run (every leg, every kernel)
-for f in ("oneshot_host_pointers.txt", "issue_peak.txt"):
+for f in ("oneshot_host_pointers.txt", "issue_peak.txt", "issue_peak2.txt"):
     if os.path.exists(os.path.join(src, f)) and os.path.getsize(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), P(f))
 for f in ("bench_headline_under_rocprof.json", "bench_full_under_rocprof.json"):
@@ -67,7 +67,7 @@ json.dump({"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WR
            "by_codec": traffic, "workloads": {w: {k: r for c in v.values() for k, r in c.items()} for w, v in traffic.items()}}, open(P("pmc_traffic.json"), "w"), indent=1)
 
 N_XCD, N_CU = 8, 256
-PEAK = {"valu_vop12_per_cu_cycle": 2.0, "valu_vop3_per_cu_cycle": 1.0, "salu_per_cu_cycle": 1.0}      # tools/dev/issue_peak.hip, measured on this GPU (profiles/<tag>_issue_peak.txt)
+PEAK = {"valu_per_cu_cycle": 0.95, "valu_single_source_stream_per_cu_cycle": 1.8, "salu_per_cu_cycle": 1.0}      # tools/dev/issue_peak.hip + issue_peak2.hip, measured on this GPU (profiles/<tag>_issue_peak*.txt)
 clock = {}                                     # codec -> {kernel: (GHz, avg ns)} from the GRBM_GUI_ACTIVE passes of the configs[4] legs
 for f in sorted(glob.glob(os.path.join(src, "clk_config5_*_counter_collection.csv"))):
     codec = os.path.basename(f)[len("clk_config5_"):-len("_counter_collection.csv")]
@@ -93,21 +93,22 @@ for f in sorted(glob.glob(os.path.join(src, "sqa_*_counter_collection.csv"))):
              "lds_bank_conflict_share": round(raw.get("SQ_LDS_BANK_CONFLICT", 0) / idx, 3), "lds_unaligned_stall_share": round(raw.get("SQ_LDS_UNALIGNED_STALL", 0) / idx, 4),
              "lds_cycles_per_lds_instruction": round(idx / max(1, raw.get("SQ_INSTS_LDS", 1)), 2)}
         # Issue rates against what a CU can issue (round 5; replaces round 4's `valu_busy_frac`, a ratio of two counters with different units that came
-        # out above 1): wave-instructions per CU and cycle over the CU's BUSY cycles. Measured peaks of this GPU (tools/dev/issue_peak.hip): 2.0 for
-        # VOP1 / VOP2 vector instructions, 1.0 for 3-operand / modifier VOP3 ones (v_alignbyte, v_min3, clamped adds, ..._e64 compares and selects),
-        # 1.0 scalar (ONE scalar unit per CU for all its waves). The counters do not split VOP3 from VOP2, so the vector fraction is a bracket:
-        # between insts / 2 (all VOP1/2) and insts / 1 (all VOP3), the upper end capped at 1. The scalar fraction is exact.
+        # out above 1): wave-instructions per CU and cycle over the CU's BUSY cycles. Measured peaks of this GPU (tools/dev/issue_peak.hip, issue_peak2.hip):
+        # 0.95 vector instructions per CU cycle for any real mix -- the classic 4 cycles per wave64 instruction on each of the 4 SIMDs; only a stream made
+        # of nothing but single-VGPR-source VOP1 / VOP2 instructions reaches 1.8, and one other instruction in four brings the whole stream back to 0.95
+        # (so the bracket the first half of round 5 printed had the right upper end and a meaningless lower one) -- and 1.0 scalar (ONE scalar unit per CU).
         busy = max(1, raw.get("SQ_BUSY_CU_CYCLES", 1))
         v_rate, s_rate = raw.get("SQ_INSTS_VALU", 0) / busy, raw.get("SQ_INSTS_SALU", 0) / busy
         d["valu_insts_per_cu_cycle"] = round(v_rate, 3)
         d["salu_insts_per_cu_cycle"] = round(s_rate, 3)
-        d["valu_issue_frac_bracket"] = [round(min(1.0, v_rate / PEAK["valu_vop12_per_cu_cycle"]), 3), round(min(1.0, v_rate / PEAK["valu_vop3_per_cu_cycle"]), 3)]
+        d["valu_issue_frac"] = round(min(1.0, v_rate / PEAK["valu_per_cu_cycle"]), 3)
         d["salu_issue_frac"] = round(min(1.0, s_rate / PEAK["salu_per_cu_cycle"]), 3)
         if kind == "config5" and k in clock.get(codec, {}):
             ghz, ns = clock[codec][k]
             d["clock_GHz_measured"] = round(ghz, 3)
             d["cu_busy_share_of_kernel"] = round(busy / N_CU / (ghz * ns), 3)
         d["bound"] = ("lds-pipe" if d["lds_pipe_busy_frac"] >= 0.8 else
+                      "vector issue" if d["valu_issue_frac"] >= 0.9 else
                       "scalar unit (one per CU)" if d["salu_issue_frac"] >= 0.6 else
                       "lds-pipe" if d["lds_pipe_busy_frac"] >= 0.6 else
                       "mixed: vector + scalar + LDS issue, none saturated; latency at the resident waves" if d["wave_time_waiting_frac"] < 0.6 else
