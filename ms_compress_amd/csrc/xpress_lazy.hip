@@ -34,7 +34,8 @@ namespace msc {
 #define XZ_LIST  512u                     // parked walks (positions) of a whole unit: slots are handed out by a counter that only grows, slot i belongs to lane i
 #define XZ_CACHE 4u                       // ends of long matches kept for the other positions inside them
 #ifndef XZ_FREP
-#define XZ_FREP 3u                        // chain candidates a lane may finish per step (the DONE / NEW blocks run once per step)
+#define XZ_FREP 4u                        // chain candidates a lane may finish per step (the DONE / NEW blocks run once per step). Even: the two candidate register
+                                          // sets of the compare loop are back in place after a step. configs[4], round 5: 2: 30.9 ms, 3: 31.0, 4: 28.0, 6: 29.3, 8: 32.3
 #endif
 #define XZ_OWN_EXT 112u                   // a lane compares up to here itself, 16 bytes a step; beyond, the wave compares 256 bytes a step from global memory
 
@@ -148,7 +149,8 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 			// A walk's FIRST candidate (16 bytes and link) is fetched at the END of the step that claimed it (`cand`, `nlk`), so that the LDS round trip
 			// overlaps the other blocks of the next step.
 			uint32_t st = XZ_IDLE, p = 0, q = 0, best = 0, x = 0, dl = 0, cap = 0, lim = 0, chain = 0, elen = 0, nlk = 0;
-			uint4 own = make_uint4(0, 0, 0, 0), cand = make_uint4(0, 0, 0, 0);
+			uint4 own = make_uint4(0, 0, 0, 0), cand = make_uint4(0, 0, 0, 0), candB = make_uint4(0, 0, 0, 0);
+			uint32_t nlkB = 0, nkeep = 0;
 			bool single = false, fetch = false;
 			for (;;) {
 				if (st == XZ_IDLE) {                               // idle lanes take their next job
@@ -161,34 +163,43 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 				// ---- FIND: one 16-byte compare of one chain candidate (its first 16 bytes against my own in registers)
 				// (written with selects, not nested branches: the compiler's exec-mask bookkeeping for the nested form was as long as the
 				// arithmetic; the only branch left guards the loads of the next candidate)
+				// Two register sets for "the candidate being compared" and "the one after it" that swap roles from one compare to the next (round 5:
+				// the select form `if (more) { cand = cand2; nlk = nlk2; }` cost ten v_mov per compare, and this kernel runs at 0.88 of the CU's
+				// vector issue rate). Every lane in FIND takes part in every compare of a step, so all of them hold their live candidate in the same
+				// set; a lane that leaves for FIND2 takes its candidate's link along in `nkeep`. (No test for "no link": 0xFFFF fails the distance
+				// test, p <= 65533 in FIND.)
+#define XZ_COMPARE(CA, NA, CB, NB) { \
+					const bool f = st == XZ_FIND; \
+					if (!__ballot(f)) { break; } \
+					XZ_CNT(2, f ? 1 : 0) \
+					/* the candidate AFTER this one (its place is known: my candidate's link) is asked for before this one is compared, */ \
+					/* so its LDS round trip runs under the compare */ \
+					const bool pf = f && chain > 1u && (p - NA) <= XZ_WIN; \
+					if (pf) { \
+						const uint32_t xw = NA - tb + XZ_WIN; \
+						CB = lds_ld128(s_data, xw); \
+						NB = s_links[xw]; \
+					} \
+					const uint32_t l = xz_diff16(CA, own); \
+					const bool to2 = f && l == 16u && cap > 16u; \
+					const bool upd = f && !to2; \
+					const uint32_t lc2 = l < cap ? l : cap; \
+					const uint32_t key = (lc2 << 16) | (0xFFFFu - (p - x)); \
+					best = (upd && key > best) ? key : best; \
+					chain -= upd ? 1u : 0u; \
+					const bool more = upd && pf && (best >> 16) < 48u; \
+					x = upd ? NA : x; \
+					nkeep = to2 ? NA : nkeep; \
+					dl = to2 ? 16u : dl; \
+					st = to2 ? (uint32_t)XZ_FIND2 : (upd ? (more ? (uint32_t)XZ_FIND : (uint32_t)XZ_DONE) : st); \
+					if (upd) { fetch = false; } }
 				#pragma unroll 1
-				for (uint32_t rep = 0; rep < XZ_FREP; ++rep) {
-					const bool f = st == XZ_FIND;
-					if (!__ballot(f)) { break; }
-					XZ_CNT(2, f ? 1 : 0)
-					// the candidate AFTER this one (its place is known: my candidate's link) is asked for before this one is compared,
-					// so its LDS round trip runs under the compare
-					const bool pf = f && nlk != 0xFFFFu && chain > 1u && (p - nlk) <= XZ_WIN;
-					uint4 cand2 = cand; uint32_t nlk2 = nlk;
-					if (pf) {
-						const uint32_t xw = nlk - tb + XZ_WIN;
-						cand2 = lds_ld128(s_data, xw);
-						nlk2 = s_links[xw];
-					}
-					const uint32_t l = xz_diff16(cand, own);
-					const bool to2 = f && l == 16u && cap > 16u;
-					const bool upd = f && !to2;
-					const uint32_t lc2 = l < cap ? l : cap;
-					const uint32_t key = (lc2 << 16) | (0xFFFFu - (p - x));
-					best = (upd && key > best) ? key : best;
-					chain -= upd ? 1u : 0u;
-					const bool more = upd && pf && (best >> 16) < 48u;
-					x = upd ? nlk : x;
-					dl = to2 ? 16u : dl;
-					st = to2 ? (uint32_t)XZ_FIND2 : (upd ? (more ? (uint32_t)XZ_FIND : (uint32_t)XZ_DONE) : st);
-					if (upd) { fetch = false; }
-					if (more) { cand = cand2; nlk = nlk2; }
+				for (uint32_t rep = 0; rep < XZ_FREP; rep += 2u) {
+					XZ_COMPARE(cand, nlk, candB, nlkB)
+					if (rep + 1u < XZ_FREP) { XZ_COMPARE(candB, nlkB, cand, nlk) }
+					else if (st == XZ_FIND) { cand = candB; nlk = nlkB; }       // (an odd number of compares per step: back to the first set)
 				}
+#undef XZ_COMPARE
 				// ---- FIND2 / EXT: 16 more bytes of the same candidate (both sides from LDS)
 				if (__ballot(st == XZ_FIND2 || st == XZ_EXT)) {
 					if (st == XZ_FIND2 || st == XZ_EXT) {
@@ -202,8 +213,8 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 							const uint32_t key = (l << 16) | (0xFFFFu - (p - x));
 							best = best > key ? best : key;
 							--chain;
-							fetch = nlk != 0xFFFFu && chain != 0u && (p - nlk) <= XZ_WIN && (best >> 16) < 48u;
-							x = nlk;
+							fetch = chain != 0u && (p - nkeep) <= XZ_WIN && (best >> 16) < 48u;
+							x = nkeep;
 							st = fetch ? XZ_FIND : XZ_DONE;
 						} else {
 							if (la == 16u && l >= XZ_OWN_EXT && lim > XZ_OWN_EXT) { dl = XZ_OWN_EXT; st = XZ_COOP; }   // still equal at 112: the wave takes over
@@ -303,7 +314,7 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 								own = own_n;
 								x = x_n;
 								best = 0u; chain = 11u; dl = 0u;
-								fetch = x != 0xFFFFu && p - x <= XZ_WIN;
+								fetch = p - x <= XZ_WIN;                          // (x == 0xFFFF, no link: the difference wraps, p <= 65533 here)
 								st = fetch ? XZ_FIND : XZ_DONE;
 							}
 						}
