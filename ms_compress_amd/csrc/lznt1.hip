@@ -90,19 +90,13 @@ __device__ __forceinline__ uint32_t lz_lcp_tail(const uint8_t* d, uint32_t q, ui
 	}
 	return l;
 }
-// Common prefix of d[q..] and the string at d[p..] whose first 16 bytes are o0..o3, limited to maxlen (>= 3); 0 when the
-// candidate does not exist (!valid) or the first 3 bytes differ (hash collision). Branch-free up to 16 bytes.
-__device__ __forceinline__ uint32_t lz_lcp(const uint8_t* d, uint32_t q, bool valid, uint32_t p, uint32_t maxlen,
-                                           uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3)
+// First difference of two 16-byte blocks given their XOR, as a BIT index limited to capbits (<= 128): common.h first_nz_byte16 without
+// its final shift -- the limit (8 x min(max_len, 16)) rides in the minimum that finds the difference, so the byte count needs no clamp.
+__device__ __forceinline__ uint32_t lz_diff_bits16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t capbits)
 {
-	uint4 c;
-	c = lz_ld128(d, q);
-	const uint32_t f = first_nz_byte16(c.x ^ o0, c.y ^ o1, c.z ^ o2, c.w ^ o3);
-	uint32_t l = (valid && f >= 3u) ? f : 0u;
-	if (l == 16u && maxlen > 16u) { l = lz_lcp_tail(d, q, p, maxlen); }
-	return l < maxlen ? l : maxlen;
+	const uint32_t a = ffbl_raw(x1) | 32u, b = ffbl_raw(x2) | 64u, c = ffbl_raw(x3) | 96u;
+	return min3u(min3u(ffbl_raw(x0), a, b), c, capbits);
 }
-
 // One window (64 positions, lane = position) of the lazy parse of a chunk: Find for the positions at / after the parse
 // position `entry` (the 4 oldest candidates per lane, the rest on demand), greedy walk, token mask. Returns the parse
 // position after the window; key = (len << 12) | (4095 - q) of this lane's match (valid where matchmask is set),
@@ -143,6 +137,7 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 	#pragma unroll
 	for (uint32_t j = 0; j <= LZ_SELF; ++j) { ex[j] = j < cnt && q[j] < p; }
 	const bool longer = maxlen > 16u;
+	const uint32_t capb = (maxlen < 16u ? maxlen : 16u) << 3;
 #if defined(LZ_PROBE) && LZ_PROBE == 5      /* dev probe (SUBTRACTIVE, not bit-exact): the eager scan of the odd windows is skipped (their positions are literals unless finished) */
 	if (!((wbase >> 6) & 1u))
 #endif
@@ -152,10 +147,9 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 		for (uint32_t k = 0; k < LZ_SELF; ++k) { c[k] = lz_ld128(s_data, q[k]); }
 		#pragma unroll
 		for (uint32_t k = 0; k < LZ_SELF; ++k) {
-			uint32_t lk = first_nz_byte16(c[k].x ^ o0, c[k].y ^ o1, c[k].z ^ o2, c[k].w ^ o3);
-			if (ex[k] && lk == 16u && longer) { lk = lz_lcp_tail(s_data, q[k], p, maxlen); }   // long match
-			lk = lk < maxlen ? lk : maxlen;
-			const uint32_t kk = ex[k] ? ((lk << 12) | (q[k] ^ 4095u)) : 0u;
+			uint32_t lb = lz_diff_bits16(c[k].x ^ o0, c[k].y ^ o1, c[k].z ^ o2, c[k].w ^ o3, capb);     // length in bits (the low three dropped below)
+			if (ex[k] && lb >= 128u && longer) { const uint32_t l = lz_lcp_tail(s_data, q[k], p, maxlen); lb = (l < maxlen ? l : maxlen) << 3; }   // long match
+			const uint32_t kk = ex[k] ? (((lb & ~7u) << 9) | (q[k] ^ 4095u)) : 0u;
 			key = kk > key ? kk : key;
 		}
 	}
@@ -227,21 +221,21 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 			uint32_t kbest = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)mp);
 			const uint32_t pL = wbase + mp;
 			const bool longL = maxL > 16u;
+			const uint32_t capL = (maxL < 16u ? maxL : 16u) << 3;
 			for (uint32_t base = sL + LZ_SELF; base < eL; base += 64u) {
 				const uint32_t qq = s_bucket[base + lane];         // unconditional load (past the array's end it reads the table), masked below
 				const bool v1 = lane < eL - base, v2 = qq < pL;     // else: this lane is at or beyond pL's own entry
 				const bool valid = v1 && v2;
 				const u64 vmask = __builtin_amdgcn_ballot_w64(v1) & __builtin_amdgcn_ballot_w64(v2);
 				const uint4 c = lz_ld128(s_data, qq);
-				uint32_t l2 = first_nz_byte16(c.x ^ a0, c.y ^ a1, c.z ^ a2, c.w ^ a3);
-				if (valid && l2 == 16u && longL) { l2 = lz_lcp_tail(s_data, qq, pL, maxL); }
-				l2 = l2 < maxL ? l2 : maxL;
+				uint32_t l2 = lz_diff_bits16(c.x ^ a0, c.y ^ a1, c.z ^ a2, c.w ^ a3, capL);   // in bits
+				if (valid && l2 >= 128u && longL) { const uint32_t l = lz_lcp_tail(s_data, qq, pL, maxL); l2 = (l < maxL ? l : maxL) << 3; }
 #if defined(LZ_PROBE) && LZ_PROBE == 3      /* dev probe: 20 more VALU instructions per finishing step */
 				{ uint32_t y_ = l2; _Pragma("unroll") for (int q_ = 0; q_ < 20; ++q_) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(y_) : "v"(qq)); } asm volatile("" :: "v"(y_)); }
 #elif defined(LZ_PROBE) && LZ_PROBE == 4    /* dev probe: one more 16-byte LDS read per finishing step */
 				{ const uint4 y_ = lds_ld128(s_data, (qq * 7u + 64u) & 4095u); asm volatile("" :: "v"(y_.x), "v"(y_.y), "v"(y_.z), "v"(y_.w)); }
 #endif
-				uint32_t k2; asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(k2) : "v"((l2 << 12) | (qq ^ 4095u)), "s"(vmask));   // (a key below 3 << 12 is no match)
+				uint32_t k2; asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(k2) : "v"(((l2 & ~7u) << 9) | (qq ^ 4095u)), "s"(vmask));   // (a key below 3 << 12 is no match)
 				const uint32_t m = wave_max_u32(k2);
 				kbest = m > kbest ? m : kbest;                   // longest, then oldest (older blocks hold the larger 4095 - q)
 				if ((kbest >> 12) == maxL || ~vmask) { break; }  // max_len reached / all older candidates seen
