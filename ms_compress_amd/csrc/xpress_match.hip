@@ -330,6 +330,9 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 #if defined(XF_PROBE) && XF_PROBE == 8        /* dev probe (not bit-exact): NO link load and no dependent chain -- the next candidate lies 37 bytes further back; the compares are the product's */
 				x = (uint32_t)(rc - adj - 37) & 0xFFFFu; if (rc - adj < 37) { x = 0xFFFFu; }
 				if (false)
+#elif defined(XF_PROBE) && XF_PROBE == 9      /* dev probe (not bit-exact): the link gather on every SECOND step only (what a two-links-per-gather layout would issue), arithmetic in between */
+				x = (uint32_t)(rc - adj - 37) & 0xFFFFu; if (rc - adj < 37) { x = 0xFFFFu; }
+				if (chain & 1u)
 #endif
 				x = (LINKW == WINDOW) ? (uint32_t)s_links[xr - lrel]
 				                      : (uint32_t)*reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(lkb) + (u64)(uint32_t)((rc << 1) + 131072));
