@@ -538,7 +538,8 @@ def main():
     import torch
     import ms_compress_amd as m
     from ms_compress_amd import corpus, sharding
-    rank, local_rank, world = sharding.init_distributed("gloo" if args.oversubscribe else None)
+    # (MSCOMP_AMD_BENCH_BACKEND overrides; two ranks on ONE GPU cannot form an RCCL group, so the test mode asks for gloo)
+    rank, local_rank, world = sharding.init_distributed(os.environ.get("MSCOMP_AMD_BENCH_BACKEND") or ("gloo" if args.oversubscribe else None))
     if world != want:
         sys.exit("bench.py: --gpus %d but the launcher started %d rank(s); launch with torch.distributed.run --nproc-per-node %d "
                  "(or let bench.py spawn them: no WORLD_SIZE in the environment)" % (want, world, want))
@@ -546,7 +547,7 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    rdev = None if args.oversubscribe else dev           # where the timing reduction's tensors live (gloo: host)
+    rdev = None                                          # the timing reduction's tensors: sharding.reduce_job puts them where its backend needs them
     ctx = m.Context(device=local_rank)
     cor = Corpus(corpus, dev)
     fmt = m.FORMATS[args.codec]
@@ -562,6 +563,7 @@ def main():
                    "bytes_per_step": cor.total * REPLICAS, "units": head["units"],
                    "bytes_rank0": head["bytes_rank0"], "compression_ratio": head["compression_ratio"],
                    "parallelism": "shard-per-gpu x%d, no data-path collective" % world,
+                   "backend": sharding.backend_name(),
                    "MiB_per_s": head["MiB_per_s"]},
         "roofline": head["roofline"],
         "parity_checked": {args.codec: head["parity_checked"]},

@@ -46,38 +46,90 @@ def dist_env():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+_GROUP = None          # the RCCL group the timing collectives run on when it came up on every rank (None: the gloo world group, host tensors)
+_BACKEND = None        # "nccl" | "gloo" | None (one process)
+_NOTE = None           # why gloo is in use although RCCL was asked for
+
+
+def backend_name():
+    """'nccl' (= RCCL on ROCm), 'gloo', 'gloo (nccl failed: ...)' or None for a one-process run -- goes into the bench line's config."""
+    if _BACKEND == "gloo" and _NOTE:
+        return "gloo (%s)" % _NOTE
+    return _BACKEND
+
+
+def _rccl_group(local_rank, world):
+    """A process group on RCCL over all ranks, proven by one all-reduce on this rank's GPU. Raises when anything in that fails."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
+    x = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", local_rank))
+    dist.all_reduce(x, group=g)
+    torch.cuda.synchronize()
+    if int(x.item()) != world:
+        raise RuntimeError("RCCL all-reduce over %d ranks gave %d" % (world, int(x.item())))
+    return g
+
+
 def init_distributed(backend=None):
-    """Initialise torch.distributed when launched with WORLD_SIZE > 1 ('nccl' = RCCL on ROCm; 'gloo' for the CPU tests)."""
+    """Initialise torch.distributed when launched with WORLD_SIZE > 1. The data path has no collective; what runs over the
+    process group is the barrier around the timed region and the MAX / SUM reduction of its figures. The WORLD group is always gloo (host
+    tensors, 127.0.0.1 / loopback: it cannot fail for GPU reasons) and is the channel on which the ranks AGREE; on GPUs an RCCL group
+    ('nccl' = RCCL on ROCm) is created beside it and proven with one all-reduce -- if that fails on ANY rank (or `backend` /
+    MSCOMP_AMD_BENCH_BACKEND says "gloo") every rank stays on gloo and `backend_name()` says why. The first real N > 1 run on N GPUs is the
+    driver's: a failing RCCL bring-up must cost the line's "backend" key, not the whole scaling curve."""
+    global _GROUP, _BACKEND, _NOTE
     import torch
     import torch.distributed as dist
     rank, local_rank, world = dist_env()
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        forced = backend or os.environ.get("MSCOMP_AMD_BENCH_BACKEND") or None
+        want_rccl = forced == "nccl" or (forced is None and torch.cuda.is_available())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        kw = {}
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            kw["device_id"] = torch.device("cuda", local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # one node: the container's hostname may not resolve
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        _BACKEND, _GROUP, _NOTE = "gloo", None, None
+        if want_rccl:
+            ok, why, g = 1, "", None
+            try:
+                g = _rccl_group(local_rank, world)
+            except Exception as ex:                                # noqa: BLE001 -- anything: a missing backend, IPC handles, a dead link
+                ok, why = 0, "%s: %s" % (type(ex).__name__, str(ex).splitlines()[0][:120] if str(ex) else "")
+            flag = torch.tensor([ok], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # gloo: every rank learns whether EVERY rank has RCCL
+            if int(flag.item()) == 1:
+                _GROUP, _BACKEND = g, "nccl"
+            else:
+                _NOTE = "nccl failed" + (" here, " + why if not ok else " on another rank")
+                if rank == 0 or not ok:
+                    import sys
+                    print("ms_compress_amd.sharding: rank %d: RCCL did not come up (%s): timing collectives over gloo" % (rank, why or "another rank"), file=sys.stderr)
     return rank, local_rank, world
 
 
 def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if _GROUP is not None:
+            import torch
+            dist.barrier(group=_GROUP, device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def reduce_job(elapsed_s, units_bytes, device=None):
-    """Whole-job figures from per-rank ones: time = MAX over ranks, bytes = SUM over ranks (the only collectives used)."""
+    """Whole-job figures from per-rank ones: time = MAX over ranks, bytes = SUM over ranks (the only collectives used). On RCCL the two
+    scalars live on this rank's GPU, on gloo on the host (`device` is kept for callers of the earlier signature and ignored on gloo)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return float(elapsed_s), int(units_bytes)
-    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
-    b = torch.tensor([int(units_bytes)], dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.all_reduce(b, op=dist.ReduceOp.SUM)
+    dev = (device if device is not None else torch.device("cuda", torch.cuda.current_device())) if _GROUP is not None else None
+    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=dev)
+    b = torch.tensor([int(units_bytes)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_GROUP)
+    dist.all_reduce(b, op=dist.ReduceOp.SUM, group=_GROUP)
     return float(t.item()), int(b.item())

@@ -34,7 +34,9 @@ def test_the_drivers_own_command_prints_one_short_parseable_line():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0 and line["unit"] == "MB/s"
-    assert "configs[4]" in line["config"]["workload"] and line["config"]["bytes_per_step"] == 3391017280
+    from ms_compress_amd import corpus
+    total = sum(corpus.SIZES) * 16 if corpus.source() == "synthetic" else None        # (SILESIA_DIR: the real files have the same sizes by corpus.source()'s own check)
+    assert "configs[4]" in line["config"]["workload"] and line["config"]["bytes_per_step"] == (total or 3391017280)
     assert 0 < line["roofline"]["frac"] < 1 and line["roofline"]["bound"] == "hbm" and line["roofline"]["kernel_ms_per_launch"] > 0
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["balanced_value"] >= line["cpu_baseline"]["value"] * 0.5 and line["cpu_baseline"]["cores"] >= 1
     assert line["parity_checked"] == {"lznt1": True, "xpress": True, "xpress_huff": True}
@@ -56,10 +58,31 @@ def test_two_ranks_share_the_gpu():
     """python bench.py --gpus 2 --oversubscribe: the sharded multi-rank path end to end (self-spawned ranks, gloo timing reduction,
     every rank's shard through the parity gate). One line, marked as a test run."""
     line = _bench(["--gpus", "2", "--oversubscribe", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-extra"])
-    assert line["n_gpus"] == 2 and "oversubscribed" in line and line["scaling"] == "strong"
+    assert line["n_gpus"] == 2 and "oversubscribed" in line and line["scaling"] == "strong" and line["config"]["backend"] == "gloo"
     assert line["parity_checked"] == {"lznt1": True}
     assert line["config"]["bytes_per_step"] == 3391017280 and line["config"]["bytes_rank0"] * 2 == 3391017280
     assert line["config"]["lznt1_parity_checked"] is True and line["value"] > 0
+
+
+def test_rccl_that_cannot_come_up_leaves_a_gloo_job():
+    """RCCL asked for (MSCOMP_AMD_BENCH_BACKEND=nccl) with two ranks on ONE GPU -- RCCL refuses a communicator with a duplicate device --: the
+    ranks must agree on gloo, finish the job and name the backend in the line (sharding.init_distributed)."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("the duplicate-device refusal needs exactly one visible GPU")
+    line = _bench(["--gpus", "2", "--oversubscribe", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-extra"], env={"MSCOMP_AMD_BENCH_BACKEND": "nccl"}, timeout=600)
+    assert line["n_gpus"] == 2 and line["parity_checked"] == {"lznt1": True} and line["value"] > 0
+    assert line["config"]["backend"].startswith("gloo (nccl failed"), line["config"]["backend"]
+
+
+def test_two_ranks_on_two_gpus_over_rccl():
+    """python bench.py --gpus 2 exactly as the driver runs it for N = 2 (no test switches): needs two GPUs, runs by itself wherever they are visible"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (%d visible)" % torch.cuda.device_count())
+    line = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--config5-only"])
+    assert line["n_gpus"] == 2 and "oversubscribed" not in line and line["config"]["backend"] in ("nccl",) or line["config"]["backend"].startswith("gloo (nccl failed")
+    assert line["parity_checked"] == {"lznt1": True, "xpress": True, "xpress_huff": True} and line["value"] > 0
 
 
 def test_two_ranks_launched_the_drivers_way():

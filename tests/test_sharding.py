@@ -103,3 +103,57 @@ def test_two_rank_gloo_job():
     assert s0 == 0 and e0 == s1 and e1 == 37                      # disjoint cover
     assert t0 == t1 == 2.0                                         # MAX over ranks
     assert b0 == b1 and b0 > 0                                     # SUM over ranks, same on both
+
+
+def _fallback_worker(rank, world, port, q, mode):
+    """RCCL asked for, RCCL unavailable: `mode` = "raise" patches the group bring-up to raise on EVERY rank, "one" on rank 0 only (rank 1's
+    bring-up "succeeds" with a stand-in group) -- either way every rank must end up on gloo, say why, and the reductions must work."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("MSCOMP_AMD_BENCH_BACKEND", None)
+    import torch.distributed as dist
+    from ms_compress_amd import sharding
+
+    def broken(local_rank, w):
+        if mode == "raise" or rank == 0:
+            raise RuntimeError("forced: hipIpcGetMemHandle: invalid argument")
+        return dist.group.WORLD                                   # stand-in for a healthy RCCL group on the other rank
+    if mode != "real":
+        sharding._rccl_group = broken
+    r, lr, w = sharding.init_distributed("nccl")                  # ("real": no GPU here -> the genuine bring-up fails by itself)
+    name = sharding.backend_name()
+    sharding.barrier()
+    t, b = sharding.reduce_job(3.0 - rank, 10 + rank)
+    q.put((rank, name, t, b))
+    dist.destroy_process_group()
+
+
+def test_rccl_failure_falls_back_to_gloo_on_every_rank():
+    """the first N > 1 run on RCCL is the driver's; a failing bring-up -- on all ranks or on one -- must leave a working
+    gloo job whose line names the backend, not a lost scaling curve."""
+    import pytest
+    for mode in ("raise", "one", "real"):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=180) for _ in procs)
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        for rank, name, t, b in res:
+            assert name.startswith("gloo (nccl failed"), (mode, name)
+            assert t == 3.0 and b == 21
+        if mode == "one":
+            assert "here" in res[0][1] and "another rank" in res[1][1]
+
+
+def test_backend_env_switch(monkeypatch):
+    """MSCOMP_AMD_BENCH_BACKEND=gloo: no RCCL bring-up is attempted at all (one process: nothing is initialised, the name stays None)"""
+    from ms_compress_amd import sharding
+    monkeypatch.setenv("MSCOMP_AMD_BENCH_BACKEND", "gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    assert sharding.init_distributed() == (0, 0, 1) and sharding.backend_name() is None
+    assert sharding.reduce_job(1.5, 7) == (1.5, 7)
