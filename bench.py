@@ -376,19 +376,18 @@ def cpu_baseline(fmt, cor, budget_s=10.0, sa_dict=False):
     caps = np.array([loader.load_oracle().orc_max_compressed_size(fmt, int(x)) + 2 for x in ulen], np.uint64)
     fn = ref.ms_compress if ref is not None else None
     nthr = min(threads, len(ulen))
-    dt1, st, _ = loader.time_units_ex(fn, fmt, blob, uoff, ulen, caps, nthr, 1)
-    busy = loader.load_oracle().orc_last_busy_seconds()
+    busy_l = []
+    dt1, st, _ = loader.time_units_ex(fn, fmt, blob, uoff, ulen, caps, nthr, 1, busy=busy_l)
     assert bool((st == 0).all()), "the CPU baseline reported an error status"
     more = max(0, min(19, int(budget_s / 4 / max(dt1, 1e-3)) - 1))
     dt = dt1
     if more:
-        dt += loader.time_units_ex(fn, fmt, blob, uoff, ulen, caps, nthr, more)[0]
-        busy += loader.load_oracle().orc_last_busy_seconds()
+        dt += loader.time_units_ex(fn, fmt, blob, uoff, ulen, caps, nthr, more, busy=busy_l)[0]
     passes, sample = 1 + more, int(ulen.sum())
     # the load-balanced figure: bytes x threads / thread-seconds spent inside ms_compress -- what these cores give when every thread always has
     # a unit to take (a queue of many files); `value` is the SAME UNIT LIST as the GPU leg in one pass, whose whole-file legs last as long as
     # the largest file on one core. Both are printed; a speed-up should be read against the balanced one.
-    balanced = sample * passes * nthr / max(busy, 1e-9) / 1e6
+    balanced = sample * passes * nthr / max(sum(busy_l), 1e-9) / 1e6
     k1 = 1 if fmt != 3 else min(64, len(ulen))         # single thread: the first file (its first 64 units for Xpress)
     s1 = int(ulen[:k1].sum())
     d1, st1, _ = loader.time_units_ex(fn, fmt, blob, uoff[:k1], ulen[:k1], caps[:k1], 1, 1)
@@ -616,7 +615,7 @@ def main():
         extra["one_rank_of_8"] = r8
         # the suffix-array dictionary flavour of LZNT1 (csrc/lznt1_sa.hip) on the 12 files; HIP events per kernel as everywhere
         b2, o2, l2, d2 = single_gpu_workload(cor, "silesia_files")
-        ctx.lib.mscomp_amd_set_lznt1_sa_dict(1)
+        ctx.set_lznt1_sa_dict(True)                      # (per context: the plans this context creates from here on; nothing process-wide)
         try:
             j2 = Job(m, ctx, m.FORMATS["lznt1"], b2, o2, l2)
             t2, p2 = timed(j2, steps2, 1, sharding)
@@ -627,7 +626,7 @@ def main():
             if not args.no_cpu:
                 extra["lznt1_sa_dict"]["cpu_baseline"] = cpu_baseline(m.FORMATS["lznt1"], cor, sa_dict=True)
         finally:
-            ctx.lib.mscomp_amd_set_lznt1_sa_dict(0)
+            ctx.set_lznt1_sa_dict(None)
         dec = {}
         for codec, wl in (("lznt1", "mozilla"), ("xpress", "silesia_units64k"), ("xpress_huff", "silesia_units64k")):
             f2 = m.FORMATS[codec]
@@ -685,6 +684,10 @@ def main():
         print(text, flush=True)
     ctx.close()
     if world > 1:
+        if sharding.abandoned_bringup():                 # a hung RCCL bring-up thread is still inside the runtime: no teardown through it
+            sys.stdout.flush(); sys.stderr.flush()
+            sharding.barrier()
+            os._exit(0)
         torch.distributed.destroy_process_group()
 
 

@@ -221,15 +221,22 @@ MSCompStatus mscomp_amd_debug_xpress_matches(mscomp_amd_ctx* ctx, const uint8_t*
 /* Stage-level test hook: the code lengths HuffmanEncoder<15,512>::CreateCodes (include/mscomp/HuffmanEncoder.h:58-107, the heap build with
  * its > 15-bit rescale loop) gives for n histograms of 512 counts; h_counts (n x 512 uint32) and h_lens (n x 512 bytes) are host arrays. */
 MSCompStatus mscomp_amd_debug_huff_lengths(mscomp_amd_ctx* ctx, const uint32_t* h_counts, size_t n, uint8_t* h_lens);
+/* The mscomp_amd_debug_set_* hooks below choose between BIT-IDENTICAL kernels for the tests and are process-wide; the library ignores them unless
+ * MSCOMP_AMD_TEST_HOOKS=1 was in the environment when it was loaded (1 = they work). A deployment never sets it. */
+int          mscomp_amd_debug_hooks_enabled(void);
 /* Test hook: the Xpress parse/emit stage has two bit-identical kernels (one wave per unit; four
  * or sixteen waves per unit with speculative segments). 0 = chosen by batch size (default), 1 / 2 / 3 = force. Process-wide. */
 void         mscomp_amd_debug_set_xpress_emit(int mode);
 /* The reference has two LZNT1 dictionaries, chosen when it is BUILT (/root/reference/include/mscomp/config.h:83-88): the default one and,
  * with -DMSCOMP_WITH_LZNT1_SA_DICT, a suffix-array one (/root/reference/include/mscomp/LZNT1Dictionary_SA.h) whose matches have the same
- * lengths but other offsets -- so the compressed bytes differ. A deployment that replaces such a build selects the same flavour here
- * (process-wide; or by MSCOMP_AMD_LZNT1_SA_DICT=1 in the environment when the library loads). Decompression is not affected. */
+ * lengths but other offsets -- so the compressed bytes differ. A deployment that replaces such a build selects the same flavour here.
+ * The flavour is a property of a PLAN, fixed when the plan is created: from its context's setting (mscomp_amd_ctx_set_lznt1_sa_dict: 1 / 0, -1 =
+ * follow the process default) or else from the process default (mscomp_amd_set_lznt1_sa_dict, or MSCOMP_AMD_LZNT1_SA_DICT=1 in the environment
+ * when the library loads). Changing a setting never touches a plan that exists. The entries without a context argument (ms_compress, ms_deflate,
+ * mscomp_amd_compress_units_host) make their plans per call and follow the process default of that moment. Decompression is not affected. */
 void         mscomp_amd_set_lznt1_sa_dict(int on);
 int          mscomp_amd_get_lznt1_sa_dict(void);
+MSCompStatus mscomp_amd_ctx_set_lznt1_sa_dict(mscomp_amd_ctx* ctx, int on);
 /* Test hook: Xpress decompression has two bit-identical paths: 0 = default (32-bit tokens, a flag word per step, then the copy kernels that
  * Xpress+Huffman uses), 1 = one wave per stream taking a token per step and moving the bytes itself (round 1's kernel). Process-wide. */
 void         mscomp_amd_debug_set_xpress_decoder(int mode);

@@ -33,7 +33,7 @@ EXPORTS = [  # every symbol include/mscomp_amd.h declares (tests check the libra
     "ms_deflate_init", "ms_deflate", "ms_deflate_end", "lznt1_deflate_init", "lznt1_deflate", "lznt1_deflate_end",
     "xpress_deflate_init", "xpress_deflate", "xpress_deflate_end", "xpress_inflate_init", "xpress_inflate", "xpress_inflate_end",
     "ms_decompress", "lznt1_decompress", "xpress_decompress", "xpress_huff_decompress", "mscomp_amd_plan_create_decompress", "mscomp_amd_decompress_batch",
-    "mscomp_amd_version", "mscomp_amd_debug_xpress_matches", "mscomp_amd_debug_huff_lengths", "mscomp_amd_debug_lds_lane_order", "mscomp_amd_debug_set_xpress_emit", "mscomp_amd_debug_set_lznt1", "mscomp_amd_debug_set_serial_atomics", "mscomp_amd_compress_units_host", "mscomp_amd_decompress_units_host", "mscomp_amd_host_pool_release", "mscomp_amd_debug_set_finder", "mscomp_amd_debug_set_one_shot", "mscomp_amd_debug_set_xpress_decoder", "mscomp_amd_debug_lzg_open", "mscomp_amd_set_lznt1_sa_dict", "mscomp_amd_get_lznt1_sa_dict", "mscomp_amd_debug_lzd_walked",
+    "mscomp_amd_version", "mscomp_amd_debug_xpress_matches", "mscomp_amd_debug_huff_lengths", "mscomp_amd_debug_lds_lane_order", "mscomp_amd_debug_set_xpress_emit", "mscomp_amd_debug_set_lznt1", "mscomp_amd_debug_set_serial_atomics", "mscomp_amd_compress_units_host", "mscomp_amd_decompress_units_host", "mscomp_amd_host_pool_release", "mscomp_amd_debug_set_finder", "mscomp_amd_debug_set_one_shot", "mscomp_amd_debug_set_xpress_decoder", "mscomp_amd_debug_lzg_open", "mscomp_amd_set_lznt1_sa_dict", "mscomp_amd_get_lznt1_sa_dict", "mscomp_amd_ctx_set_lznt1_sa_dict", "mscomp_amd_debug_hooks_enabled", "mscomp_amd_debug_lzd_walked",
 ]
 
 
@@ -116,6 +116,10 @@ def load_library():
     lib.mscomp_amd_set_lznt1_sa_dict.restype = None
     lib.mscomp_amd_get_lznt1_sa_dict.argtypes = []
     lib.mscomp_amd_get_lznt1_sa_dict.restype = C.c_int
+    lib.mscomp_amd_ctx_set_lznt1_sa_dict.argtypes = [C.c_void_p, C.c_int]
+    lib.mscomp_amd_ctx_set_lznt1_sa_dict.restype = C.c_int
+    lib.mscomp_amd_debug_hooks_enabled.argtypes = []
+    lib.mscomp_amd_debug_hooks_enabled.restype = C.c_int
     lib.mscomp_amd_debug_set_xpress_decoder.argtypes = [C.c_int]
     lib.mscomp_amd_debug_set_xpress_decoder.restype = None
     lib.mscomp_amd_debug_set_finder.argtypes = [C.c_int]
@@ -209,6 +213,12 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def set_lznt1_sa_dict(self, on):
+        """LZNT1 dictionary flavour of the plans this context creates from now on: True / False, None = the process default."""
+        st = self.lib.mscomp_amd_ctx_set_lznt1_sa_dict(self._h, -1 if on is None else int(bool(on)))
+        if st != MSCOMP_OK:
+            raise MSCompError(st, "mscomp_amd_ctx_set_lznt1_sa_dict")
 
     def profile_enable(self, on=True):
         self.lib.mscomp_amd_profile_enable(self._h, 1 if on else 0)

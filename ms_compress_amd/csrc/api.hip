@@ -47,6 +47,7 @@ struct DevBuf {
 };
 
 struct ProfRec { const char* name; hipEvent_t a, b; };
+bool lznt1_sa_for(const mscomp_amd_ctx* c);              // the flavour a plan created in `c` right now would get
 const uint32_t XH_FB_BLOCKS = 256;                     // persistent blocks of the fallback kernel (one per CU: its package pool fills the LDS)
 
 } // namespace
@@ -70,6 +71,7 @@ struct mscomp_amd_ctx {
 	hipEvent_t h_tab_ev = nullptr; bool h_tab_busy = false;   // (a stream that shares a hardware queue with a busy one would make that wait as long as the other's kernels)
 	std::vector<DevBuf> table_pool;                    // table buffers of destroyed plans, reused by the next plan (hipFree waits for the whole device: it would stall pipelines that create a plan per batch)
 	uint64_t epoch = 1;                                // bumped when one of the buffers above moves (captured graphs are stale then)
+	int lznt1_sa = -1;                                 // LZNT1 dictionary flavour of the plans this context creates: -1 = the process default at plan creation, 0 / 1 = set for this context
 	bool profiling = false;
 	std::vector<ProfRec> recs;
 	std::vector<hipEvent_t> free_events;
@@ -88,6 +90,7 @@ struct mscomp_amd_plan {
 	bool decompress = false;
 	uint32_t n_units = 0, n_chunks = 0;
 	uint64_t total_in = 0, max_unit = 0;
+	bool lznt1_sa = false;                             // LZNT1: the suffix-array dictionary flavour -- fixed when the plan is created: a plan never changes its bytes under a running caller
 	bool no_graph = false;                             // one-shot plans run with changing buffer addresses: a captured graph would be re-captured every time
 	DevBuf tables;                                     // in_off | out_off | chunk_prefix
 	DevBuf tokpre;                                     // decompression by tokens: first token slot | first candidate slot of every unit (2 x (n_units + 1) u64)
@@ -108,6 +111,12 @@ struct mscomp_amd_plan {
 };
 
 namespace {
+
+// The mscomp_amd_debug_set_* hooks pick between bit-identical kernels for the tests. They are process-wide, so the product ignores them unless the
+// process asked for them BEFORE the library was loaded (MSCOMP_AMD_TEST_HOOKS=1: tests/conftest.py and the tools do): a deployment cannot have its
+// kernels switched under it by a stray call.
+bool test_hooks_on() { static const bool on = [] { const char* e = getenv("MSCOMP_AMD_TEST_HOOKS"); return e && *e == '1'; }(); return on; }
+bool lznt1_sa_for(const mscomp_amd_ctx* c) { return (c->lznt1_sa >= 0 ? c->lznt1_sa : g_lznt1_sa.load(std::memory_order_relaxed)) != 0; }
 
 struct DeviceGuard {
 	int prev = -1; bool ok = true;
@@ -156,7 +165,12 @@ uint32_t chunks_of(MSCompFormat f, bool decompress, uint64_t n)
 
 extern "C" {
 
-const char* mscomp_amd_version(void) { return "mscomp_amd 0.5 (gfx950, HIP; LZNT1 / Xpress / Xpress+Huffman compressors and decompressors, LZNT1 streaming, host batches over several GPUs)"; }
+#ifdef MSCOMP_AMD_DEV
+#define MSCOMP_AMD_FLAVOUR "; DEVELOPMENT flavour: + the measurement-mode Xpress+Huffman finders"
+#else
+#define MSCOMP_AMD_FLAVOUR ""
+#endif
+const char* mscomp_amd_version(void) { return "mscomp_amd 0.6 (gfx950, HIP; LZNT1 / Xpress / Xpress+Huffman compressors and decompressors, LZNT1 streaming, host batches over several GPUs" MSCOMP_AMD_FLAVOUR ")"; }
 
 size_t lznt1_max_compressed_size(size_t n)       { return n + 3 + 2 * ((n + 4095) / 4096); }
 size_t xpress_max_compressed_size(size_t n)      { return n + 4 + 4 * (n / 32); }
@@ -262,6 +276,7 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 	mscomp_amd_plan* p = new (std::nothrow) mscomp_amd_plan();
 	if (!p) { return MSCOMP_MEM_ERROR; }
 	p->ctx = c; p->format = format; p->decompress = decompress; p->n_units = (uint32_t)n_units;
+	p->lznt1_sa = !decompress && format == MSCOMP_LZNT1 && lznt1_sa_for(c);
 
 	const size_t host_words = n_units * 4 + (n_units + 2) / 2 + 1;
 	std::vector<uint64_t> host;
@@ -431,10 +446,17 @@ static MSCompStatus plan_create_impl(mscomp_amd_ctx* c, MSCompFormat format, boo
 	if (ok && format == MSCOMP_LZNT1) { ok = c->slots.reserve((size_t)p->n_chunks * LZNT1_SLOT + 64); }
 	if (ok && format != MSCOMP_LZNT1) {
 		const size_t per = (size_t)p->n_chunks * 65536u * sizeof(uint16_t) + 64;
-		// (mlen3: 4 bytes per position, both halves of the match word. Xpress+Huffman's sorted-span finder keeps its padded position array in `links`
-		// and its bucket starts, XS_STARTS_STRIDE words per chunk, in `lasthead`)
-		const size_t lh = format == MSCOMP_XPRESS_HUFF ? (size_t)p->n_chunks * XS_STARTS_STRIDE * sizeof(uint32_t) + 64 : per / 2 + 64;
-		ok = c->links.reserve(per + 2 * XS_FRONT_PAD) && c->mlen3.reserve(2 * per) && c->lasthead.reserve(lh);
+		// (mlen3: 4 bytes per position, both halves of the match word)
+#ifdef MSCOMP_AMD_DEV
+		// (development flavour: Xpress+Huffman's sorted-span finder keeps its padded position array in `links` and its bucket starts, XS_STARTS_STRIDE
+		// words per chunk, in `lasthead` -- reserved only when that measurement mode is switched on)
+		static const bool xs_on = [] { const char* e = getenv("MSCOMP_AMD_XH_SORT"); return e && atoi(e) != 0; }();
+		const size_t lh = (xs_on && format == MSCOMP_XPRESS_HUFF) ? (size_t)p->n_chunks * XS_STARTS_STRIDE * sizeof(uint32_t) + 64 : per / 2 + 64;
+		const size_t lpad = xs_on ? 2 * XS_FRONT_PAD : 0;
+#else
+		const size_t lh = per / 2 + 64, lpad = 0;
+#endif
+		ok = c->links.reserve(per + lpad) && c->mlen3.reserve(2 * per) && c->lasthead.reserve(lh);
 		if (ok && format == MSCOMP_XPRESS) {
 			const size_t nw = (size_t)p->n_chunks * 1024u + 64;
 			ok = c->wtok.reserve(nw * 8) && c->wmat.reserve(nw * 8) && c->wfar.reserve(nw * 4);
@@ -600,7 +622,7 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 	switch (p->format) {
 	case MSCOMP_LZNT1: {
 		uint8_t* slots = static_cast<uint8_t*>(c->slots.p);
-		if (g_lznt1_sa.load(std::memory_order_relaxed)) { KernelTimer t(c, "lznt1_sa_chunk_kernel"); launch_lznt1_sa_chunks(st, d_in, p->bt, slots, slot_size); }
+		if (p->lznt1_sa) { KernelTimer t(c, "lznt1_sa_chunk_kernel"); launch_lznt1_sa_chunks(st, d_in, p->bt, slots, slot_size); }
 		else { KernelTimer t(c, "lznt1_chunk_kernel"); launch_lznt1_chunks(st, d_in, p->bt, slots, slot_size); }
 		{ KernelTimer t(c, "scan_sizes"); launch_scan_sizes(st, slot_size, prefix, p->n_chunks, tile_sums); }
 		{ KernelTimer t(c, "concat_slots_kernel"); launch_concat_slots(st, slots, LZNT1_SLOT, slot_size, prefix, p->bt, d_out); }
@@ -624,15 +646,20 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 		uint32_t* extra = static_cast<uint32_t*>(c->extra.p); uint8_t* lens = static_cast<uint8_t*>(c->lens.p);
 		uint16_t* codes = static_cast<uint16_t*>(c->codes.p); uint32_t* fbflag = static_cast<uint32_t*>(c->fbflag.p);
 		uint32_t* fb_count = static_cast<uint32_t*>(c->fb_list.p); uint32_t* fb_list = fb_count + 16;
-		static const bool xh_lazy = [] { const char* e = getenv("MSCOMP_AMD_XH_LAZY"); return e && atoi(e) != 0; }();   // dev / measurement switch: the lazy finder of xhuff_lazy.hip
+#ifdef MSCOMP_AMD_DEV
+		static const bool xh_lazy = [] { const char* e = getenv("MSCOMP_AMD_XH_LAZY"); return e && atoi(e) != 0; }();   // measurement switch: the lazy finder of xhuff_lazy.hip
 		static const int xh_sort = [] { const char* e = getenv("MSCOMP_AMD_XH_SORT"); return e ? atoi(e) : 0; }();      // the finder of xpress_sort.hip (sorted spans instead of the chain walk)
 		if (xh_sort && !xh_lazy) {
 			{ KernelTimer t(c, "xp_sort_kernel"); launch_xp_sort(st, d_in, p->bt, links + XS_FRONT_PAD, reinterpret_cast<uint32_t*>(mlen3), reinterpret_cast<uint32_t*>(lasthead)); }
 			{ KernelTimer t(c, "xp_find2_kernel"); launch_xp_find2(st, d_in, p->bt, links + XS_FRONT_PAD, reinterpret_cast<const uint32_t*>(lasthead), reinterpret_cast<uint32_t*>(mlen3), 0xFFFFu, 1); }
-		} else {
+		} else if (xh_lazy) {
 			{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
-			if (xh_lazy) { KernelTimer t(c, "xh_lazy_kernel"); launch_xh_lazy(st, d_in, p->bt, links, lasthead, mlen3); }
-			else { KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0xFFFFu, 1); }
+			{ KernelTimer t(c, "xh_lazy_kernel"); launch_xh_lazy(st, d_in, p->bt, links, lasthead, mlen3); }
+		} else
+#endif
+		{
+			{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
+			{ KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0xFFFFu, 1); }
 		}
 		{ KernelTimer t(c, "xh_parse_kernel"); launch_xh_parse(st, d_in, p->bt, mlen3, moff, tokbits, counts, extra); }
 		{ KernelTimer t(c, "xh_huff_kernel"); launch_xh_huff(st, p->bt, counts, extra, lens, codes, slot_size, fb_list, fb_count, fbflag); }
@@ -794,8 +821,9 @@ MSCompStatus mscomp_amd_debug_huff_lengths(mscomp_amd_ctx* c, const uint32_t* h_
 	return ok ? MSCOMP_OK : MSCOMP_ERRNO;
 }
 
+int mscomp_amd_debug_hooks_enabled(void) { return test_hooks_on() ? 1 : 0; }
 // Test hook: which Xpress parse/emit kernel runs (0 = chosen by batch size, 1 = one wave per unit, 2 = four waves per unit).
-void mscomp_amd_debug_set_xpress_emit(int mode) { set_xpress_emit_mode(mode); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
+void mscomp_amd_debug_set_xpress_emit(int mode) { if (!test_hooks_on()) { return; } set_xpress_emit_mode(mode); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 // ... and which LZNT1 chunk kernel (0 = default, 1 = one wave per chunk, 2 = four waves per chunk).
 uint32_t mscomp_amd_debug_lzd_walked(mscomp_amd_ctx* c)
 {
@@ -805,8 +833,18 @@ uint32_t mscomp_amd_debug_lzd_walked(mscomp_amd_ctx* c)
 	return lzd_read_walked();
 }
 
-void mscomp_amd_set_lznt1_sa_dict(int on) { g_lznt1_sa.store(on ? 1 : 0, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
+// The LZNT1 dictionary flavour is a property of a PLAN, fixed when the plan is created (the reference fixes it when the library is built,
+// config.h:83-88): from its context's setting (mscomp_amd_ctx_set_lznt1_sa_dict) or, when the context has none, from the process default below.
+// Changing either never touches a plan that exists, so callers that run plans concurrently keep their bytes. The one-shot entries (ms_compress,
+// ms_deflate: no context argument) and the host-batch entry create their plans per call and follow the process default of that moment.
+void mscomp_amd_set_lznt1_sa_dict(int on) { g_lznt1_sa.store(on ? 1 : 0, std::memory_order_relaxed); }
 int  mscomp_amd_get_lznt1_sa_dict(void) { return g_lznt1_sa.load(std::memory_order_relaxed); }
+MSCompStatus mscomp_amd_ctx_set_lznt1_sa_dict(mscomp_amd_ctx* c, int on)
+{
+	if (!c || on < -1 || on > 1) { return MSCOMP_ARG_ERROR; }
+	c->lznt1_sa = on;
+	return MSCOMP_OK;
+}
 int mscomp_amd_debug_lzg_open(mscomp_amd_ctx* c, uint64_t words, uint32_t* out)
 {	// test hook: the open-word counters of the last lzglobal.hip run (`words` = the plan's word count: sum of capacity + 64 over the units taken)
 	if (!c || !out || !c->lzg_words.p) { return -1; }
@@ -814,13 +852,13 @@ int mscomp_amd_debug_lzg_open(mscomp_amd_ctx* c, uint64_t words, uint32_t* out)
 	if (!g.ok || hipStreamSynchronize(c->stream) != hipSuccess) { return -1; }
 	return hipMemcpy(out, static_cast<uint32_t*>(c->lzg_words.p) + words, LZG_PASSES * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
-void mscomp_amd_debug_set_xpress_decoder(int mode) { g_xpd_mode.store(mode, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
-void mscomp_amd_debug_set_finder(int mode) { g_finder_mode.store(mode, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
-void mscomp_amd_debug_set_one_shot(int mode) { g_one_zero_copy.store(mode == 1 ? 0 : 1, std::memory_order_relaxed); }
-void mscomp_amd_debug_set_lznt1(int mode) { set_lznt1_mode(mode); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
+void mscomp_amd_debug_set_xpress_decoder(int mode) { if (!test_hooks_on()) { return; } g_xpd_mode.store(mode, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
+void mscomp_amd_debug_set_finder(int mode) { if (!test_hooks_on()) { return; } g_finder_mode.store(mode, std::memory_order_relaxed); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
+void mscomp_amd_debug_set_one_shot(int mode) { if (!test_hooks_on()) { return; } g_one_zero_copy.store(mode == 1 ? 0 : 1, std::memory_order_relaxed); }
+void mscomp_amd_debug_set_lznt1(int mode) { if (!test_hooks_on()) { return; } set_lznt1_mode(mode); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 // Test hook: 1 = the order-independent form of the LZNT1 bucket sort and the Xpress chain links on every device (what a device that fails the
 // lane-order self-check gets), 0 = back to one atomic per 64 positions
-void mscomp_amd_debug_set_serial_atomics(int on) { set_serial_atomics(-1, on); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
+void mscomp_amd_debug_set_serial_atomics(int on) { if (!test_hooks_on()) { return; } set_serial_atomics(-1, on); g_mode_epoch.fetch_add(1, std::memory_order_acq_rel); }
 
 // Hardware self-check (see util.hip): lanes whose returning LDS atomic was NOT served in lane order, summed over
 // blocks x rounds x 64 lanes x {add, exchange}; 0 on gfx950. 0xFFFFFFFF = the check could not run.
@@ -875,7 +913,7 @@ struct OneShotTls {
 	MSCompStatus plan_for(MSCompFormat f, bool dec, uint64_t in_len, uint64_t out_cap, mscomp_amd_plan** out)
 	{
 		for (auto& e : plans) {
-			if (e.format == f && e.decompress == dec && e.in_len == in_len && e.out_cap == out_cap) { e.used = ++tick; *out = e.plan; return MSCOMP_OK; }
+			if (e.format == f && e.decompress == dec && e.in_len == in_len && e.out_cap == out_cap && e.plan->lznt1_sa == (!dec && f == MSCOMP_LZNT1 && lznt1_sa_for(ctx))) { e.used = ++tick; *out = e.plan; return MSCOMP_OK; }
 		}
 		const uint64_t z = 0;
 		mscomp_amd_plan* p = nullptr;

@@ -239,17 +239,20 @@ MSCompStatus run_range(Worker* w, const Job& j, size_t u0, size_t u1, bool on_ca
 			if (!sl) { fail(MSCOMP_ERRNO); return; }
 			if (!sl->reserve((size_t)b.in_total, (size_t)b.out_total, n)) { fail(MSCOMP_MEM_ERROR); return; }
 			uint8_t* d_in = static_cast<uint8_t*>(sl->d_in);
-			std::vector<void*> held;                                   // (another thread's large one-shot call may have page-locked some of these inputs: its registration must outlive our copies)
+			// (another thread's large one-shot call may have page-locked some of these inputs: its registration must outlive our copies. RAII: the
+			// references go back on EVERY way out of this iteration, a std::bad_alloc from push_back included -- ADVICE r05)
+			struct Held { std::vector<void*> v; ~Held() { drop(); } void drop() { for (void* t : v) { msc::host_pins_release(t); } v.clear(); } } held;
+			held.v.reserve(n);
 			for (size_t i = 0; i < n;) {                               // units that lie back to back in the caller's memory AND on the device go as one copy
 				size_t e = i + 1;
 				uint64_t bytes = b.in_len[i];
 				while (e < n && (b.in_len[e - 1] & 15u) == 0 && j.in_ptrs[b.b0 + e] == j.in_ptrs[b.b0 + e - 1] + b.in_len[e - 1]) { bytes += b.in_len[e]; ++e; }
-				if (bytes) { void* t = msc::host_pins_hold(j.in_ptrs[b.b0 + i], (size_t)bytes); if (t) { held.push_back(t); } }
-				if (bytes && hipMemcpyAsync(d_in + b.in_off[i], j.in_ptrs[b.b0 + i], (size_t)bytes, hipMemcpyHostToDevice, w->up) != hipSuccess) { for (void* t : held) { msc::host_pins_release(t); } fail(MSCOMP_ERRNO); return; }
+				if (bytes) { void* t = msc::host_pins_hold(j.in_ptrs[b.b0 + i], (size_t)bytes); if (t) { held.v.push_back(t); } }
+				if (bytes && hipMemcpyAsync(d_in + b.in_off[i], j.in_ptrs[b.b0 + i], (size_t)bytes, hipMemcpyHostToDevice, w->up) != hipSuccess) { fail(MSCOMP_ERRNO); return; }
 				i = e;
 			}
 			const bool up_ok = hipStreamSynchronize(w->up) == hipSuccess;
-			for (void* t : held) { msc::host_pins_release(t); }
+			held.drop();
 			if (!up_ok) { fail(MSCOMP_ERRNO); return; }
 			if (trace) { tl[k * 6 + 1] = now_ms(); }
 			{ std::lock_guard<std::mutex> lk(mu); uploaded[k] = 1; }

@@ -38,6 +38,9 @@ void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, 
 // arrays for a superset of the true token starts; the offsets of all other positions are 0.
 void launch_xp_lazy2(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, uint16_t* mlen3, uint16_t* moff);
 
+#ifdef MSCOMP_AMD_DEV
+// MEASUREMENT MODES, in the development flavour of the library only (libmscomp_amd_dev.so, `make dev`): two more Xpress+Huffman match finders that
+// give the same bytes as xp_find_kernel and lose to it. The product library has ONE finder per codec and does not contain them.
 // the lazy finder for Xpress+Huffman (xhuff_lazy.hip, round 5; a measurement mode, MSCOMP_AMD_XH_LAZY=1): the chunk's links in LDS, candidate bytes from L2
 void launch_xh_lazy(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead, uint16_t* mlen3);
 
@@ -49,6 +52,7 @@ void launch_xh_lazy(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, 
 #define XS_FRONT_PAD 32u
 void launch_xp_sort(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* sorted, uint32_t* words, uint32_t* starts);
 void launch_xp_find2(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* sorted, const uint32_t* starts, uint32_t* words, uint32_t max_off, int clip);
+#endif
 
 // ---- Xpress stream emission (xpress_emit.hip): one wavefront per unit ----
 void set_xpress_emit_mode(int mode);

@@ -39,7 +39,9 @@ __device__ unsigned long long g_lz_prof[16];
 #define LZ_TEND
 #endif
 
+#ifndef LZ_TBL_BITS
 #define LZ_TBL_BITS 11
+#endif
 #define LZ_TBL      (1u << LZ_TBL_BITS)
 #ifndef LZ_SELF
 #define LZ_SELF     4u       // candidates each lane scans by itself before the wave cooperates
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __rest
 		uint32_t segctr;                                                   // next segment to hand out
 		uint32_t total[2];
 	};
-	static_assert(sizeof(Lds) <= 20480, "eight blocks per CU");
+	static_assert(sizeof(Lds) <= (LZ_TBL_BITS == 11 ? 20480 : 27306), "eight blocks per CU (dev variants with a wider hash: six)");
 	__shared__ Lds L;
 	uint8_t* const s_data = L.data; uint16_t* const s_cnt = L.cnt; uint16_t* const s_bucket = L.bucket;
 	u64* const s_tok = L.tok; u64* const s_mat = L.mat; uint16_t* const s_endc = L.endc; uint16_t (* const s_ptok)[LZ4_MAXM] = L.ptok;

@@ -31,7 +31,9 @@ namespace msc {
 
 #define XZ_WIN   0x2000u                  // Xpress window (MaxOffset)
 #define XZ_PAD   144u                     // bytes staged behind the tile: a lane extends a capped match up to 112 + 16 bytes itself
+#ifndef XZ_LIST
 #define XZ_LIST  512u                     // parked walks (positions) of a whole unit: slots are handed out by a counter that only grows, slot i belongs to lane i
+#endif
 #define XZ_CACHE 4u                       // ends of long matches kept for the other positions inside them
 #ifndef XZ_FREP
 #define XZ_FREP 4u                        // chain candidates a lane may finish per step (the DONE / NEW blocks run once per step). Even: the two candidate register
@@ -128,6 +130,9 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 			uint4* __restrict__ moz = reinterpret_cast<uint4*>(ml.p + 2u * tb);                // words (length | offset << 16) of unvisited positions read as "no match"
 			for (uint32_t i = tid; i * 4u < ln; i += NT) { moz[i] = make_uint4(0u, 0u, 0u, 0u); }
 		}
+#ifdef XZ_FENCE   /* dev probe: the tile's cleared words are in L2 before any wave stores a match word over them */
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
 		__syncthreads();
 
 		// ---- rounds: round 0 = my segment + my parked walk; later rounds = walks parked while the tile was worked on (resume points)
@@ -243,8 +248,16 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 						// Inside a long run every segment start finds the same source at the same distance: the end of a long match is kept
 						// (start | distance << 16 | length << 32, one 64-bit LDS word per entry) and reused by every position inside it.
 						uint32_t res = 0xFFFFFFFFu;
+						// ONE lane's view of an entry, broadcast (round 6): a wave's LDS read is served in two halves of 32 lanes, and another wave's
+						// insertion can land BETWEEN them -- lanes 0-31 then held the old entry, lanes 32-63 the new one, `res` stopped being
+						// wave-uniform and the compare below ran (ballots, readlanes) for half a wave: a match end too far out, its successor never
+						// claimed, literals where the reference has a match. Found by real files (64 KiB pieces of periodic GPU code tables: 3-10 %
+						// of the units when many long matches of one distance are extended at once); tests/test_gpu_parity.py
+						// test_lazy_finder_long_match_cache_under_concurrent_insertions keeps it.
 						for (uint32_t c = 0; c < XZ_CACHE; ++c) {
-							const u64 ce = s_cache[c];
+							const u64 ce_l = s_cache[c];
+							const u64 ce = (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ce_l) |
+							               ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ce_l >> 32)) << 32);
 							const uint32_t cs = (uint32_t)ce & 0xFFFFu, cd = (uint32_t)(ce >> 16) & 0xFFFFu, cl = (uint32_t)(ce >> 32);
 							if (cd == pb - pa && pb >= cs && pb - cs < cl && cl - (pb - cs) >= from) { res = cl - (pb - cs); }
 						}

@@ -49,6 +49,12 @@ def dist_env():
 _GROUP = None          # the RCCL group the timing collectives run on when it came up on every rank (None: the gloo world group, host tensors)
 _BACKEND = None        # "nccl" | "gloo" | None (one process)
 _NOTE = None           # why gloo is in use although RCCL was asked for
+_ABANDONED = False     # an RCCL bring-up thread did not come back by its deadline and was left behind
+
+
+def abandoned_bringup():
+    """True when this process left a hung RCCL bring-up thread behind: end the process with os._exit, not through interpreter teardown."""
+    return _ABANDONED
 
 
 def backend_name():
@@ -93,11 +99,28 @@ def init_distributed(backend=None):
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         _BACKEND, _GROUP, _NOTE = "gloo", None, None
         if want_rccl:
-            ok, why, g = 1, "", None
-            try:
-                g = _rccl_group(local_rank, world)
-            except Exception as ex:                                # noqa: BLE001 -- anything: a missing backend, IPC handles, a dead link
+            # the bring-up runs in a thread of its own with a deadline: RCCL can also HANG instead of failing (seen here: two ranks on one GPU sit
+            # in communicator creation forever) -- a rank that is not through after MSCOMP_AMD_RCCL_TIMEOUT_S seconds votes "no" and the job goes on
+            # over gloo; the abandoned thread is a daemon, bench.py leaves with os._exit when sharding.abandoned_bringup() says one is left behind
+            import threading
+            global _ABANDONED
+            ok, why, g, box = 1, "", None, []
+
+            def bring_up():
+                try:
+                    box.append(_rccl_group(local_rank, world))
+                except Exception as ex:                            # noqa: BLE001 -- anything: a missing backend, IPC handles, a dead link
+                    box.append(ex)
+            th = threading.Thread(target=bring_up, name="rccl-bring-up", daemon=True)
+            th.start()
+            th.join(float(os.environ.get("MSCOMP_AMD_RCCL_TIMEOUT_S", "150")))
+            if th.is_alive():
+                ok, why, _ABANDONED = 0, "no answer after %s s" % os.environ.get("MSCOMP_AMD_RCCL_TIMEOUT_S", "150"), True
+            elif isinstance(box[0], Exception):
+                ex = box[0]
                 ok, why = 0, "%s: %s" % (type(ex).__name__, str(ex).splitlines()[0][:120] if str(ex) else "")
+            else:
+                g = box[0]
             flag = torch.tensor([ok], dtype=torch.int64)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # gloo: every rank learns whether EVERY rank has RCCL
             if int(flag.item()) == 1:

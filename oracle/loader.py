@@ -33,8 +33,11 @@ def load_oracle():
     global _oracle
     if _oracle is None:
         so = os.path.join(HERE, "liboracle.so")
-        if not os.path.exists(so):
-            build()
+        try:
+            build()                                   # (mtime check inside: a stale prebuilt library lacks newer symbols -- ADVICE r05)
+        except Exception:
+            if not os.path.exists(so):
+                raise
         lib = C.CDLL(so)
         lib.orc_compress.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
         lib.orc_compress.restype = C.c_int
@@ -57,7 +60,8 @@ def load_oracle():
         lib.orc_time_units_ex.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         lib.orc_time_units_ex.restype = C.c_double
-        lib.orc_last_busy_seconds.restype = C.c_double
+        lib.orc_time_units_ex2.argtypes = lib.orc_time_units_ex.argtypes + [C.POINTER(C.c_double)]
+        lib.orc_time_units_ex2.restype = C.c_double
         _oracle = lib
     return _oracle
 
@@ -158,9 +162,10 @@ def time_units(fn, fmt, units, caps, threads, passes):
     return dt, status, out_len
 
 
-def time_units_ex(fn, fmt, blob, in_off, in_len, caps, threads, passes, keep_output=False):
+def time_units_ex(fn, fmt, blob, in_off, in_len, caps, threads, passes, keep_output=False, busy=None):
     """time_units for units given as (offset, length) into ONE numpy uint8 array (units may alias: replicas of the same files cost no
-    memory on the input side), handed to the threads one at a time in the order given. Returns (seconds, statuses, lengths[, out, out_off])."""
+    memory on the input side), handed to the threads one at a time in the order given. Returns (seconds, statuses, lengths[, out, out_off]).
+    busy: a list that receives the thread-seconds spent inside fn during this call (its own figure: concurrent calls do not mix)."""
     import numpy as np
     lib = load_oracle()
     in_off = np.ascontiguousarray(in_off, dtype=np.uint64); in_len = np.ascontiguousarray(in_len, dtype=np.uint64)
@@ -169,8 +174,11 @@ def time_units_ex(fn, fmt, blob, in_off, in_len, caps, threads, passes, keep_out
     out = np.empty(int(out_off[-1] + caps[-1]) + 64 if len(caps) else 64, dtype=np.uint8)
     out_len = np.zeros(len(caps), dtype=np.uint64); status = np.zeros(len(caps), dtype=np.int32)
     fp = C.cast(fn, C.c_void_p) if fn is not None else None
-    dt = lib.orc_time_units_ex(fp, fmt, blob.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, len(caps), out.ctypes.data, out_off.ctypes.data,
-                               caps.ctypes.data, out_len.ctypes.data, status.ctypes.data, threads, passes)
+    b = C.c_double(0.0)
+    dt = lib.orc_time_units_ex2(fp, fmt, blob.ctypes.data, in_off.ctypes.data, in_len.ctypes.data, len(caps), out.ctypes.data, out_off.ctypes.data,
+                                caps.ctypes.data, out_len.ctypes.data, status.ctypes.data, threads, passes, C.byref(b))
+    if busy is not None:
+        busy.append(b.value)
     return (dt, status, out_len, out, out_off) if keep_output else (dt, status, out_len)
 
 

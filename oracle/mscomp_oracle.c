@@ -895,49 +895,59 @@ double orc_time_units(void* fn, int format, const uint8_t* in, const uint64_t* i
 /* The same with explicit unit lengths and one unit per grab: units may alias each other in `in` (the replicas of bench.py's
  * job are the same 12 files) and are handed out one at a time in the order given (bench.py passes whole files longest first). */
 typedef struct { int format; const uint8_t* in; const uint64_t* in_off; const uint64_t* in_len; size_t n_units; uint8_t* out; const uint64_t* out_off;
-                 const uint64_t* out_cap; uint64_t* out_len; int32_t* status; size_t next; pthread_mutex_t mu; one_shot_fn fn; } ex_job;
-/* seconds spent INSIDE fn, summed over the threads, by the last orc_time_units_ex call (all its passes): bytes x threads / this = the
- * rate the same cores would give on a queue long enough to keep every thread busy (bench.py's load-balanced CPU figure) */
-static double orc_busy_seconds;
-double orc_last_busy_seconds(void) { return orc_busy_seconds; }
+                 const uint64_t* out_cap; uint64_t* out_len; int32_t* status; size_t next; pthread_mutex_t mu; one_shot_fn fn; double busy; } ex_job;
+/* seconds spent INSIDE fn, summed over the threads and passes of ONE orc_time_units_ex2 call: bytes x threads / this = the rate the same cores
+ * would give on a queue long enough to keep every thread busy (bench.py's load-balanced CPU figure). Kept in the job and returned through an out
+ * parameter: two concurrent calls do not see each other's figure. */
 static void* ex_worker(void* arg)
 {
 	ex_job* j = (ex_job*)arg;
+	double busy = 0.0;
 	for (;;) {
 		pthread_mutex_lock(&j->mu);
 		const size_t i = j->next++;
 		pthread_mutex_unlock(&j->mu);
-		if (i >= j->n_units) { return NULL; }
+		if (i >= j->n_units) { break; }
 		size_t ol = (size_t)j->out_cap[i];
 		struct timespec a, b;
 		clock_gettime(CLOCK_MONOTONIC, &a);
 		const int st = j->fn(j->format, j->in + j->in_off[i], (size_t)j->in_len[i], j->out + j->out_off[i], &ol);
 		clock_gettime(CLOCK_MONOTONIC, &b);
 		j->status[i] = st; j->out_len[i] = st == ORC_OK ? ol : 0;
-		pthread_mutex_lock(&j->mu);
-		orc_busy_seconds += (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
-		pthread_mutex_unlock(&j->mu);
+		busy += (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
 	}
+	pthread_mutex_lock(&j->mu);
+	j->busy += busy;
+	pthread_mutex_unlock(&j->mu);
+	return NULL;
 }
-double orc_time_units_ex(void* fn, int format, const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, size_t n_units,
-                         uint8_t* out, const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status, int threads, int passes)
+double orc_time_units_ex2(void* fn, int format, const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, size_t n_units,
+                          uint8_t* out, const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status, int threads, int passes,
+                          double* busy_seconds)
 {
 	struct timespec t0, t1;
+	double busy = 0.0;
 	if (threads < 1) { threads = 1; }
 	if (threads > 256) { threads = 256; }
-	orc_busy_seconds = 0.0;
 	clock_gettime(CLOCK_MONOTONIC, &t0);
 	for (int p = 0; p < passes; ++p) {
-		ex_job f = { format, in, in_off, in_len, n_units, out, out_off, out_cap, out_len, status, 0, PTHREAD_MUTEX_INITIALIZER, fn ? (one_shot_fn)fn : (one_shot_fn)orc_compress };
+		ex_job f = { format, in, in_off, in_len, n_units, out, out_off, out_cap, out_len, status, 0, PTHREAD_MUTEX_INITIALIZER, fn ? (one_shot_fn)fn : (one_shot_fn)orc_compress, 0.0 };
 		pthread_t th[256]; pthread_attr_t at; int started = threads;
 		pthread_attr_init(&at); pthread_attr_setstacksize(&at, 8u << 20);
 		for (int t = 1; t < threads; ++t) { if (pthread_create(&th[t], &at, ex_worker, &f)) { started = t; break; } }
 		ex_worker(&f);
 		for (int t = 1; t < started; ++t) { pthread_join(th[t], NULL); }
 		pthread_attr_destroy(&at);
+		busy += f.busy;
 	}
 	clock_gettime(CLOCK_MONOTONIC, &t1);
+	if (busy_seconds) { *busy_seconds = busy; }
 	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+double orc_time_units_ex(void* fn, int format, const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, size_t n_units,
+                         uint8_t* out, const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status, int threads, int passes)
+{
+	return orc_time_units_ex2(fn, format, in, in_off, in_len, n_units, out, out_off, out_cap, out_len, status, threads, passes, NULL);
 }
 
 /* research helper (chunk-parallel Xpress-Huffman decoding): where do the chunks of a stream start? Decodes the stream

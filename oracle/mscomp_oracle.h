@@ -50,7 +50,10 @@ double orc_time_units(void* fn, int format, const uint8_t* in, const uint64_t* i
 /* The same with explicit unit lengths / capacities (units may alias each other in `in`) and ONE unit per grab, in the order given. */
 double orc_time_units_ex(void* fn, int format, const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, size_t n_units,
                          uint8_t* out, const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status, int threads, int passes);
-double orc_last_busy_seconds(void);   /* thread-seconds inside fn during the last orc_time_units_ex call */
+/* the same; *busy_seconds (may be NULL) = thread-seconds spent inside fn, summed over threads and passes of THIS call */
+double orc_time_units_ex2(void* fn, int format, const uint8_t* in, const uint64_t* in_off, const uint64_t* in_len, size_t n_units,
+                          uint8_t* out, const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status, int threads, int passes,
+                          double* busy_seconds);
 
 /* LZNT1 dictionary flavour of orc_compress (process-wide, like the reference's build switch): 0 = the default dictionary
  * (include/mscomp/LZNT1Dictionary.h), 1 = the suffix-array dictionary (MSCOMP_WITH_LZNT1_SA_DICT, include/mscomp/LZNT1Dictionary_SA.h). */

@@ -114,3 +114,32 @@ def huff_histograms(n=240, seed=11):
             c[0] = 1
         out.append(c)
     return out
+
+
+def periodic_with_mutations(n=65536, period=3756, seed=9, gap=(150, 400)):
+    """A random block of `period` bytes repeated, one byte changed every 150-400 positions: every position finds a match at distance `period`
+    (or twice that) that runs to the next change -- hundreds of matches of ONE distance, each longer than the 112 bytes a lane of the lazy Xpress
+    finder extends by itself, extended by all waves of a block at once (the shape of the real files -- 64 KiB pieces of GPU code tables --
+    on which its long-match cache gave wave-divergent answers; csrc/xpress_lazy.hip)."""
+    rnd = random.Random(seed)
+    base = bytes(rnd.getrandbits(8) for _ in range(period))
+    out = bytearray((base * (n // period + 1))[:n])
+    p = period + rnd.randint(*gap)
+    while p < n:
+        out[p] = (out[p] + 1 + rnd.getrandbits(7)) & 0xFF
+        p += rnd.randint(*gap)
+    return bytes(out)
+
+
+def few_distances(n=65536, dists=(3756, 7426, 3704, 486, 524), seed=11, run=(120, 320)):
+    """An LZ-generated stream whose copies come from a handful of distances only and run 120-320 bytes each, one fresh byte between them: the
+    greedy parse is long matches of alternating distances (what 64 KiB pieces of the GPU code tables in the image look like), so the blocks of the
+    lazy Xpress finder extend long matches of several distances at once and its 4-entry long-match cache is written and read all the time."""
+    rnd = random.Random(seed)
+    out = bytearray(rnd.getrandbits(8) for _ in range(max(dists) + 64))
+    while len(out) < n:
+        d = rnd.choice(dists)
+        for _ in range(rnd.randint(*run)):
+            out.append(out[-d])
+        out.append(rnd.getrandbits(8))
+    return bytes(out[:n])

@@ -3,6 +3,7 @@ import sys
 
 import pytest
 
+os.environ.setdefault("MSCOMP_AMD_TEST_HOOKS", "1")      # the mscomp_amd_debug_set_* kernel switches work only in processes that ask for them before the library loads
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

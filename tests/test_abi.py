@@ -199,3 +199,17 @@ def test_every_c_symbol_of_the_reference_is_exported():
     want = {s for s in syms(ref) if not s.startswith("_Z") and not s.startswith("_")}
     ours = syms(os.path.join(ROOT, "ms_compress_amd", "libmscomp_amd.so"))
     assert len(want) >= 25 and not (want - ours), sorted(want - ours)
+
+
+def test_kernel_switches_are_inert_unless_the_process_asked_for_them():
+    """mscomp_amd_debug_set_*: process-wide switches between bit-identical kernels, for tests. The library honours them only when
+    MSCOMP_AMD_TEST_HOOKS=1 was in the environment when it loaded (tests/conftest.py sets it); any other process gets no-ops."""
+    import subprocess
+    import sys
+    code = "import sys; sys.path.insert(0, %r); import ms_compress_amd as m; l = m.load_library(); l.mscomp_amd_debug_set_finder(2); print(l.mscomp_amd_debug_hooks_enabled())" % ROOT
+    for val, want in ((None, "0"), ("1", "1"), ("0", "0")):
+        env = {k: v for k, v in os.environ.items() if k != "MSCOMP_AMD_TEST_HOOKS"}
+        if val is not None:
+            env["MSCOMP_AMD_TEST_HOOKS"] = val
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == want, (val, r.stdout, r.stderr[-500:])

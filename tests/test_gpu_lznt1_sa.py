@@ -65,7 +65,7 @@ def test_corpus_golden_and_round_trip(sa_mode):
 
 
 def test_switching_back_replays_the_default_flavour(oracle, gpu_ctx):
-    """the switch is process-wide and plans notice it (mode epoch): same plan shape, other bytes, and back."""
+    """the process default is read when a plan is CREATED: same plan shape, other bytes, and back."""
     import ms_compress_amd as m
     u = [bytes(np.random.default_rng(3).choice(np.frombuffer(b"abc", np.uint8), 30000))]
     a, _ = m.compress_units(2, u, ctx=gpu_ctx)
@@ -91,3 +91,36 @@ def test_host_pointer_one_shot_calls(oracle, sa_mode):
     g = json.load(open(os.path.join(G, "corpus_full.json")))["mozilla"]
     out = m.compress(2, big)
     assert len(out) == g["lznt1_sa"]["len"] and sha(out) == g["lznt1_sa"]["sha256"]
+
+
+def test_the_flavour_belongs_to_the_plan_and_can_be_set_per_context(oracle, gpu_ctx):
+    """mscomp_amd_ctx_set_lznt1_sa_dict: two contexts of one process with different flavours; a plan created under one setting keeps its
+    bytes when the setting (its context's or the process default) changes afterwards -- nothing process-wide reaches into an existing plan."""
+    import torch
+    import ms_compress_amd as m
+    u = bytes(np.random.default_rng(5).choice(np.frombuffer(b"abcd", np.uint8), 50000))
+    want_d, want_sa = oracle.oracle_compress(2, u)[1], oracle.oracle_compress_sa(u)[1]
+    assert want_d != want_sa
+    other = m.Context()
+    other.set_lznt1_sa_dict(True)
+    try:
+        assert m.compress_units(2, [u], ctx=other)[0][0] == want_sa and m.compress_units(2, [u], ctx=gpu_ctx)[0][0] == want_d
+        # one plan, created with the flavour on, executed after every switch was flipped the other way
+        cap = m.max_compressed_size(2, len(u)) + 2
+        plan = m.Plan(other, 2, [0], [len(u)], [0], [cap])
+        other.set_lznt1_sa_dict(False)
+        other.lib.mscomp_amd_set_lznt1_sa_dict(0)
+        d_in = torch.frombuffer(bytearray(u + bytes(16)), dtype=torch.uint8).cuda()
+        d_out = torch.zeros(cap + 16, dtype=torch.uint8, device="cuda"); d_len = torch.zeros(1, dtype=torch.int64, device="cuda"); d_st = torch.zeros(1, dtype=torch.int32, device="cuda")
+        plan.execute(d_in, d_out, d_len, d_st); torch.cuda.synchronize()
+        assert bytes(d_out[: int(d_len[0])].cpu().numpy()) == want_sa
+        plan.close()
+        assert m.compress_units(2, [u], ctx=other)[0][0] == want_d                   # a NEW plan of that context follows its new setting
+        other.set_lznt1_sa_dict(None)
+        other.lib.mscomp_amd_set_lznt1_sa_dict(1)
+        try:
+            assert m.compress_units(2, [u], ctx=other)[0][0] == want_sa              # no context setting: the process default of the moment
+        finally:
+            other.lib.mscomp_amd_set_lznt1_sa_dict(0)
+    finally:
+        other.close()

@@ -405,6 +405,25 @@ def test_lazy_xpress_finder_tiles_runs_and_parked_walks(oracle, gpu_ctx):
             assert s == 0 and g == exp, "finder %d unit %d (%d bytes)" % (finder, i, len(u))
 
 
+def test_lazy_finder_long_match_cache_under_concurrent_insertions(oracle, gpu_ctx):
+    """Round 6, found by REAL files (tests/test_gpu_realdata.py: 64 KiB pieces of the GPU code tables in the image): the lazy Xpress finder keeps
+    the ends of long matches in a 4-entry cache in LDS that all waves of a block read and write. A wave's read of an entry is served in two halves
+    of 32 lanes; an insertion by another wave between the halves left the wave with two different views, its hit / miss decision stopped being
+    uniform and half a wave ran the cooperative compare -- a match end too far out, the next token start never claimed, literals where the
+    reference has a match, in 1-10 % of such units and never twice the same. The shape that does it: one period, a changed byte every 500-3000
+    positions (matches of ONE distance, hundreds to thousands of bytes long, extended by all waves at once). Many copies of such units, several
+    passes: every copy must give the oracle's bytes."""
+    import ms_compress_amd as m
+    units = [cases.periodic_with_mutations(seed=5, gap=(500, 3000)), cases.periodic_with_mutations(seed=6, period=3700, gap=(400, 2500)),
+             cases.periodic_with_mutations(seed=7, period=1878, gap=(500, 3000)), cases.periodic_with_mutations(n=50000, seed=8, period=7426, gap=(300, 2000))]
+    want = [oracle.oracle_compress(3, u)[1] for u in units]
+    for _ in range(3):
+        got, st = m.compress_units(3, [u for u in units for _ in range(160)], ctx=gpu_ctx)
+        assert all(s == 0 for s in st)
+        bad = [i for i, g in enumerate(got) if g != want[i // 160]]
+        assert not bad, "%d of %d copies differ from the oracle, first: copy %d of unit %d" % (len(bad), len(got), bad[0] % 160, bad[0] // 160)
+
+
 def _lznt1_tokens(chunk_image):
     """(position, length, offset) of every token of ONE compressed LZNT1 chunk image (lznt1_decompress.cpp:37-121); offset 0 = literal"""
     hdr = chunk_image[0] | (chunk_image[1] << 8)

@@ -114,9 +114,13 @@ def _fallback_worker(rank, world, port, q, mode):
     from ms_compress_amd import sharding
 
     def broken(local_rank, w):
+        if mode == "hang" and rank == 1:
+            import time
+            time.sleep(3600)                                      # RCCL can hang instead of failing: the deadline must catch it
         if mode == "raise" or rank == 0:
             raise RuntimeError("forced: hipIpcGetMemHandle: invalid argument")
         return dist.group.WORLD                                   # stand-in for a healthy RCCL group on the other rank
+    os.environ["MSCOMP_AMD_RCCL_TIMEOUT_S"] = "3"
     if mode != "real":
         sharding._rccl_group = broken
     r, lr, w = sharding.init_distributed("nccl")                  # ("real": no GPU here -> the genuine bring-up fails by itself)
@@ -124,6 +128,8 @@ def _fallback_worker(rank, world, port, q, mode):
     sharding.barrier()
     t, b = sharding.reduce_job(3.0 - rank, 10 + rank)
     q.put((rank, name, t, b))
+    if sharding.abandoned_bringup():
+        os._exit(0)
     dist.destroy_process_group()
 
 
@@ -131,7 +137,7 @@ def test_rccl_failure_falls_back_to_gloo_on_every_rank():
     """the first N > 1 run on RCCL is the driver's; a failing bring-up -- on all ranks or on one -- must leave a working
     gloo job whose line names the backend, not a lost scaling curve."""
     import pytest
-    for mode in ("raise", "one", "real"):
+    for mode in ("raise", "one", "hang", "real"):
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
@@ -147,6 +153,8 @@ def test_rccl_failure_falls_back_to_gloo_on_every_rank():
             assert t == 3.0 and b == 21
         if mode == "one":
             assert "here" in res[0][1] and "another rank" in res[1][1]
+        if mode == "hang":
+            assert "no answer after" in res[1][1]
 
 
 def test_backend_env_switch(monkeypatch):

@@ -6,7 +6,7 @@ R=$(cd "$(dirname "$0")/../.." && pwd)
 C=$R/ms_compress_amd/csrc
 mkdir -p $R/build
 make -C $C -j8 > /dev/null
-OBJS="api.o lznt1.o lznt1_sa.o util.o xpress_match.o xpress_sort.o xpress_lazy.o xpress_emit.o xhuff.o xhuff_lazy.o decompress.o lzglobal.o stream.o hostbatch.o"
+OBJS="api.o lznt1.o lznt1_sa.o util.o xpress_match.o xpress_lazy.o xpress_emit.o xhuff.o decompress.o lzglobal.o stream.o hostbatch.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-exceptions -Wno-unused-function $3 -c $C/$2.hip -o $R/build/$2_$1.o
 (cd $C && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/build/libmscomp_amd_$1.so ${OBJS/$2.o/$R/build/$2_$1.o})
 echo built build/libmscomp_amd_$1.so

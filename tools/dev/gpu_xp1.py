@@ -1,4 +1,5 @@
 """ONE Xpress stream per file back to bytes: time per phase (HIP events) for the files named on the command line (default mozilla)."""
+import os as _os; _os.environ.setdefault("MSCOMP_AMD_TEST_HOOKS", "1")   # (the kernel switches: csrc/api.hip test_hooks_on)
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

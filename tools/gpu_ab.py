@@ -1,6 +1,7 @@
 """Dev helper (GPU box): one codec on BASELINE configs[4] (or the 12 files alone) with the finder variant given, per-kernel ms.
     python tools/gpu_ab.py <codec> <finder mode: 1 default | 2 previous kernel> [config5|single] [steps]
 Also checks the packed output of replica 0 against tests/golden/corpus_full.json when run on the synthetic corpus (single)."""
+import os as _os; _os.environ.setdefault("MSCOMP_AMD_TEST_HOOKS", "1")   # (the kernel switches: csrc/api.hip test_hooks_on)
 import json, os, sys, hashlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

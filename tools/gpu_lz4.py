@@ -1,4 +1,5 @@
 """Dev: LZNT1 chunk kernels (1 = one wave per chunk, 2 = four waves per chunk): parity on the edge units + speed on mozilla."""
+import os as _os; _os.environ.setdefault("MSCOMP_AMD_TEST_HOOKS", "1")   # (the kernel switches: csrc/api.hip test_hooks_on)
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

@@ -1,4 +1,5 @@
 """Dev helper (GPU box): what one rank of an 8-GPU run holds (2 replicas, 424 MB), per-kernel ms next to an eighth of the whole job's."""
+import os as _os; _os.environ.setdefault("MSCOMP_AMD_TEST_HOOKS", "1")   # (the kernel switches: csrc/api.hip test_hooks_on)
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,4 +1,5 @@
 """Dev: the bench's Xpress batch (corpus cut into 64 KiB units) under every parse/emit kernel."""
+import os as _os; _os.environ.setdefault("MSCOMP_AMD_TEST_HOOKS", "1")   # (the kernel switches: csrc/api.hip test_hooks_on)
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,4 +1,5 @@
 """Dev: one big Xpress stream (whole file as ONE unit): emit kernel time, one wave vs four waves per unit."""
+import os as _os; _os.environ.setdefault("MSCOMP_AMD_TEST_HOOKS", "1")   # (the kernel switches: csrc/api.hip test_hooks_on)
 import sys, os, ctypes as C, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

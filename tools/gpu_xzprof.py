@@ -1,5 +1,6 @@
 """Dev helper (GPU box): the lazy Xpress finder per corpus member (64 KiB units): kernel ms next to the all-positions finder and,
 with a -DXZ_PROFILE build, its counters (state-machine steps, positions claimed, candidate compares, matches stored)."""
+import os as _os; _os.environ.setdefault("MSCOMP_AMD_TEST_HOOKS", "1")   # (the kernel switches: csrc/api.hip test_hooks_on)
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
