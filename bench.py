@@ -538,12 +538,13 @@ def main():
     import ms_compress_amd as m
     from ms_compress_amd import corpus, sharding
     # (MSCOMP_AMD_BENCH_BACKEND overrides; two ranks on ONE GPU cannot form an RCCL group, so the test mode asks for gloo)
-    rank, local_rank, world = sharding.init_distributed(os.environ.get("MSCOMP_AMD_BENCH_BACKEND") or ("gloo" if args.oversubscribe else None))
+    rank, local_rank, world = sharding.dist_env()
+    if args.oversubscribe:
+        local_rank %= max(1, torch.cuda.device_count())
+    rank, _, world = sharding.init_distributed(os.environ.get("MSCOMP_AMD_BENCH_BACKEND") or ("gloo" if args.oversubscribe else None), device=local_rank)
     if world != want:
         sys.exit("bench.py: --gpus %d but the launcher started %d rank(s); launch with torch.distributed.run --nproc-per-node %d "
                  "(or let bench.py spawn them: no WORLD_SIZE in the environment)" % (want, world, want))
-    if args.oversubscribe:
-        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rdev = None                                          # the timing reduction's tensors: sharding.reduce_job puts them where its backend needs them
@@ -684,9 +685,9 @@ def main():
         print(text, flush=True)
     ctx.close()
     if world > 1:
-        if sharding.abandoned_bringup():                 # a hung RCCL bring-up thread is still inside the runtime: no teardown through it
-            sys.stdout.flush(); sys.stderr.flush()
-            sharding.barrier()
+        sys.stdout.flush(); sys.stderr.flush()
+        sharding.barrier()
+        if sharding.abandoned_bringup():                 # a hung RCCL bring-up thread is still inside some rank's runtime: no teardown through it, on any rank
             os._exit(0)
         torch.distributed.destroy_process_group()
 

@@ -53,7 +53,8 @@ _ABANDONED = False     # an RCCL bring-up thread did not come back by its deadli
 
 
 def abandoned_bringup():
-    """True when this process left a hung RCCL bring-up thread behind: end the process with os._exit, not through interpreter teardown."""
+    """True when some rank of the job left a hung RCCL bring-up thread behind: every rank then ends with barrier + os._exit instead of tearing the
+    process group down (a rank that destroys it while another still sits in a collective resets that rank's connection)."""
     return _ABANDONED
 
 
@@ -79,13 +80,14 @@ def _rccl_group(local_rank, world):
     return g
 
 
-def init_distributed(backend=None):
+def init_distributed(backend=None, device=None):
     """Initialise torch.distributed when launched with WORLD_SIZE > 1. The data path has no collective; what runs over the
     process group is the barrier around the timed region and the MAX / SUM reduction of its figures. The WORLD group is always gloo (host
     tensors, 127.0.0.1 / loopback: it cannot fail for GPU reasons) and is the channel on which the ranks AGREE; on GPUs an RCCL group
     ('nccl' = RCCL on ROCm) is created beside it and proven with one all-reduce -- if that fails on ANY rank (or `backend` /
     MSCOMP_AMD_BENCH_BACKEND says "gloo") every rank stays on gloo and `backend_name()` says why. The first real N > 1 run on N GPUs is the
-    driver's: a failing RCCL bring-up must cost the line's "backend" key, not the whole scaling curve."""
+    driver's: a failing RCCL bring-up must cost the line's "backend" key, not the whole scaling curve.
+    device: this rank's GPU ordinal (default: LOCAL_RANK)."""
     global _GROUP, _BACKEND, _NOTE
     import torch
     import torch.distributed as dist
@@ -108,7 +110,7 @@ def init_distributed(backend=None):
 
             def bring_up():
                 try:
-                    box.append(_rccl_group(local_rank, world))
+                    box.append(_rccl_group(local_rank if device is None else int(device), world))
                 except Exception as ex:                            # noqa: BLE001 -- anything: a missing backend, IPC handles, a dead link
                     box.append(ex)
             th = threading.Thread(target=bring_up, name="rccl-bring-up", daemon=True)
@@ -121,9 +123,10 @@ def init_distributed(backend=None):
                 ok, why = 0, "%s: %s" % (type(ex).__name__, str(ex).splitlines()[0][:120] if str(ex) else "")
             else:
                 g = box[0]
-            flag = torch.tensor([ok], dtype=torch.int64)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # gloo: every rank learns whether EVERY rank has RCCL
-            if int(flag.item()) == 1:
+            flag = torch.tensor([ok, 0 if _ABANDONED else 1], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)            # gloo: every rank learns whether EVERY rank has RCCL -- and whether any rank left a hung thread behind
+            _ABANDONED = int(flag[1].item()) == 0                  # (then ALL ranks leave the same way: barrier, os._exit)
+            if int(flag[0].item()) == 1:
                 _GROUP, _BACKEND = g, "nccl"
             else:
                 _NOTE = "nccl failed" + (" here, " + why if not ok else " on another rank")

@@ -13,12 +13,20 @@ pytestmark = pytest.mark.gpu
 
 
 def _bench(args, env=None, timeout=900):
+    import signal
     e = dict(os.environ)
     e.update(env or {})
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    # (its own session: on a timeout the WHOLE tree goes -- the launcher's workers too, which subprocess.run's own kill would leave behind on the GPU)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        raise AssertionError("bench.py %s did not finish in %d s\n%s" % (" ".join(args), timeout, err[-2000:]))
+    assert p.returncode == 0, err[-2000:]
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
     return json.loads(lines[0])
 
 
@@ -65,14 +73,16 @@ def test_two_ranks_share_the_gpu():
 
 
 def test_rccl_that_cannot_come_up_leaves_a_gloo_job():
-    """RCCL asked for (MSCOMP_AMD_BENCH_BACKEND=nccl) with two ranks on ONE GPU -- RCCL refuses a communicator with a duplicate device --: the
-    ranks must agree on gloo, finish the job and name the backend in the line (sharding.init_distributed)."""
+    """RCCL asked for (MSCOMP_AMD_BENCH_BACKEND=nccl) with two ranks on ONE GPU -- a communicator with a duplicate device cannot come up: RCCL
+    refuses it or, as measured on this stack, never answers --: the bring-up's deadline must fire, the ranks must agree on gloo, finish the job and
+    name the backend in the line (sharding.init_distributed)."""
     import torch
     if torch.cuda.device_count() != 1:
         pytest.skip("the duplicate-device refusal needs exactly one visible GPU")
-    line = _bench(["--gpus", "2", "--oversubscribe", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-extra"], env={"MSCOMP_AMD_BENCH_BACKEND": "nccl"}, timeout=600)
+    line = _bench(["--gpus", "2", "--oversubscribe", "--steps", "1", "--warmup", "0", "--no-cpu", "--no-extra"],
+                  env={"MSCOMP_AMD_BENCH_BACKEND": "nccl", "MSCOMP_AMD_RCCL_TIMEOUT_S": "30"}, timeout=300)
     assert line["n_gpus"] == 2 and line["parity_checked"] == {"lznt1": True} and line["value"] > 0
-    assert line["config"]["backend"].startswith("gloo (nccl failed"), line["config"]["backend"]
+    assert line["config"]["backend"].startswith("gloo (nccl failed"), line["config"]["backend"]      # (failed or hung: on this stack two ranks on one GPU sit in communicator creation)
 
 
 def test_two_ranks_on_two_gpus_over_rccl():

@@ -129,6 +129,7 @@ def _fallback_worker(rank, world, port, q, mode):
     t, b = sharding.reduce_job(3.0 - rank, 10 + rank)
     q.put((rank, name, t, b))
     if sharding.abandoned_bringup():
+        q.close(); q.join_thread()                                # (the queue's feeder thread must be through before the process is cut off)
         os._exit(0)
     dist.destroy_process_group()
 

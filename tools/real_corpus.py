@@ -27,7 +27,7 @@ import numpy as np
 
 MIN_SIZE = 64 << 10
 MAX_SIZE = 128 << 20
-DEFAULT_MAX_BYTES = 1280 << 20
+DEFAULT_MAX_BYTES = 1100 << 20
 
 
 def _torch_lib():
