@@ -481,6 +481,57 @@ def end_to_end_leg(m, fmt, blob, in_off, in_len, desc, reps=3):
             "what": "mscomp_amd_compress_units_host, %s: pageable host memory in and out, wall clock, median of %d calls" % (desc, reps)}
 
 
+def real_files_leg(m, ctx, sharding, max_mb, data_dir, steps=3, cpu=True):
+    """REAL files instead of the generated corpus (tools/real_corpus.py: a deterministic list of files from this box -- ELF
+    objects, archives, GPU code tables, Python source, text -- or every file of --data-dir / SILESIA_DIR): per codec the HBM-resident rate, the
+    compression ratio, the kernels' times, the reference's CPU encoder over the same unit list on this host's threads, and the verdict of a
+    byte-for-byte comparison of EVERY unit with what that encoder wrote. Goes to bench_extra.json (`extra.real_files`), never into `value`."""
+    import torch
+    from tools import real_corpus
+    from oracle import loader
+    t0 = time.perf_counter()
+    rc = real_corpus.RealCorpus(max_mb << 20, data_dir)
+    res = {"source": rc.source, "files": len(rc.paths), "bytes": rc.total, "kinds": rc.kinds(), "largest_file": int(rc.len.max()) if len(rc.len) else 0,
+           "read_s": round(time.perf_counter() - t0, 1)}
+    dev = torch.device("cuda", ctx.device)
+    d_blob = torch.from_numpy(rc.blob).to(dev)
+    ref = loader.load_ref()
+    fn = ref.ms_compress if ref is not None else None
+    threads = max(1, min(os.cpu_count() or 1, 256))
+    for codec in ("lznt1", "xpress", "xpress_huff"):
+        fmt = m.FORMATS[codec]
+        uoff, ulen, _ = rc.units(65536 if fmt == 3 else None)
+        job = Job(m, ctx, fmt, d_blob, uoff, ulen)
+        dt, prof = timed(job, steps, 1, sharding)
+        out_bytes = job.out_bytes()
+        leg = {"MB_per_s": round(job.in_bytes * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3), "units": int(len(ulen)),
+               "what": "independent 64 KiB units" if fmt == 3 else "one unit per file", "compression_ratio": round(out_bytes / job.in_bytes, 4),
+               "kernels_ms_per_step": {k: round(v[0] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}
+        if cpu:
+            caps = np.array([loader.load_oracle().orc_max_compressed_size(fmt, int(x)) + 2 for x in ulen], np.uint64)
+            order = np.argsort(-ulen.astype(np.int64), kind="stable")
+            busy = []
+            nthr = min(threads, len(ulen))
+            cdt, st, ln, out, ooff = loader.time_units_ex(fn, fmt, rc.blob, uoff[order], ulen[order], caps[order], nthr, 1, keep_output=True, busy=busy)
+            assert bool((st == 0).all()), "the host reference reported an error status"
+            d_packed, d_poff = m.compact_batch(ctx, job.out_off, job.caps, job.d_out, job.d_len)
+            torch.cuda.synchronize()
+            poff = d_poff.cpu().numpy().astype(np.int64)
+            packed = d_packed[: int(poff[-1])].cpu().numpy()
+            same = bool(np.array_equal(np.diff(poff).astype(np.uint64)[order], ln))
+            for k, i in enumerate(order):
+                if not same:
+                    break
+                same = bool(np.array_equal(packed[int(poff[i]):int(poff[i + 1])], out[int(ooff[k]):int(ooff[k]) + int(ln[k])]))
+            leg.update({"identical_to_reference": same, "checker": "reference" if ref is not None else "port",
+                        "cpu_MB_per_s": round(job.in_bytes / cdt / 1e6, 1), "cpu_balanced_MB_per_s": round(job.in_bytes * nthr / max(sum(busy), 1e-9) / 1e6, 1), "cpu_threads": nthr})
+            if not same:
+                sys.exit("bench.py: the %s output for the real files differs from the reference's: no number is reported" % codec)
+        job.close()
+        res[codec] = leg
+    return res
+
+
 def sharded_leg(m, ctx, cor, fmt, rank, world, steps, warmup, sharding, dev):
     """One codec over the config-5 job: this rank's contiguous unit range, timed; whole-job figures by MAX / SUM over the ranks."""
     off, ln, desc = config5_units(cor, fmt)
@@ -527,6 +578,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="headline leg only")
     ap.add_argument("--config5-only", action="store_true", help="the three codecs over BASELINE configs[4], none of the other legs")
     ap.add_argument("--full", action="store_true", help="print the whole document (every leg, every kernel) instead of the short line; it is written to bench_extra.json either way")
+    ap.add_argument("--real-files", type=int, nargs="?", const=1100, default=0, metavar="MB", help="also run the three codecs over REAL files of this box (tools/real_corpus.py; "
+                    "~1.1 GB by default, read from disk: minutes on a fresh box) and compare every unit with the reference's CPU encoder; results in bench_extra.json")
+    ap.add_argument("--data-dir", default=None, help="the real-files leg over every file of this directory instead")
     ap.add_argument("--oversubscribe", action="store_true", help="TEST ONLY: let the N ranks share the visible GPUs (gloo for the timing reduction); "
                     "exercises the sharded multi-rank path on a 1-GPU box, the line is marked and is not an N-GPU measurement")
     args = ap.parse_args()
@@ -645,6 +699,8 @@ def main():
             if not args.no_cpu:
                 decf[codec]["cpu_baseline"] = cpu_decompress_baseline(f2, b2, whole=list(zip(o2, l2)))
         extra["decompress_files"] = decf
+    if world == 1 and (args.real_files or args.data_dir):
+        extra["real_files"] = real_files_leg(m, ctx, sharding, args.real_files or 1100, args.data_dir, cpu=not args.no_cpu)
     # The line the driver parses: SHORT (< 4 KB), scalars only, no sentences. Everything else -- the other legs, every kernel's time,
     # the secondary-bound counters -- goes to bench_extra.json beside this script (and gpurun_out/ when that exists, so that it travels back).
     legs = {args.codec: head}
@@ -658,6 +714,9 @@ def main():
         if cb:
             res["config"]["%s_cpu_MB_per_s" % codec] = cb["value"]
             res["config"]["%s_cpu_balanced_MB_per_s" % codec] = cb["balanced_value"]
+    if extra.get("real_files"):
+        for codec in ("lznt1", "xpress", "xpress_huff"):
+            res["config"]["%s_real_files_MB_per_s" % codec] = extra["real_files"][codec]["MB_per_s"]
     if extra.get("one_rank_of_8"):
         for codec, r in extra["one_rank_of_8"].items():
             res["config"]["%s_one_rank_of_8_rate_vs_whole_job" % codec] = r["rate_vs_whole_job_on_one_gpu"]
@@ -676,7 +735,7 @@ def main():
             line = full
         text = json.dumps(line, separators=(",", ":"))
         if not args.full and len(text) >= 4000:            # never print a line the driver cannot keep: shed the optional parts instead (bench_extra.json has them)
-            for k in [k for k in line["config"] if k.endswith(("_cpu_MB_per_s", "_cpu_balanced_MB_per_s", "_one_rank_of_8_rate_vs_whole_job", "_ms_per_step"))]:
+            for k in [k for k in line["config"] if k.endswith(("_cpu_MB_per_s", "_cpu_balanced_MB_per_s", "_one_rank_of_8_rate_vs_whole_job", "_ms_per_step", "_real_files_MB_per_s"))]:
                 del line["config"][k]
             if "cpu_baseline" in line:
                 line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:60]
