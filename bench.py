@@ -41,7 +41,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 REPLICAS = 16                # BASELINE.json configs[4]
-PROFILE_TAG = "r05"              # the committed profiles the PMC / SQ figures are looked up in; a missing file falls back to the round before and says so
+PROFILE_TAG = "r06"              # the committed profiles the PMC / SQ figures are looked up in; a missing file falls back to the round before and says so
 # the kernel SYMBOL behind the library's timer name of each codec's dominant kernel (template instance included, so that the
 # PMC figures of the Xpress and the Xpress+Huffman match finder are never mixed up)
 SYMBOLS = {
@@ -255,7 +255,7 @@ def timed(job, steps, warmup, sharding):
 # ---------------------------------------------------------------- roofline ----------------------------------------------------------------
 def _profile_doc(name):
     """(document, tag it came from): the current round's committed profile, else the round before's (and the line says which)"""
-    for tag in (PROFILE_TAG, "r04"):
+    for tag in (PROFILE_TAG, "r05"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, name)))), tag
         except Exception:

@@ -74,6 +74,34 @@ def _gpu_units(m, ctx, fmt, d_in, uoff, ulen):
     return d_packed[: int(poff[-1])].cpu().numpy(), poff, (d_out, out_off, d_len)
 
 
+def _repeat_passes(m, ctx, fmt, d_in, uoff, ulen, passes=4):
+    """The same plan executed again and again: every pass must leave EXACTLY the bytes of the first one (which the caller has compared with the
+    reference's). The kernels hand work between lanes and waves through LDS; a race there shows as a pass that differs -- on real data, at rates
+    of one unit in thousands (the long-match cache of the lazy Xpress finder, round 6) -- and never as a wrong first pass alone."""
+    import torch
+    caps = np.array([m.max_compressed_size(fmt, int(x)) + 2 for x in ulen], np.uint64)
+    out_off, out_total = m.pack_offsets(caps)
+    plan = m.Plan(ctx, fmt, uoff, ulen, out_off, caps)
+    first = None
+    for k in range(passes + 1):
+        d_out = torch.zeros(out_total + 16, dtype=torch.uint8, device=d_in.device)
+        d_len = torch.zeros(len(ulen), dtype=torch.int64, device=d_in.device)
+        d_st = torch.full((len(ulen),), -9, dtype=torch.int32, device=d_in.device)
+        plan.execute(d_in, d_out, d_len, d_st)
+        torch.cuda.synchronize()
+        assert bool((d_st == 0).all().item())
+        if first is None:
+            first = (d_out, d_len)
+        else:
+            assert bool(torch.equal(d_len, first[1])), "pass %d: a unit's compressed size changed between two passes over the same input" % k
+            if not bool(torch.equal(d_out, first[0])):
+                diff = torch.nonzero(d_out != first[0])[0].item()
+                unit = int(np.searchsorted(out_off, diff, side="right")) - 1
+                raise AssertionError("pass %d: unit %d compressed to other bytes than in the first pass" % (k, unit))
+    plan.close()
+    return first
+
+
 def _same_bytes(got, goff, want, woff, wlen, what, paths=None, idx=None):
     glen = np.diff(goff).astype(np.uint64)
     bad = np.nonzero(glen != wlen)[0]
@@ -118,6 +146,8 @@ def test_real_files_match_the_reference_encoder(oracle, gpu_ctx, real, d_blob, f
     _same_bytes(got, goff, want, woff, wlen, CODEC[fmt], real.paths, idx)
     d_back = _decoded_back(m, gpu_ctx, fmt, d_blob, uoff, ulen, dev_out)
     assert bool(torch.equal(d_back, d_blob)), "the GPU decoder did not return the files"
+    d_first, _ = _repeat_passes(m, gpu_ctx, fmt, d_blob, uoff, ulen)                       # four more passes: the same bytes every time ...
+    assert bool(torch.equal(d_first, dev_out[0])), "a second plan over the same units gave other bytes"        # ... and the bytes checked above
     _SUMMARY[CODEC[fmt]] = {"units": int(len(ulen)), "bytes": int(ulen.sum()), "compressed": int(wlen.sum()), "compression_ratio": round(float(wlen.sum()) / float(ulen.sum()), 4),
                             "checker": kind, "mismatches": 0}
 
@@ -158,3 +188,73 @@ def test_real_files_through_the_host_batch_entry(oracle, real, fmt):
     rc2, blen, bst = m.decompress_units_host(fmt, m.HostViews(out, ooff[:-1], lens), m.HostViews(back, uoff, ulen), devices=(0,))
     assert rc2 == 0 and bool((bst == 0).all()) and np.array_equal(blen, ulen)
     assert np.array_equal(back, real.blob), "the host-batch decoder did not return the files"
+
+
+def test_xpress_huff_unit_mode_and_other_kernel_paths_on_real_files(oracle, gpu_ctx, real, d_blob):
+    """The paths the default batch does not take, on the first ~200 MB of the corpus: Xpress+Huffman with every 64 KiB unit independent (each with
+    its own end-of-stream symbol); Xpress through the all-positions finder and every emit kernel (sub-batches of 512 units, as the host-batch entry
+    cuts them: four waves per unit there); LZNT1 through the one-wave-per-chunk kernel. All against the reference's bytes."""
+    import ms_compress_amd as m
+    lib = gpu_ctx.lib
+    assert lib.mscomp_amd_debug_hooks_enabled() == 1
+    uoff, ulen, idx = real.units(65536)
+    keep = int(np.searchsorted(np.cumsum(ulen), 200 << 20)) + 1
+    uoff, ulen, idx = uoff[:keep], ulen[:keep], idx[:keep]
+    want4, woff4, wlen4, _ = _reference_units(oracle, 4, real.blob, uoff, ulen)
+    got, goff, _ = _gpu_units(m, gpu_ctx, 4, d_blob, uoff, ulen)
+    _same_bytes(got, goff, want4, woff4, wlen4, "xpress_huff, 64 KiB units", real.paths, idx)
+    want3, woff3, wlen3, _ = _reference_units(oracle, 3, real.blob, uoff, ulen)
+    try:
+        for finder, emit in ((2, 0), (1, 1), (1, 2), (1, 3), (2, 4)):
+            lib.mscomp_amd_debug_set_finder(finder); lib.mscomp_amd_debug_set_xpress_emit(emit)
+            for a in range(0, len(ulen), 512):
+                b = min(a + 512, len(ulen))
+                got, goff, _ = _gpu_units(m, gpu_ctx, 3, d_blob, uoff[a:b], ulen[a:b])
+                _same_bytes(got, goff, want3, woff3[a:b], wlen3[a:b], "xpress finder %d emit %d units %d.." % (finder, emit, a), real.paths, idx[a:b])
+    finally:
+        lib.mscomp_amd_debug_set_finder(1); lib.mscomp_amd_debug_set_xpress_emit(0)
+    fo, fl, fi = real.units(None)
+    nf = int(np.searchsorted(np.cumsum(fl), 200 << 20)) + 1
+    want2, woff2, wlen2, _ = _reference_units(oracle, 2, real.blob, fo[:nf], fl[:nf])
+    lib.mscomp_amd_debug_set_lznt1(1)
+    try:
+        got, goff, _ = _gpu_units(m, gpu_ctx, 2, d_blob, fo[:nf], fl[:nf])
+    finally:
+        lib.mscomp_amd_debug_set_lznt1(0)
+    _same_bytes(got, goff, want2, woff2, wlen2, "lznt1, one wave per chunk", real.paths, fi[:nf])
+
+
+def test_drop_in_calls_and_the_sa_flavour_on_real_files(oracle, gpu_ctx, real):
+    """ms_compress / ms_decompress with HOST pointers (the reference's own entry, /root/reference/include/mscomp.h:59,79) for the largest file, a
+    mid-sized one and the smallest, all three formats; and the suffix-array dictionary flavour of LZNT1 (the reference built with
+    MSCOMP_WITH_LZNT1_SA_DICT, oracle/_ref/libMSCompression_sa.so when it travelled) over the first ~100 MB of files."""
+    import ms_compress_amd as m
+    order = np.argsort(real.len.astype(np.int64), kind="stable")
+    pick = [int(order[-1]), int(order[len(order) // 2]), int(order[0])]
+    ref = oracle.load_ref()
+    for i in pick:
+        data = real.blob[int(real.off[i]):int(real.off[i]) + int(real.len[i])].tobytes()
+        for fmt in (2, 3, 4):
+            st, want = (oracle.ref_compress(fmt, data) if ref is not None else oracle.oracle_compress(fmt, data))
+            assert st == 0
+            got = m.compress(fmt, data)
+            assert got == want, "ms_compress(%s) of %s differs from the reference's output" % (CODEC[fmt], real.paths[i])
+            assert m.decompress(fmt, got, len(data)) == data
+    sa = oracle.load_ref_sa()
+    fo, fl, fi = real.units(None)
+    nf = int(np.searchsorted(np.cumsum(fl), 100 << 20)) + 1
+    keep = [k for k in range(nf) if int(fl[k]) <= (24 << 20)]                       # (the reference's SA build runs 11-24 MB/s on a thread)
+    units = [real.blob[int(fo[k]):int(fo[k]) + int(fl[k])].tobytes() for k in keep]
+    other = m.Context()
+    other.set_lznt1_sa_dict(True)
+    try:
+        got, st = m.compress_units(2, units, ctx=other)
+    finally:
+        other.close()
+    assert all(s == 0 for s in st)
+    from concurrent.futures import ThreadPoolExecutor
+    comp = (lambda u: oracle.ref_compress_sa(u)[1]) if sa is not None else (lambda u: oracle.oracle_compress_sa(u)[1])
+    with ThreadPoolExecutor(min(64, os.cpu_count() or 1) if sa is not None else 1) as ex:      # (the restatement's flavour switch is process-wide: one thread)
+        want = list(ex.map(comp, units))
+    for k, g, w in zip(keep, got, want):
+        assert g == w, "lznt1 (suffix-array flavour) of %s differs from the reference's output" % real.paths[int(fi[k])]
