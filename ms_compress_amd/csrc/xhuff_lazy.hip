@@ -304,7 +304,8 @@ __global__ __launch_bounds__(1024) void xh_lazy_kernel(const uint8_t* __restrict
 				// length << 32) and reused by every position inside it (xpress_lazy.hip)
 				uint32_t res = 0xFFFFFFFFu;
 				for (uint32_t ci = 0; ci < XHZ_CACHE; ++ci) {
-					const u64 ce = s_cache[ci];
+					const u64 ce_l = s_cache[ci];                                           // (ONE lane's view, broadcast: see xpress_lazy.hip -- another wave's insertion between the two halves of this read made the hit / miss decision non-uniform)
+					const u64 ce = (u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ce_l) | ((u64)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ce_l >> 32)) << 32);
 					const uint32_t cs = (uint32_t)ce & 0xFFFFu, cdd = (uint32_t)(ce >> 16) & 0xFFFFu, cl = (uint32_t)(ce >> 32);
 					if (cdd == dist0 && pb >= cs && pb - cs < cl && cl - (pb - cs) >= 48u) { res = cl - (pb - cs); }
 				}
