@@ -424,6 +424,30 @@ def test_lazy_finder_long_match_cache_under_concurrent_insertions(oracle, gpu_ct
         assert not bad, "%d of %d copies differ from the oracle, first: copy %d of unit %d" % (len(bad), len(got), bad[0] % 160, bad[0] // 160)
 
 
+@pytest.mark.parametrize("fmt", [2, 3, 4])
+def test_repetitive_families_many_copies(oracle, gpu_ctx, fmt):
+    """Highly repetitive inputs -- the shapes on which waves and blocks do the most handing-over (long matches extended cooperatively, speculative
+    segments that re-synchronise late, parses that land on the same few positions) -- as many concurrent copies per batch, two passes: every copy
+    must give the oracle's bytes (a race between waves shows up in SOME copies of SOME passes; one unit alone can run clean for ever)."""
+    import random
+    import ms_compress_amd as m
+    rnd = random.Random(31)
+    noise = bytes(rnd.getrandbits(8) for _ in range(70000))
+    units = [cases.periodic_with_mutations(n=65536, period=p, seed=40 + i, gap=g) for i, (p, g) in enumerate(((1, (300, 3000)), (2, (200, 2000)), (3, (500, 2500)), (7, (100, 900)),
+                                                                                                           (64, (300, 3000)), (257, (150, 1500)), (4096, (400, 4000)), (8191, (500, 5000))))]
+    units += [cases.few_distances(seed=50, run=(600, 3000)), cases.few_distances(dists=(1, 2, 3, 4095, 4096, 4097), seed=51, run=(40, 900)),
+              cases.few_distances(dists=(8192, 8191, 8190, 16), seed=52, run=(100, 5000)), (noise[:4000] + bytes(9000)) * 5, (b"ab" * 3000 + noise[:100]) * 10]
+    if fmt != 3:
+        units += [cases.periodic_with_mutations(n=200000, period=65536, seed=60, gap=(1000, 9000)), cases.periodic_with_mutations(n=150000, period=3756, seed=61, gap=(500, 3000))]
+    want = [oracle.oracle_compress(fmt, u)[1] for u in units]
+    copies = 48
+    for _ in range(2):
+        got, st = m.compress_units(fmt, [u for u in units for _ in range(copies)], ctx=gpu_ctx)
+        assert all(s == 0 for s in st)
+        bad = [i for i, g in enumerate(got) if g != want[i // copies]]
+        assert not bad, "%d of %d copies differ from the oracle, first: copy %d of unit %d (%d bytes)" % (len(bad), len(got), bad[0] % copies, bad[0] // copies, len(units[bad[0] // copies]))
+
+
 def _lznt1_tokens(chunk_image):
     """(position, length, offset) of every token of ONE compressed LZNT1 chunk image (lznt1_decompress.cpp:37-121); offset 0 = literal"""
     hdr = chunk_image[0] | (chunk_image[1] << 8)

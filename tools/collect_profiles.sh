@@ -42,8 +42,8 @@ for codec in lznt1 xpress xpress_huff; do
 done
 # 6. the drop-in entry with host pointers (PCIe-inclusive; never `value`): one 51 MB buffer per call, all three codecs, both directions
 python tools/gpu_oneshot.py > $D/oneshot_host_pointers.txt 2>&1
-tools/dev/issue_peak > $D/issue_peak.txt 2>&1
-tools/dev/issue_peak2 > $D/issue_peak2.txt 2>&1
+[ -x tools/dev/issue_peak ] && tools/dev/issue_peak > $D/issue_peak.txt 2>&1
+[ -x tools/dev/issue_peak2 ] && tools/dev/issue_peak2 > $D/issue_peak2.txt 2>&1
 # the counter summaries go into profiles/ of THIS copy of the repository first: the bench line below attaches them (roofline.traffic / .secondary)
 python tools/update_profiles.py $D $TAG > $D/update_on_box.log 2>&1
 python bench.py 2> $D/bench.err | tail -1 > $D/bench.json
