@@ -172,7 +172,7 @@ MSCompStatus mscomp_amd_compress_units_host(MSCompFormat format, int n_dev, cons
                                             const uint8_t* const* in_ptrs, const size_t* in_lens, uint8_t* const* out_ptrs, const size_t* out_caps,
                                             size_t* out_lens, MSCompStatus* statuses);
 /* The same for the decoders: unit i is one ms_decompress call (mscomp.h:88) with *out_len = out_caps[i] on entry; statuses[i] =
- * MSCOMP_OK / MSCOMP_BUF_ERROR / MSCOMP_DATA_ERROR exactly as the reference's one-shot decoder returns them. */
+ * MSCOMP_OK / MSCOMP_BUF_ERROR / MSCOMP_DATA_ERROR exactly as the reference's one-shot decoder returns them (DESIGN_DECODERS.md). */
 MSCompStatus mscomp_amd_decompress_units_host(MSCompFormat format, int n_dev, const int* devices, size_t n_units,
                                               const uint8_t* const* in_ptrs, const size_t* in_lens, uint8_t* const* out_ptrs, const size_t* out_caps,
                                               size_t* out_lens, MSCompStatus* statuses);

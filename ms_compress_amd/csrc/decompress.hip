@@ -897,7 +897,7 @@ __global__ __launch_bounds__(64) void xpt_parse_kernel(const uint8_t* __restrict
 //            holding segments is the true parse. The FIRST of a run of segments that do not hold is walked again from the exit of the segment
 //            before it -- a segment that holds, so this is the true state -- and goes on through the run until it arrives where a later
 //            segment had landed: one round per run, whatever its length (there are stretches of 100 KB and more that no speculative walk
-//            enters: flag words 0xAAAAAAAA / 0x55555555 in a lattice of 52-54 bytes). XPS_ROUNDS rounds are launched; a segment
+//            enters: flag words 0xAAAAAAAA / 0x55555555 in a lattice of 52-54 bytes, DESIGN_DECODERS.md). XPS_ROUNDS rounds are launched; a segment
 //            behind a run may stop holding when the run's exit changes, which is what the further rounds are for.
 //   emit:    with the segments' token and byte counts summed up, every segment is walked once more from its true state, writing its tokens
 //            at their place and making the tests that need the output offset.

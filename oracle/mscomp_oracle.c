@@ -950,7 +950,7 @@ double orc_time_units_ex(void* fn, int format, const uint8_t* in, const uint64_t
 	return orc_time_units_ex2(fn, format, in, in_off, in_len, n_units, out, out_off, out_cap, out_len, status, threads, passes, NULL);
 }
 
-/* research helper (chunk-parallel Xpress-Huffman decoding): where do the chunks of a stream start? Decodes the stream
+/* research helper (DESIGN_DECODERS.md, chunk-parallel Xpress-Huffman decoding): where do the chunks of a stream start? Decodes the stream
  * (cap bytes of room) and records the input offset of every chunk's table; returns the number of chunks or a negative status. */
 long orc_xh_chunk_starts(const uint8_t* in, size_t n, size_t cap, uint64_t* starts, size_t max_starts)
 {
@@ -965,7 +965,7 @@ long orc_xh_chunk_starts(const uint8_t* in, size_t n, size_t cap, uint64_t* star
 	return st == ORC_OK ? k : st;
 }
 
-/* research helper: how long are the copy chains of a stream? depth[i] = 0 for a literal byte, else depth of its source + 1
+/* research helper (DESIGN_DECODERS.md): how long are the copy chains of a stream? depth[i] = 0 for a literal byte, else depth of its source + 1
  * (depth: cap entries). Returns the decoded length or a negative status. */
 void orc_xh_depth_first_period(int on) { orc_xh_depth_mode = on; }
 long long orc_xh_copy_depths(const uint8_t* in, size_t n, size_t cap, uint32_t* depth)
@@ -980,7 +980,7 @@ long long orc_xh_copy_depths(const uint8_t* in, size_t n, size_t cap, uint32_t* 
 	return st == ORC_OK ? (long long)len : st;
 }
 
-/* research helper: ONE chunk of an Xpress-Huffman stream, parsed without its output -- what a speculative chunk wave would
+/* research helper (DESIGN_DECODERS.md): ONE chunk of an Xpress-Huffman stream, parsed without its output -- what a speculative chunk wave would
  * compute. `at` = offset of the chunk's 256-byte table. res[0] = offset where the next chunk starts, res[1] = bytes the chunk produces,
  * res[2] = how far its matches reach in front of the chunk's first byte (max of offset - bytes produced so far, 0 if none), res[3] = tokens.
  * Returns 0 (chunk done), 1 (the stream ends here) or a negative status (bad table / bad data; capacity is not checked). */
@@ -1028,7 +1028,7 @@ int orc_xh_parse_chunk(const uint8_t* in, size_t n, size_t at, uint64_t res[4])
 	return ended;
 }
 
-/* research helper: src[i] = i for a literal byte, else the byte of the match's first period it copies (< i); out: the bytes. */
+/* research helper (DESIGN_DECODERS.md): src[i] = i for a literal byte, else the byte of the match's first period it copies (< i); out: the bytes. */
 long long orc_xh_sources(const uint8_t* in, size_t n, size_t cap, uint32_t* src, uint8_t* out)
 {
 	size_t len = cap;
