@@ -91,6 +91,7 @@ struct mscomp_amd_plan {
 	uint32_t n_units = 0, n_chunks = 0;
 	uint64_t total_in = 0, max_unit = 0;
 	bool lznt1_sa = false;                             // LZNT1: the suffix-array dictionary flavour -- fixed when the plan is created: a plan never changes its bytes under a running caller
+	bool matches_ready = false;                        // the caller has run the links + find kernels of this execution itself, range by range (the pipelined one-shot call): plan_launch skips them once
 	bool no_graph = false;                             // one-shot plans run with changing buffer addresses: a captured graph would be re-captured every time
 	DevBuf tables;                                     // in_off | out_off | chunk_prefix
 	DevBuf tokpre;                                     // decompression by tokens: first token slot | first candidate slot of every unit (2 x (n_units + 1) u64)
@@ -632,10 +633,13 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 	case MSCOMP_XPRESS: {
 		uint16_t* links = static_cast<uint16_t*>(c->links.p); uint16_t* lasthead = static_cast<uint16_t*>(c->lasthead.p);
 		uint16_t* mlen3 = static_cast<uint16_t*>(c->mlen3.p); uint16_t* moff = mlen3 + 1;   /* one word per position: length - 3 | offset << 16 (common.h S16) */
-		{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
-		// units of one link chunk: Find only where a greedy parse can start a token, window and links in LDS; longer streams: every position
-		if (g_finder_mode.load(std::memory_order_relaxed) != 2 && p->max_unit <= 65536u) { KernelTimer t(c, "xp_lazy2_kernel"); launch_xp_lazy2(st, d_in, p->bt, links, mlen3, moff); }
-		else { KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0x2000u, 0); }
+		if (p->matches_ready) { p->matches_ready = false; }
+		else {
+			{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
+			// units of one link chunk: Find only where a greedy parse can start a token, window and links in LDS; longer streams: every position
+			if (g_finder_mode.load(std::memory_order_relaxed) != 2 && p->max_unit <= 65536u) { KernelTimer t(c, "xp_lazy2_kernel"); launch_xp_lazy2(st, d_in, p->bt, links, mlen3, moff); }
+			else { KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0x2000u, 0); }
+		}
 		{ KernelTimer t(c, "xpress_emit_kernel"); launch_xpress_emit(st, d_in, p->bt, mlen3, moff, xpress_win_bufs(c, p->n_chunks), d_out, d_out_len, d_status); }
 		break;
 	}
@@ -657,7 +661,8 @@ static MSCompStatus plan_launch(mscomp_amd_plan* p, const uint8_t* d_in, uint8_t
 			{ KernelTimer t(c, "xh_lazy_kernel"); launch_xh_lazy(st, d_in, p->bt, links, lasthead, mlen3); }
 		} else
 #endif
-		{
+		if (p->matches_ready) { p->matches_ready = false; }
+		else {
 			{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links(st, d_in, p->bt, links, lasthead); }
 			{ KernelTimer t(c, "xp_find_kernel"); launch_xp_find(st, d_in, p->bt, links, lasthead, mlen3, moff, 0xFFFFu, 1); }
 		}
@@ -1036,6 +1041,8 @@ extern "C" {
 // 1.7 ms pageable); without it the copies still work.
 // Slices of about 24 MiB (6 144 chunks: three rounds of the chunk kernel's 2 048 resident blocks; with 4 MiB slices the kernels ran at a
 // third of their batch rate and the call took 4.9 instead of 2.7 ms), equal in size, at least two.
+static const size_t ONE_RANGED_MIN = [] { const char* e = getenv("MSCOMP_AMD_ONE_RANGED_MIN_MB"); const long v = e ? atol(e) : 8; return (size_t)(v >= 1 && v <= 65536 ? v : 8) << 20; }();   // Xpress / Xpress+Huffman one-shot calls from this size on go up in ranges (one_shot)
+static const uint32_t ONE_RANGE_CHUNKS = [] { const char* e = getenv("MSCOMP_AMD_ONE_RANGE_CHUNKS"); const long v = e ? atol(e) : 256; return (uint32_t)(v >= 1 && v <= 65536 ? v : 256); }();   // 64 KiB chunks per range (256 = 16 MiB; 51 MB, ms per call Xpress / Xpress+Huffman: 32: 5.22 / 5.85, 64: 4.38 / 4.99, 128: 4.04 / 4.65, 256: 3.91 / 4.55, one copy: 4.23 / 4.92)
 static const size_t ONE_SLICE = [] { const char* e = getenv("MSCOMP_AMD_ONE_SLICE_MB"); const long v = e ? atol(e) : 24; return (size_t)(v >= 1 && v <= 4096 ? v : 24) << 20; }();   // (a value that is no number of MiB in 1..4096 is ignored)
 static MSCompStatus lznt1_compress_pipelined(OneShotTls& tls, const uint8_t* in, size_t in_len, uint8_t* out, size_t* out_len)
 {
@@ -1162,13 +1169,39 @@ static MSCompStatus one_shot(MSCompFormat format, bool decompress, const uint8_t
 	uint64_t* d_len = static_cast<uint64_t*>(c->one_meta.p); int32_t* d_st = reinterpret_cast<int32_t*>(d_len + 1);
 	// (another thread's large LZNT1 call may have page-locked this very input: keep its registration alive until our copy is through)
 	struct Held { std::vector<std::pair<const uint8_t*, size_t>> v; ~Held() { if (!v.empty()) { g_pins.release(v); } } } held{ g_pins.hold(in, in_len) };
-	if (in_len && hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, c->stream) != hipSuccess) { return MSCOMP_ERRNO; }
+	// Xpress / Xpress+Huffman compression of ONE large buffer (round 6): the buffer goes up in ranges of ONE_RANGE_CHUNKS chunks
+	// on the upload stream and the match finding of a range -- chain links and Find, the two kernels that can run on part of a unit: a chunk's links
+	// and matches depend on the chunks in front of it only -- starts as soon as the range (and the 64 bytes behind it that the last positions compare
+	// into) has landed, under the upload of the next one; parse / Huffman / encode (or the Xpress emit kernels) follow over the whole buffer as
+	// before: one stream's flag words, and the place of an Xpress+Huffman chunk in the output, couple all chunks. A copy from pageable memory holds
+	// the calling thread, not the GPU, so no page-locking is needed for the overlap.
+	const bool ranged = !decompress && (format == MSCOMP_XPRESS || format == MSCOMP_XPRESS_HUFF) && in_len >= ONE_RANGED_MIN &&
+	                    g_one_zero_copy.load(std::memory_order_relaxed);      // (mscomp_amd_debug_set_one_shot(1) / MSCOMP_AMD_ONE_ZEROCOPY=0: the one-copy path, for A/B runs and tests)
+	if (!ranged && in_len && hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, c->stream) != hipSuccess) { return MSCOMP_ERRNO; }
 	struct { uint64_t len; int32_t st; int32_t pad; } meta;
-	for (;;) {
+	for (bool first = true;; first = false) {
 		if (!c->one_out.reserve(dev_cap + 64)) { return MSCOMP_MEM_ERROR; }
 		mscomp_amd_plan* p = nullptr;
 		MSCompStatus s = tls.plan_for(format, decompress, in_len, dev_cap, &p);
 		if (s != MSCOMP_OK) { return s; }
+		if (ranged && first) {
+			const uint32_t nch = p->n_chunks, nr = (nch + ONE_RANGE_CHUNKS - 1u) / ONE_RANGE_CHUNKS;
+			if (!tls.slices(nr)) { return MSCOMP_MEM_ERROR; }
+			uint16_t* links = static_cast<uint16_t*>(c->links.p); uint16_t* lasthead = static_cast<uint16_t*>(c->lasthead.p);
+			uint16_t* mlen3 = static_cast<uint16_t*>(c->mlen3.p); uint16_t* moff = mlen3 + 1;
+			const uint32_t max_off = format == MSCOMP_XPRESS ? 0x2000u : 0xFFFFu; const int clip = format == MSCOMP_XPRESS ? 0 : 1;
+			if (hipEventRecord(tls.ev[0], c->stream) != hipSuccess || hipStreamWaitEvent(tls.h2d, tls.ev[0], 0) != hipSuccess) { return MSCOMP_ERRNO; }   // (the staging buffer's last reader was on the execution stream)
+			for (uint32_t r = 0; r < nr; ++r) {
+				const uint32_t c0 = r * ONE_RANGE_CHUNKS, cnt = nch - c0 < ONE_RANGE_CHUNKS ? nch - c0 : ONE_RANGE_CHUNKS;
+				const size_t b0 = (size_t)c0 * 65536u + (r ? 64u : 0u);
+				size_t b1 = (size_t)(c0 + cnt) * 65536u + 64u; if (b1 > in_len) { b1 = in_len; }
+				if (b1 > b0 && hipMemcpyAsync(d_in + b0, in + b0, b1 - b0, hipMemcpyHostToDevice, tls.h2d) != hipSuccess) { return MSCOMP_ERRNO; }
+				if (hipEventRecord(tls.ev[1 + r], tls.h2d) != hipSuccess || hipStreamWaitEvent(c->stream, tls.ev[1 + r], 0) != hipSuccess) { return MSCOMP_ERRNO; }
+				{ KernelTimer t(c, "xp_links_kernel"); launch_xp_links_range(c->stream, d_in, p->bt, links, lasthead, c0, cnt); }
+				{ KernelTimer t(c, "xp_find_kernel"); launch_xp_find_range(c->stream, d_in, p->bt, links, lasthead, mlen3, moff, max_off, clip, c0, cnt); }
+			}
+			p->matches_ready = true;
+		}
 		s = mscomp_amd_plan_execute(p, d_in, static_cast<uint8_t*>(c->one_out.p), d_len, d_st);
 		if (s != MSCOMP_OK) { return s; }
 		if (hipMemcpyAsync(&meta, d_len, sizeof meta, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||

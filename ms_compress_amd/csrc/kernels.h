@@ -34,6 +34,10 @@ void launch_lznt1_sa_chunks(hipStream_t st, const uint8_t* d_in, const BatchTabl
 void launch_xp_links(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead);
 void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead,
                     uint16_t* mlen3, uint16_t* moff, uint32_t max_off, int clip);
+// the same over chunks [chunk_base, chunk_base + chunk_count) only (the pipelined one-shot call: a range's kernels run while the next range is on its way up)
+void launch_xp_links_range(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead, uint32_t chunk_base, uint32_t chunk_count);
+void launch_xp_find_range(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead,
+                          uint16_t* mlen3, uint16_t* moff, uint32_t max_off, int clip, uint32_t chunk_base, uint32_t chunk_count);
 // the lazy finder (xpress_lazy.hip): Find only where a greedy parse can start a token -- Xpress, every unit at most 64 KiB. Fills the same
 // arrays for a superset of the true token starts; the offsets of all other positions are 0.
 void launch_xp_lazy2(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, uint16_t* mlen3, uint16_t* moff);
@@ -62,8 +66,6 @@ struct XpressWinBufs { u64* wtok; u64* wmat; uint32_t* wfar; uint32_t* wecur; ui
                        uint32_t* sbtot; u64* sbpre; uint32_t* seam; u64* seampos; uint32_t* used; };
 void launch_xpress_emit(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* mlen3, const uint16_t* moff,
                         const XpressWinBufs& wb, uint8_t* d_out, u64* d_out_len, int32_t* d_status);
-
-void launch_xp_links_range(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* links, uint16_t* lasthead, uint32_t chunk_base, uint32_t chunk_count);
 
 // ---- Xpress+Huffman chunk pipeline (xhuff.hip) ----
 void launch_xh_parse(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* mlen3, const uint16_t* moff,

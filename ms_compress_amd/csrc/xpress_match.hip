@@ -206,7 +206,7 @@ template <uint32_t WINDOW, uint32_t LINKW, uint32_t NT, uint32_t XP_TILE>   // L
 __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                      const uint16_t* __restrict__ links, const uint16_t* __restrict__ lasthead,
                                                      S16 mlen3, S16 moff,
-                                                     uint32_t max_off, int clip)
+                                                     uint32_t max_off, int clip, uint32_t tile_base)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	uint8_t* const s_data = smem;                                             // WINDOW + XP_TILE + 64 bytes
@@ -218,6 +218,7 @@ __global__ __launch_bounds__(NT) void xp_find_kernel(const uint8_t* __restrict__
 	// across groups the chunks stay round-robin over the XCDs (cheap and expensive files are spread evenly).
 	uint32_t bid = blockIdx.x;
 	if ((bid | 127u) < gridDim.x) { const uint32_t wi = bid & 127u; bid = (bid & ~127u) + (wi & 7u) * 16u + (wi >> 3); }
+	bid += tile_base;                                                         // (a launch over a RANGE of chunks: the pipelined one-shot call, api.hip)
 	constexpr uint32_t TPC = 65536u / XP_TILE;                                // tiles per chunk
 	const uint32_t lc = bid / TPC;
 	const uint32_t tstart = (bid % TPC) * XP_TILE;                            // tile start inside the chunk
@@ -406,10 +407,10 @@ void launch_xp_links(hipStream_t st, const uint8_t* d_in, const BatchTables& bt,
 // tile = positions per block: 4096 for Xpress (4 blocks/CU), 8192 for Xpress+Huffman (the 64 KiB window is re-staged half as
 // often; 72 KiB of LDS, still 2 blocks/CU)
 #define XH_TILE_SEL 8192u
-void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead,
-                    uint16_t* mlen3, uint16_t* moff, uint32_t max_off, int clip)
+void launch_xp_find_range(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead,
+                          uint16_t* mlen3, uint16_t* moff, uint32_t max_off, int clip, uint32_t chunk_base, uint32_t chunk_count)
 {
-	if (bt.n_chunks == 0) { return; }
+	if (chunk_count == 0) { return; }
 	static PerDeviceOnce attr;
 	constexpr uint32_t TXP = 4096u, TXH = XH_TILE_SEL;
 	const uint32_t lds_xp = 0x2000u + TXP + 64u + (0x2000u + TXP) * 2u;           // data + all links of the window in LDS
@@ -421,10 +422,15 @@ void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, 
 		attr.done();
 	}
 	if (max_off <= 0x2000u) {
-		hipLaunchKernelGGL((xp_find_kernel<0x2000u, 0x2000u, 512u, TXP>), dim3(bt.n_chunks * (65536u / TXP)), dim3(512), lds_xp, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip);
+		hipLaunchKernelGGL((xp_find_kernel<0x2000u, 0x2000u, 512u, TXP>), dim3(chunk_count * (65536u / TXP)), dim3(512), lds_xp, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip, chunk_base * (65536u / TXP));
 	} else {
-		hipLaunchKernelGGL((xp_find_kernel<0x10000u, 0u, 1024u, TXH>), dim3(bt.n_chunks * (65536u / TXH)), dim3(1024), lds_xh, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip);
+		hipLaunchKernelGGL((xp_find_kernel<0x10000u, 0u, 1024u, TXH>), dim3(chunk_count * (65536u / TXH)), dim3(1024), lds_xh, st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip, chunk_base * (65536u / TXH));
 	}
+}
+void launch_xp_find(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, const uint16_t* links, const uint16_t* lasthead,
+                    uint16_t* mlen3, uint16_t* moff, uint32_t max_off, int clip)
+{
+	launch_xp_find_range(st, d_in, bt, links, lasthead, mlen3, moff, max_off, clip, 0u, bt.n_chunks);
 }
 
 } // namespace msc

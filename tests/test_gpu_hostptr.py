@@ -167,6 +167,31 @@ def test_whole_file_host_pointer_xpress_formats(gpu_ctx, fmt, key):
     assert st == m.MSCOMP_BUF_ERROR and bool((out[g["len"] - 1:] == GUARD).all())
 
 
+@pytest.mark.parametrize("fmt,key", [(3, "xpress"), (4, "xpress_huff")])
+def test_ranged_upload_of_large_xpress_calls(gpu_ctx, mozilla, fmt, key):
+    """Round 6: ms_compress(Xpress / Xpress+Huffman) of a buffer of 8 MiB or more uploads it in ranges of 256 chunks and runs the chain links and
+    Find of a range under the upload of the next (csrc/api.hip one_shot). The bytes must be the batch path's and the reference's: mozilla (51 MB, 7
+    ranges) against the reference's digest; sizes at and around the range boundaries and the switch-over size against the one-copy form of the
+    same call (mscomp_amd_debug_set_one_shot(1)) and the HBM-resident batch path."""
+    import ms_compress_amd as m
+    lib = m.load_library()
+    g = GOLD["mozilla"][key]
+    st, ol, out = _call(lib, fmt, mozilla, lib.ms_max_compressed_size(fmt, len(mozilla)), 64)
+    assert st == 0 and ol == g["len"] and sha(out[:ol]) == g["sha256"]
+    for n in ((8 << 20) - 1, 8 << 20, (8 << 20) + 1, (16 << 20) + 63, (16 << 20) + 64, (16 << 20) + 65, (24 << 20) + 65536 - 3, 30_000_001):
+        data = np.ascontiguousarray(mozilla[:n])
+        cap = lib.ms_max_compressed_size(fmt, n)
+        st, ol, out = _call(lib, fmt, data, cap, 64)
+        lib.mscomp_amd_debug_set_one_shot(1)
+        try:
+            st1, ol1, out1 = _call(lib, fmt, data, cap, 64)
+        finally:
+            lib.mscomp_amd_debug_set_one_shot(0)
+        assert st == 0 and st1 == 0 and ol == ol1 and bool((out[:ol] == out1[:ol1]).all()), "ranged and one-copy call differ at %d bytes" % n
+        got, st2 = m.compress_units(fmt, [data.tobytes()], ctx=gpu_ctx)
+        assert st2 == [0] and got[0] == out[:ol].tobytes(), "the one-shot call and the batch path differ at %d bytes" % n
+
+
 # ---- fixed-seed slices of the soaks (tools/dev/fuzz_decode.py, fuzz_big.py, fuzz_sa.py) -------------------------------------------------
 def _gen(rnd, n, kind=None):
     kind = rnd.randrange(6) if kind is None else kind
