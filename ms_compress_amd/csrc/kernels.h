@@ -23,7 +23,11 @@ bool serial_atomics_on_current_device();
 void set_serial_atomics(int device, int on);           // on: 1 = one lane at a time. device >= 0: that device's self-check verdict; device < 0: the process-wide test hook (its 0 does NOT clear a verdict)
 
 // ---- LZNT1 (lznt1.hip) ----
+#ifdef LZ_TBL_GLOBAL         /* dev variant (round 6): a 12-bit hash whose bucket-end table (8 KiB) leaves LDS after the sort -- it lies behind the chunk's image in its slot */
+#define LZNT1_SLOT (4352u + 8192u)
+#else
 #define LZNT1_SLOT 4352u     // scratch bytes per 4 KiB chunk image (2 B header + <=4096 B payload + emit slack)
+#endif
 void set_lznt1_mode(int mode);
 void launch_lznt1_chunks(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* slots, uint32_t* slot_size);
 void launch_lznt1_sa_chunks(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint8_t* slots, uint32_t* slot_size);   // lznt1_sa.hip: the suffix-array dictionary flavour

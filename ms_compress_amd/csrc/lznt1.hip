@@ -40,7 +40,11 @@ __device__ unsigned long long g_lz_prof[16];
 #endif
 
 #ifndef LZ_TBL_BITS
+#ifdef LZ_TBL_GLOBAL
+#define LZ_TBL_BITS 12
+#else
 #define LZ_TBL_BITS 11
+#endif
 #endif
 #define LZ_TBL      (1u << LZ_TBL_BITS)
 #ifndef LZ_SELF
@@ -118,8 +122,13 @@ __device__ __forceinline__ uint32_t lz_window(const uint8_t* s_data, const uint1
 		const uint32_t mask3 = (1u << shift) + 2u;
 		maxlen = (n - p < mask3) ? n - p : mask3;
 		const uint32_t h = lz_hash(o0 & 0xFFFFFFu);          // >= 1
+#ifdef LZ_TBL_GLOBAL
+		const uint32_t se = ld32(reinterpret_cast<const uint8_t*>(s_cnt + (h - 1u)));   // (the table lies in global memory here: both ends in ONE 4-byte gather)
+		s = se & 0xFFFFu; e = se >> 16;
+#else
 		e = s_cnt[h];                                          // bucket h = [end[h-1], end[h])
 		s = s_cnt[h - 1u];
+#endif
 	}
 	// 1. the oldest LZ_SELF candidates (LZNT1Dictionary.h:124-135: in order, strictly longer wins, stop at max_len). With
 	// key = (len << 12) | (4095 - q) the reference's choice is simply the MAXIMUM of the candidates' keys: longest first,
@@ -478,6 +487,29 @@ template <bool serial>
 __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __restrict__ d_in, BatchTables bt,
                                                           uint8_t* __restrict__ slots, uint32_t* __restrict__ slot_size)
 {
+#ifdef LZ_TBL_GLOBAL
+	// dev variant: 12-bit hash. 20 480 B exactly -> still 8 blocks per CU: the bucket-end table (8 KiB) shares its LDS with the parse records -- it is
+	// written to the chunk's scratch slot in global memory after the sort and looked up there by the parse (one 4-byte gather per lane and window) --
+	// the prefixes and flags of the emission take the place of the (then dead) bucket array, and the chunk has no pad behind it (a read behind the
+	// chunk falls into bucket[]: every length is capped by what the chunk has left).
+	struct __attribute__((aligned(16))) Lds {
+		uint8_t  data[4096];
+		uint16_t bucket[4096];
+		union {
+			uint16_t cnt[LZ_TBL];
+			struct { u64 tok[64], mat[64]; uint16_t endc[64]; uint16_t ptok[64][LZ4_MAXM]; uint32_t prog[LZ4_NSEG]; uint32_t used[LZ4_NSEG]; uint32_t segctr; uint32_t total[2]; } r;
+		};
+	};
+	static_assert(sizeof(Lds) <= 20480, "eight blocks per CU");
+	__shared__ Lds L;
+	uint8_t* const s_data = L.data; uint16_t* const s_cnt = L.cnt; uint16_t* const s_bucket = L.bucket;
+	u64* const s_tok = L.r.tok; u64* const s_mat = L.r.mat; uint16_t* const s_endc = L.r.endc; uint16_t (* const s_ptok)[LZ4_MAXM] = L.r.ptok;
+	uint32_t* const s_prog = L.r.prog; uint32_t* const s_used = L.r.used; uint32_t& s_segctr = L.r.segctr; uint32_t* const s_total = L.r.total;
+	uint16_t* const s_T = s_bucket;                                        // [64] tokens before window w          } after the parse (bucket[] is dead then)
+	uint16_t* const s_S = s_bucket + 64;                                   // [64] token bytes before window w     }
+	uint16_t* const s_flagpos = s_bucket + 128;                            // [512] byte position of group g's flag byte
+	uint32_t* const s_flagacc = reinterpret_cast<uint32_t*>(s_bucket + 640);   // [512] its bits
+#else
 	struct __attribute__((aligned(16))) Lds {                              // one object, the chunk first (see the kernel above); 20 432 B -> 8 blocks per CU
 		uint8_t  data[4096 + 32];
 		uint16_t bucket[4096];
@@ -500,6 +532,7 @@ __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __rest
 	uint16_t* const s_flagpos = s_cnt + 128;                               // [512] byte position of group g's flag byte
 	uint32_t* const s_flagacc = reinterpret_cast<uint32_t*>(s_cnt + 640);  // [512] its bits (LZ_TBL u16 = 4096 B >= 1280 + 2048)
 
+#endif
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 	const uint32_t c = blockIdx.x;
 	const uint32_t u = unit_of_chunk(bt.chunk_prefix, bt.n_units, c);
@@ -520,10 +553,15 @@ __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __rest
 		const uint32_t nvec = (((uintptr_t)src & 15u) == 0) ? (n & ~15u) : 0u;
 		for (uint32_t i = tid * 16u; i < nvec; i += 4096u) { *reinterpret_cast<uint4*>(s_data + i) = *reinterpret_cast<const uint4*>(src + i); }
 		for (uint32_t i = nvec + tid; i < n; i += 256u) { s_data[i] = src[i]; }
+#ifdef LZ_TBL_GLOBAL
+		for (uint32_t i = n + tid; i < 4096u; i += 256u) { s_data[i] = 0; }
+		for (uint32_t i = tid * 8u; i < LZ_TBL; i += 2048u) { *reinterpret_cast<uint4*>(s_cnt + i) = make_uint4(0, 0, 0, 0); }
+#else
 		for (uint32_t i = n + tid; i < 4096u + 32u; i += 256u) { s_data[i] = 0; }
 		for (uint32_t i = tid * 8u; i < LZ_TBL; i += 2048u) { *reinterpret_cast<uint4*>(s_cnt + i) = make_uint4(0, 0, 0, 0); }
 		if (tid < LZ4_NSEG) { s_prog[tid] = 0; s_used[tid] = 0; }
 		if (tid == 0) { s_segctr = 0; }
+#endif
 	}
 	__syncthreads();
 	LZ4_T(0)
@@ -581,6 +619,18 @@ __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __rest
 		}
 	}
 	__syncthreads();
+#ifdef LZ_TBL_GLOBAL
+	// the table leaves LDS: 8 KiB behind the chunk's image in its scratch slot (same CU writes and reads it: L2-resident), the parse records take its place
+	uint16_t* __restrict__ const g_tbl = reinterpret_cast<uint16_t*>(img + 4352u);
+	for (uint32_t i = tid * 8u; i < LZ_TBL; i += 2048u) { *reinterpret_cast<uint4*>(g_tbl + i) = *reinterpret_cast<const uint4*>(s_cnt + i); }
+	__syncthreads();
+	if (tid < LZ4_NSEG) { s_prog[tid] = 0; s_used[tid] = 0; }
+	if (tid == 0) { s_segctr = 0; }
+	__syncthreads();
+	const uint16_t* const tbl = g_tbl;
+#else
+	const uint16_t* const tbl = s_cnt;
+#endif
 	LZ4_T(1)
 
 	// ---- C1. speculative parse of my segment ------------------------------------------------------------------------
@@ -591,7 +641,7 @@ __global__ __launch_bounds__(256) void lznt1_chunk4_kernel(const uint8_t* __rest
 		const uint32_t wb_ = (w_) * 64u; const uint32_t we_ = (wb_ + 64u < n) ? wb_ + 64u : n; \
 		if ((entry_) >= we_) { if (lane == 0) { s_tok[w_] = 0; s_mat[w_] = 0; } cur_out = (entry_); } \
 		else { \
-			LzWin r_; cur_out = lz_window(s_data, s_cnt, s_bucket, n, lane, wb_, (entry_), r_); \
+			LzWin r_; cur_out = lz_window(s_data, tbl, s_bucket, n, lane, wb_, (entry_), r_); \
 			if ((r_.matchmask >> lane) & (u64)1) { \
 				const uint32_t p_ = wb_ + lane, best_ = r_.key >> 12; \
 				s_ptok[w_][popc_below(r_.matchmask)] = (uint16_t)(((p_ - (4095u - (r_.key & 0xFFFu)) - 1u) << r_.shift) | (best_ - 3u)); \
