@@ -1170,6 +1170,9 @@ int xpress_emit_mode_for(uint32_t n_units, uint32_t n_chunks)
 {
 	if (g_xpress_emit_mode) { return g_xpress_emit_mode; }
 	if ((n_units <= 64u || n_chunks >= 4u * n_units) && n_chunks <= 32768u) { return 4; }
+	// (round 6 sweep, units of 64 KiB spread over the corpus, ms per pass one wave / four waves per unit -- tools/dev/gpu_emit_sweep.py: 256 units 1.59 / 1.03,
+	// 512: 1.72 / 1.19, 768: 2.44 / 2.13, 1024: 2.64 / 2.49, 1536: 3.02 / 3.16, 2048: 3.09 / 3.22, 3239: 4.05 / 4.76, 6478: 7.25 / 8.97 -- the crossover lies
+	// between 1024 and 1536 units: four waves shorten a unit's serial chain while wave slots are free, one wave per unit wins once the CUs are full)
 	return n_units <= 1024u ? 2 : 1;
 }
 void launch_xpress_emit(hipStream_t st, const uint8_t* d_in, const BatchTables& bt, uint16_t* mlen3, const uint16_t* moff,
