@@ -1203,6 +1203,7 @@ static MSCompStatus one_shot(MSCompFormat format, bool decompress, const uint8_t
 			p->matches_ready = true;
 		}
 		s = mscomp_amd_plan_execute(p, d_in, static_cast<uint8_t*>(c->one_out.p), d_len, d_st);
+		p->matches_ready = false;                            // (a cached plan: whatever happened, its next execution finds its matches itself)
 		if (s != MSCOMP_OK) { return s; }
 		if (hipMemcpyAsync(&meta, d_len, sizeof meta, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
 		    hipStreamSynchronize(c->stream) != hipSuccess) { return MSCOMP_ERRNO; }

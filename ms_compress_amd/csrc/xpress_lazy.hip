@@ -130,9 +130,6 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 			uint4* __restrict__ moz = reinterpret_cast<uint4*>(ml.p + 2u * tb);                // words (length | offset << 16) of unvisited positions read as "no match"
 			for (uint32_t i = tid; i * 4u < ln; i += NT) { moz[i] = make_uint4(0u, 0u, 0u, 0u); }
 		}
-#ifdef XZ_FENCE   /* dev probe: the tile's cleared words are in L2 before any wave stores a match word over them */
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
 		__syncthreads();
 
 		// ---- rounds: round 0 = my segment + my parked walk; later rounds = walks parked while the tile was worked on (resume points)
