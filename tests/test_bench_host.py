@@ -57,10 +57,10 @@ def test_cpu_baseline_runs_the_legs_own_units():
 
 
 def test_the_printed_line_stays_short_and_parseable():
-    """bench.short_line on the whole document of the last profiled run (profiles/r05_bench_extra.json): what rank 0 prints must stay under 4 KB
+    """bench.short_line on the whole document of the last profiled run (profiles/r06_bench_extra.json): what rank 0 prints must stay under 4 KB
     (the driver's record keeps the last 8 KB of stdout: round 4's 20.8 KB line went unparsed), carry the contract's keys and hold no prose."""
     import json
-    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_extra.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_extra.json")))
     line = bench.short_line(full)
     text = json.dumps(line, separators=(",", ":"))
     assert len(text) < 4096 and "extra" not in line
