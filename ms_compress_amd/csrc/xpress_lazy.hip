@@ -22,7 +22,8 @@
 // XZ_FREP per step; the next candidate's bytes and link are asked for before the current one is compared) -> DONE (store, extend a capped
 // match, next position) -- and the wave runs the blocks once per step, so lanes on short chains do not wait for lanes on long ones
 // (the all-positions walk ran at 0.45 lane occupancy).
-// What is stored for a position is what xp_find_kernel stores (length capped at 48, offset); offsets of unvisited positions are 0.
+// What is stored for a position is what xp_find_kernel stores (length capped at 48, offset) -- or, for a capped match this kernel extended for its own
+// walk, the match's full length (round 6); offsets of unvisited positions are 0.
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 							st = fetch ? XZ_FIND : XZ_DONE;
 						} else {
 							if (la == 16u && l >= XZ_OWN_EXT && lim > XZ_OWN_EXT) { dl = XZ_OWN_EXT; st = XZ_COOP; }   // still equal at 112: the wave takes over
-							else { elen = l < lim ? l : lim; st = XZ_DONE2; }
+							else { elen = l < lim ? l : lim; st = XZ_DONE2; *reinterpret_cast<uint32_t*>(&ml[p]) = (elen - 3u) | ((p - x) << 16); }   // the extended match: its real length
 						}
 					}
 				}
@@ -230,9 +231,12 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 						const uint32_t bl = best >> 16;
 						if (bl >= 3u) {
 							const uint32_t dist = 0xFFFFu - (best & 0xFFFFu);
-							*reinterpret_cast<uint32_t*>(&ml[p]) = (bl - 3u) | (dist << 16);      // one word: length - 3 | offset << 16
 							XZ_CNT(3, 1)
-							if (bl >= 48u && lim > 48u && !single) { st = XZ_EXT; x = p - dist; dl = 48u; }    // how long is it really (the walk needs its end)
+							// A capped match is extended here -- the walk needs its end -- and its word leaves with the FULL length (round 6): the parse
+							// kernels take any length but 48 as final, so xpress_emit*'s walk no longer stops at every long match for a wave-wide compare
+							// from global memory (a microsecond on the serial chain of a unit, each). An all-positions sweep stores the capped length.
+							*reinterpret_cast<uint32_t*>(&ml[p]) = (bl - 3u) | (dist << 16);      // one word: length - 3 | offset << 16
+							if (bl >= 48u && lim > 48u && !single) { st = XZ_EXT; x = p - dist; dl = 48u; }    // how long is it really (the walk needs its end; the word is stored again with it)
 							else { elen = bl; st = XZ_DONE2; }
 						} else { elen = 1u; st = XZ_DONE2; }
 					}
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(TILE / SEG, WPE) void xp_lazy2_kernel(const uint8_t
 								s_cache[slot] = (u64)pb | ((u64)(pb - pa) << 16) | ((u64)res << 32);
 							}
 						}
-						if (lane == l0) { elen = res; st = XZ_DONE2; }
+						if (lane == l0) { elen = res; st = XZ_DONE2; *reinterpret_cast<uint32_t*>(&ml[p]) = (elen - 3u) | ((p - x) << 16); }
 					}
 					if (st == XZ_DONE2) {
 						const uint32_t e = p + elen;
