@@ -85,8 +85,13 @@ def select(max_bytes=DEFAULT_MAX_BYTES, data_dir=None):
 class RealCorpus:
     """The selected files in ONE numpy uint8 array (every file starts 16-byte aligned) + offsets / lengths / names."""
 
-    def __init__(self, max_bytes=DEFAULT_MAX_BYTES, data_dir=None):
+    def __init__(self, max_bytes=DEFAULT_MAX_BYTES, data_dir=None, deadline_s=None):
+        """deadline_s: stop STARTING new files that many seconds after the first (a fresh box pages its image in lazily, 4-12 MB/s in total: a test run
+        must not spend its whole time limit reading); the files read by then are the corpus, `self.cut_short` says so."""
+        import time
         sel = select(max_bytes, data_dir)
+        t_end = None if deadline_s is None else time.monotonic() + float(deadline_s)
+        self.cut_short = False
         self.source = ("dir:" + data_dir) if data_dir else ("dir:" + os.environ["SILESIA_DIR"] if os.environ.get("SILESIA_DIR") else "image files")
         offs, pos, kept = [], 0, []
         for p, s in sel:
@@ -96,6 +101,9 @@ class RealCorpus:
 
         def read(job):                                         # (a fresh box pages the image in lazily: one reader gets ~5 MB/s, so many read at once)
             (p, s), o = job
+            if t_end is not None and time.monotonic() > t_end:
+                self.cut_short = True
+                return -1
             try:
                 with open(p, "rb") as f:
                     return f.readinto(view[o:o + s])
