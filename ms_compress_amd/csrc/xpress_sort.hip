@@ -267,13 +267,14 @@ __global__ __launch_bounds__(NT) void xp_find2_kernel(const uint8_t* __restrict_
 			uint32_t A[7], B[7];
 			{
 				const uint32_t* __restrict__ pa = reinterpret_cast<const uint32_t*>(sa + (((i + 1u) & ~1u) << 1));
-				const uint4 a0 = *reinterpret_cast<const uint4*>(pa); const uint2 a1 = *reinterpret_cast<const uint2*>(pa + 4);
+				uint4 a0; uint2 a1;                                                   // (only 4-byte aligned: loads that say so -- ADVICE r05; the compiler still issues dwordx4 + dwordx2)
+				__builtin_memcpy(&a0, __builtin_assume_aligned(pa, 4), 16); __builtin_memcpy(&a1, __builtin_assume_aligned(pa + 4, 4), 8);
 				A[0] = a0.x; A[1] = a0.y; A[2] = a0.z; A[3] = a0.w; A[4] = a1.x; A[5] = a1.y; A[6] = 0u;
 			}
 			// ---- span B: the last entries of my bucket in the previous chunk's array
 			uint32_t npv = 0, eprev = 0;
 			if (k != 0 && nin < 11u) {
-				const uint2 se = *reinterpret_cast<const uint2*>(stp + h);              // start of bucket h, start of bucket h + 1 (or the total)
+				uint2 se; __builtin_memcpy(&se, __builtin_assume_aligned(stp + h, 4), 8);   // start of bucket h, start of bucket h + 1 (or the total)
 				eprev = se.y;
 				const uint32_t avail = se.y - se.x;
 				npv = (11u - nin) < avail ? (11u - nin) : avail;
@@ -281,7 +282,8 @@ __global__ __launch_bounds__(NT) void xp_find2_kernel(const uint8_t* __restrict_
 			B[0] = B[1] = B[2] = B[3] = B[4] = B[5] = 0u; B[6] = 0u;
 			if (npv) {
 				const uint32_t* __restrict__ pb = reinterpret_cast<const uint32_t*>(sb + (((eprev + 1u) & ~1u) << 1));
-				const uint4 b0 = *reinterpret_cast<const uint4*>(pb); const uint2 b1 = *reinterpret_cast<const uint2*>(pb + 4);
+				uint4 b0; uint2 b1;
+				__builtin_memcpy(&b0, __builtin_assume_aligned(pb, 4), 16); __builtin_memcpy(&b1, __builtin_assume_aligned(pb + 4, 4), 8);
 				B[0] = b0.x; B[1] = b0.y; B[2] = b0.z; B[3] = b0.w; B[4] = b1.x; B[5] = b1.y;
 			}
 			// ---- normalise: An halfword t = entry i - 11 + t (t = 0..10); the span starts at entry (i - 11) & ~1, one entry early when i is even
