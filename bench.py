@@ -528,6 +528,27 @@ def real_files_leg(m, ctx, sharding, max_mb, data_dir, steps=3, cpu=True):
             if not same:
                 sys.exit("bench.py: the %s output for the real files differs from the reference's: no number is reported" % codec)
         job.close()
+        # the same codec per KIND of file (>= 128 MB of it): how much the rate depends on what the bytes are
+        by_kind = {}
+        kof = np.array(rc.kind_of_files())
+        fo, fl, _ = rc.units(None)
+        for kind in sorted(set(kof.tolist())):
+            sel = np.nonzero(kof == kind)[0]
+            if int(fl[sel].sum()) < (128 << 20):                    # (a smaller batch measures its size, not its bytes: 38 MB run at a third of these rates)
+                continue
+            if fmt == 3:
+                ko, kl = [], []
+                for i in sel:
+                    st = np.arange(0, int(fl[i]), 65536, dtype=np.uint64)
+                    ko.append(st + fo[i]); kl.append(np.minimum(65536, int(fl[i]) - st).astype(np.uint64))
+                ko, kl = np.concatenate(ko), np.concatenate(kl)
+            else:
+                ko, kl = fo[sel], fl[sel]
+            jk = Job(m, ctx, fmt, d_blob, ko, kl)
+            tk, _ = timed(jk, 2, 1, sharding)
+            by_kind[kind] = {"MB_per_s": round(jk.in_bytes * 2 / tk / 1e6, 1), "bytes": jk.in_bytes, "compression_ratio": round(jk.out_bytes() / jk.in_bytes, 4)}
+            jk.close()
+        leg["by_kind"] = by_kind
         res[codec] = leg
     return res
 

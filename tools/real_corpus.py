@@ -142,23 +142,29 @@ class RealCorpus:
             rows.append(row)
         return rows
 
+    def kind_of_files(self):
+        """the kind of every file, in file order (the classes of kinds())"""
+        out = []
+        for p, o in zip(self.paths, self.off):
+            head = self.blob[int(o):int(o) + 8].tobytes()
+            if head[:4] == b"\x7fELF":
+                out.append("elf")
+            elif head[:8] == b"!<arch>\n":
+                out.append("ar")
+            elif p.endswith((".pyc",)):
+                out.append("pyc")
+            elif p.endswith((".py", ".txt", ".xml", ".json", ".html", ".js", ".pl", ".pm", ".h", ".hpp", ".ids", ".css", ".rst", ".md", ".cmake", ".yaml")):
+                out.append("text")
+            elif p.endswith((".dat", ".co", ".hsaco", ".kdb", ".db", ".bc")):
+                out.append("gpu code / tables")
+            else:
+                out.append("other")
+        return out
+
     def kinds(self):
         """bytes per file kind (by suffix / magic): what the corpus is made of"""
         k = {}
-        for p, o, l in zip(self.paths, self.off, self.len):
-            head = self.blob[int(o):int(o) + 8].tobytes()
-            if head[:4] == b"\x7fELF":
-                kind = "elf"
-            elif head[:8] == b"!<arch>\n":
-                kind = "ar"
-            elif p.endswith((".pyc",)):
-                kind = "pyc"
-            elif p.endswith((".py", ".txt", ".xml", ".json", ".html", ".js", ".pl", ".pm", ".h", ".hpp", ".ids", ".css", ".rst", ".md", ".cmake", ".yaml")):
-                kind = "text"
-            elif p.endswith((".dat", ".co", ".hsaco", ".kdb", ".db", ".bc")):
-                kind = "gpu code / tables"
-            else:
-                kind = "other"
+        for kind, l in zip(self.kind_of_files(), self.len):
             k[kind] = k.get(kind, 0) + int(l)
         return k
 
